@@ -1,0 +1,4 @@
+"""CPU oracle package (TEST INFRASTRUCTURE — see oracle/cchess_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""

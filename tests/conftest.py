@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def rules_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "rules.npz")))
+
+
+@pytest.fixture(scope="session")
+def mcts_golden():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "mcts.json")))
+
+
+@pytest.fixture(scope="session")
+def tables_golden():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "tables.json")))

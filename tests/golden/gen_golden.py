@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json by running the UNMODIFIED reference.
+
+Run in the build container (where /root/reference exists):
+    python tests/golden/gen_golden.py
+The reference is imported through tests/golden/ref_harness.py (stub tensorflow/uvloop,
+awaitable Semaphore; no reference source is modified or copied).  The outputs are small
+and committed, so the parity tests can run where the reference is absent (GPU box).
+
+Fixtures
+  tables.json  label-table pins (main.py:30-65, 211-217)
+  rules.npz    positions from seeded random playouts + crafted edge cases:
+               ordered get_legal_moves (main.py:743), sim_do_action (:647), is_kill_move
+               (:226), generate_inputs planes (:531); every position is also cross-checked
+               against the GUI rules (ChessBoard.py / chessman/*.py can_move) as move SETS.
+  mcts.json    MCTS_tree.main (main.py:473) runs with search_threads=1 and the exact-integer
+               fake forward of tests/fakenet.py: root children (label, N, W, Q, P bit
+               patterns), whole-tree digests, the ordered list of evaluated positions.
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import ref_harness as rh  # noqa: E402
+import fakenet  # noqa: E402
+
+PIECES = ".KARBNPCkarbnpc"
+START = "RNBAKABNR/9/1C5C1/P1P1P1P1P/9/9/p1p1p1p1p/1c5c1/9/rnbakabnr"
+
+
+def fen_to_board(fen):
+    b = np.zeros(90, np.uint8)
+    y = 0
+    for row in fen.split("/"):
+        x = 0
+        for ch in row:
+            if ch.isdigit():
+                x += int(ch)
+            else:
+                b[y * 9 + x] = PIECES.index(ch)
+                x += 1
+        assert x == 9, fen
+        y += 1
+    assert y == 10, fen
+    return b
+
+
+def f32bits(x):
+    return int(np.asarray(x, dtype=np.float32).reshape(-1)[0].view(np.uint32)) if np.ndim(x) else int(np.float32(x).view(np.uint32))
+
+
+# ----------------------------------------------------------------------------- chessman oracle
+def chessman_moves(cb_mod, fen, side):
+    """Move set according to ChessBoard.py / chessman/*.py (GUI rules)."""
+    from chessman.Bing import Bing
+    from chessman.Che import Che
+    from chessman.Ma import Ma
+    from chessman.Pao import Pao
+    from chessman.Shi import Shi
+    from chessman.Shuai import Shuai
+    from chessman.Xiang import Xiang
+    cls = {"k": Shuai, "a": Shi, "r": Che, "b": Xiang, "n": Ma, "p": Bing, "c": Pao}
+    cb_mod.ChessBoard.pieces.clear()  # class-level dict (quirk Q10)
+    board = cb_mod.ChessBoard.__new__(cb_mod.ChessBoard)
+    b = fen_to_board(fen)
+    for sq in range(90):
+        c = b[sq]
+        if not c:
+            continue
+        ch = PIECES[c]
+        x, y = sq % 9, sq // 9
+        red = ch.isupper()
+        # north_is_red=True layout: red pieces are the "north" army (ChessBoard.py:19-40)
+        cb_mod.ChessBoard.pieces[x, y] = cls[ch.lower()](x, y, red, "north" if red else "south")
+    out = set()
+    with rh.quiet():
+        for (x, y), p in list(cb_mod.ChessBoard.pieces.items()):
+            if p.is_red != (side == "w"):
+                continue
+            for (nx, ny) in p.get_move_locs(board):
+                out.add("abcdefghi"[x] + str(y) + "abcdefghi"[nx] + str(ny))
+    return out
+
+
+CRAFTED = [
+    # kings facing on an open file (flying general, main.py:1097-1107)
+    ("4K4/9/9/9/9/9/9/9/9/4k4", "w"), ("4K4/9/9/9/9/9/9/9/9/4k4", "b"),
+    ("3K5/9/9/9/9/9/9/9/9/3k5", "w"), ("5K3/9/9/9/4P4/9/9/9/9/5k3", "b"),
+    # one blocker between the kings
+    ("4K4/9/9/4P4/9/9/9/9/9/4k4", "w"), ("4K4/9/9/9/9/9/4p4/9/9/4k4", "b"),
+    # cannons: 0 / 1 / 2 screens on rank and file
+    ("4K4/9/9/9/C3p3r/9/9/9/9/4k4", "w"), ("4K4/9/9/9/C1P1p3r/9/9/9/9/4k4", "w"),
+    ("4K4/9/9/9/C1P1p1n1r/9/9/9/9/4k4", "w"), ("c3K4/9/P8/9/R8/9/9/9/9/4k4", "b"),
+    ("c3K4/P8/P8/9/R8/9/9/9/9/4k4", "b"),
+    # pawns either side of the river, on the edges
+    ("4K4/9/9/9/p7p/P7P/9/9/9/4k4", "w"), ("4K4/9/9/9/p7p/P7P/9/9/9/4k4", "b"),
+    ("4K4/9/9/9/9/9/9/9/9/P3k3P", "w"), ("p3K3p/9/9/9/9/9/9/9/9/4k4", "b"),
+    # knights with blocked legs, bishops with blocked eyes, advisors/kings at palace edges
+    ("1N2K2N1/1P5P1/9/9/9/9/9/9/9/4k4", "w"), ("N3K3N/9/9/9/9/9/9/9/1p5p1/1n2k2n1", "b"),
+    ("2B1K1B2/3P1P3/9/9/9/9/9/9/9/4k4", "w"), ("4K4/9/9/9/2B3B2/9/9/9/9/4k4", "w"),
+    ("4K4/9/9/9/9/2b3b2/9/9/9/4k4", "b"), ("3AKA3/9/9/9/9/9/9/9/4a4/3k1a3", "b"),
+    ("3K5/4A4/5A3/9/9/9/9/3a5/4a4/5k3", "w"), ("5K3/9/9/9/9/9/9/9/9/3k5", "b"),
+    # rooks on all four edges / corners
+    ("R3K3R/9/9/9/9/9/9/9/9/r3k3r", "w"), ("R3K3R/9/9/9/9/9/9/9/9/r3k3r", "b"),
+    ("4K4/9/9/9/R7r/9/9/9/9/4k4", "w"), ("4K4/9/9/9/R7r/9/9/9/9/4k4", "b"),
+    # dense middle game
+    ("R1BAKAB1R/9/1CN3NC1/P1P1P1P1P/9/9/p1p1p1p1p/1cn3nc1/9/r1bakab1r", "w"),
+    ("R1BAKAB1R/9/1CN3NC1/P1P1P1P1P/9/9/p1p1p1p1p/1cn3nc1/9/r1bakab1r", "b"),
+]
+
+
+def gen_tables(m, out):
+    la = m.labels_array
+    d = {
+        "n_labels": len(la),
+        "labels_sha256": hashlib.sha256("\n".join(la).encode()).hexdigest(),
+        "unflip_sha256": hashlib.sha256(np.asarray(m.unflipped_index, dtype=np.int16).tobytes()).hexdigest(),
+        "unflip_involution": all(m.unflipped_index[m.unflipped_index[i]] == i for i in range(len(la))),
+        "unflip_fixed_points": sum(1 for i in range(len(la)) if m.unflipped_index[i] == i),
+        "label2i": {k: m.label2i[k] for k in ["a0a1", "d7e8", "a2c4", "e0e9", "i9i0", "h7g9", "i7g9"]},
+        "first_labels": la[:12],
+        "last_labels": la[-4:],
+        "pieces_order": m.pieces_order,
+        "start_moves": m.GameBoard.get_legal_moves(START, "w"),
+        "perft": {},
+    }
+    # pseudo-legal perft: 44 / 1926 / 80288
+    def perft(state, player, depth):
+        if depth == 0:
+            return 1
+        n = 0
+        nxt = "b" if player == "w" else "w"
+        for mv in m.GameBoard.get_legal_moves(state, player):
+            n += perft(m.GameBoard.sim_do_action(mv, state), nxt, depth - 1) if depth > 1 else 1
+        return n
+    for dpt in (1, 2, 3):
+        d["perft"][str(dpt)] = perft(START, "w", dpt)
+    json.dump(d, open(os.path.join(out, "tables.json"), "w"), indent=1, sort_keys=True)
+    print("tables:", d["labels_sha256"][:12], d["perft"])
+
+
+def gen_rules(m, out, n_games=36, max_plies=110, seed=20260925):
+    rng = random.Random(seed)
+    cb_mod = rh.load_chessboard()
+    positions = []  # (fen, player)
+    king_capture_roots = []
+    for g in range(n_games):
+        state, player = START, "w"
+        for ply in range(max_plies):
+            positions.append((state, player))
+            moves = m.GameBoard.get_legal_moves(state, player)
+            if not moves:
+                break
+            # remember positions from which a king can be captured (search fixtures use them)
+            for mv in moves:
+                nxt = m.GameBoard.sim_do_action(mv, state)
+                if "K" not in nxt or "k" not in nxt:
+                    king_capture_roots.append((state, player))
+                    break
+            mv = rng.choice(moves)
+            state = m.GameBoard.sim_do_action(mv, state)
+            player = "b" if player == "w" else "w"
+            if "K" not in state or "k" not in state:
+                positions.append((state, player))  # king-less position: movegen must still agree
+                break
+    positions += CRAFTED
+    # both sides to move for a subset (movegen is defined for either player on any state)
+    extra = [(s, "b" if p == "w" else "w") for (s, p) in positions[::7]]
+    positions += extra
+
+    M = len(positions)
+    boards = np.zeros((M, 90), np.uint8)
+    side = np.zeros(M, np.uint8)
+    counts = np.zeros(M, np.uint16)
+    moves_arr = np.full((M, 128), 0xFFFF, np.uint16)
+    chosen = np.full(M, 0xFFFF, np.uint16)
+    next_boards = np.zeros((M, 90), np.uint8)
+    kill = np.zeros(M, np.int8)
+    planes_bits = np.zeros((M, 158), np.uint8)
+    mcts = rh.new_mcts(START, None, 1)
+    mismatches = 0
+    checked = 0
+    for i, (fen, pl) in enumerate(positions):
+        boards[i] = fen_to_board(fen)
+        side[i] = 1 if pl == "b" else 0
+        mv = m.GameBoard.get_legal_moves(fen, pl)
+        counts[i] = len(mv)
+        assert len(mv) <= 128
+        for j, a in enumerate(mv):
+            moves_arr[i, j] = m.label2i[a]
+        # second oracle: GUI rules as sets (positions with both kings only; Shuai logic needs pieces)
+        cm = chessman_moves(cb_mod, fen, pl)
+        checked += 1
+        if cm != set(mv):
+            mismatches += 1
+            print("chessman mismatch:", fen, pl, sorted(cm ^ set(mv)))
+        if mv:
+            a = mv[rng.randrange(len(mv))]
+            chosen[i] = m.label2i[a]
+            nxt = m.GameBoard.sim_do_action(a, fen)
+            next_boards[i] = fen_to_board(nxt)
+            kill[i] = m.is_kill_move(fen, nxt)
+        pl_planes = mcts.generate_inputs(fen, pl)
+        assert pl_planes.shape == (9, 10, 14)
+        planes_bits[i] = np.packbits(pl_planes.reshape(-1) > 0.5)
+    np.savez_compressed(os.path.join(out, "rules.npz"), boards=boards, side=side, counts=counts, moves=moves_arr,
+                        chosen=chosen, next_boards=next_boards, kill=kill, planes_bits=planes_bits,
+                        chessman_checked=np.int64(checked), chessman_mismatches=np.int64(mismatches))
+    print("rules: %d positions, avg %.1f moves, max %d; chessman set-equal: %d checked, %d mismatches" %
+          (M, counts.mean(), counts.max(), checked, mismatches))
+    return positions, king_capture_roots
+
+
+def dump_tree(node):
+    """pre-order, children in dict (= generation) order; same record as czo_search_tree_dump."""
+    rec = []
+
+    def walk(n, depth):
+        for a, c in n.child.items():
+            rec.append((depth, a, int(c.N), f32bits(c.W), f32bits(c.Q), f32bits(c.P), len(c.child) if c.child else -1))
+            walk(c, depth + 1)
+    walk(node, 0)
+    return rec
+
+
+def gen_mcts(m, out, positions, king_roots, seed=7):
+    rng = random.Random(seed)
+    cases = []
+    mid = [p for p in positions[200:2500:173]]
+    specs = [
+        dict(name="start_pos64", fen=START, player="w", rr=0, playouts=[64], mode="pos", salt=0),
+        dict(name="start_signed200", fen=START, player="w", rr=0, playouts=[200], mode="signed", salt=1),
+        dict(name="start_3plies", fen=START, player="w", rr=0, playouts=[60, 60, 60], mode="pos", salt=2),
+    ]
+    for i, (fen, pl) in enumerate(mid[:8]):
+        specs.append(dict(name="mid%d" % i, fen=fen, player=pl, rr=rng.randrange(0, 20), playouts=[100], mode="pos", salt=10 + i))
+    for i, (fen, pl) in enumerate(mid[8:12]):
+        specs.append(dict(name="mid_rr%d" % i, fen=fen, player=pl, rr=56 + i, playouts=[120, 40], mode="pos", salt=30 + i))
+    for i, (fen, pl) in enumerate(king_roots[:6]):
+        specs.append(dict(name="kingcap%d" % i, fen=fen, player=pl, rr=3, playouts=[150], mode="pos", salt=50 + i))
+    for i, (fen, pl) in enumerate(king_roots[6:9]):
+        specs.append(dict(name="kingcap_signed%d" % i, fen=fen, player=pl, rr=0, playouts=[150, 80], mode="signed", salt=70 + i))
+
+    for sp in specs:
+        log = []
+        fwd = fakenet.make_forward(sp["mode"], sp["salt"], log)
+        state, player, rr = sp["fen"], sp["player"], sp["rr"]
+        t = rh.new_mcts(state, fwd, 1)
+        plies = []
+        for po in sp["playouts"]:
+            with rh.quiet(), np.errstate(all="ignore"):
+                t.main(state, player, rr, po)
+            root_children = [(m.label2i[a], int(c.N), f32bits(c.W), f32bits(c.Q), f32bits(c.P)) for a, c in t.root.child.items()]
+            tree = dump_tree(t.root)
+            digest = hashlib.sha256(np.asarray([(d, m.label2i[a], n, w, q, p, k) for (d, a, n, w, q, p, k) in tree],
+                                               dtype=np.int64).astype(np.int32).tobytes()).hexdigest()
+            # play the most visited move (first max), like update_tree after get_action
+            best = max(t.root.child.items(), key=lambda kv: kv[1].N)[0]
+            plies.append(dict(state=state, player=player, rr=rr, playouts=po, root=root_children,
+                              tree_records=len(tree), tree_sha256=digest, played=m.label2i[best],
+                              root_N=int(t.root.N), evals=len(log)))
+            nxt = m.GameBoard.sim_do_action(best, state)
+            rr = rr + 1 if m.is_kill_move(state, nxt) == 0 else 0
+            state = nxt
+            player = "b" if player == "w" else "w"
+            t.update_tree(best)
+            if "K" not in state or "k" not in state:
+                break
+        cases.append(dict(name=sp["name"], mode=sp["mode"], salt=sp["salt"], plies=plies,
+                          eval_keys=["%016x" % k for k in log]))
+        print("mcts case %-18s plies=%d evals=%d tree=%s" % (sp["name"], len(plies), len(log), [p["tree_records"] for p in plies]))
+    json.dump(dict(numpy=np.__version__, cases=cases), open(os.path.join(out, "mcts.json"), "w"), separators=(",", ":"))
+
+
+def main():
+    m = rh.load_main()
+    out = HERE
+    gen_tables(m, out)
+    positions, king_roots = gen_rules(m, out)
+    gen_mcts(m, out, positions, king_roots)
+
+
+if __name__ == "__main__":
+    main()
