@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — MCTS simulations/sec of the MI355X hot path (select -> batched net -> expand/backup).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched through
+torch.distributed.run, one rank per GPU.  One "step" = one lock-step simulation of EVERY game tree on
+the rank (G simulations); after every `--playout` simulations the trees advance one ply
+(root-visit argmax -> cz_search_advance, the update_tree of the reference) so long runs stay in the
+self-play regime.  Rank 0 prints ONE JSON line.  Metric/config follow BASELINE.json:
+"MCTS simulations/sec (whole node), playout=1600, 7-block net", 8192 games per GPU (configs[2]).
+
+Inputs are synthetic: seeded random-playout positions generated on the GPU with the rules kernels,
+Glorot-uniform weights (seed 0).  Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense peaks, same guide
+
+START = np.array([3, 5, 4, 2, 1, 2, 4, 5, 3] + [0] * 9 + [0, 7, 0, 0, 0, 0, 0, 7, 0] + [6, 0, 6, 0, 6, 0, 6, 0, 6] + [0] * 18 +
+                 [13, 0, 13, 0, 13, 0, 13, 0, 13] + [0, 14, 0, 0, 0, 0, 0, 14, 0] + [0] * 9 + [10, 12, 11, 9, 8, 9, 11, 12, 10], np.uint8)
+
+
+def synth_positions(rules, G, seed, max_ply=80):
+    """Seeded uniform-random playouts from the start position, ply ~ U[0, max_ply] per game, all on the GPU
+    (K1 movegen -> random pick -> K2 apply).  Games whose king would be captured stop early."""
+    dev = rules.dev
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    boards = torch.from_numpy(np.tile(START, (G, 1))).to(dev)
+    side = torch.zeros(G, dtype=torch.uint8, device=dev)
+    rr = torch.zeros(G, dtype=torch.int32, device=dev)
+    target = torch.randint(0, max_ply + 1, (G,), generator=gen, device=dev)
+    alive = torch.ones(G, dtype=torch.bool, device=dev)
+    for ply in range(max_ply):
+        moves, count, _ = rules.movegen(boards, side, want_mask=False)
+        cnt = count.to(torch.int64) & 0xFFFF
+        go = alive & (target > ply) & (cnt > 0)
+        r = (torch.rand(G, generator=gen, device=dev) * cnt.clamp(min=1)).to(torch.int64).clamp(max=127)
+        pick = moves.gather(1, r.unsqueeze(1)).squeeze(1)
+        # do not play a king capture: keep both kings on the board for the search roots
+        nb, ns = boards.clone(), side.clone()
+        lab = torch.where(go, pick, torch.full_like(pick, -1))
+        cap, term = rules.apply_move(nb, ns, lab)
+        ok = go & (term == 0)
+        boards = torch.where(ok.unsqueeze(1), nb, boards)
+        side = torch.where(ok, ns, side)
+        rr = torch.where(ok, torch.where(cap != 0, torch.zeros_like(rr), rr + 1), rr)
+        alive = alive & (ok | ~go)
+    return boards.contiguous(), side.contiguous(), rr.contiguous()
+
+
+def cpu_baseline(blocks, seconds_target=15.0):
+    """CPU port timed on this host: C oracle search (oracle/) + NumPy fp32 net restatement, a bounded
+    sample of the same workload (same position generator family, playout-style lock-step).  Test
+    infrastructure used as the *baseline being measured*, never as the product path."""
+    from oracle import oracle as O
+    from oracle import net_numpy
+    from cchess_zero_amd.net import PolicyValueModule
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    cores = os.cpu_count() or 1
+    G = 16
+    rng = np.random.default_rng(0)
+    boards = np.tile(START, (G, 1))
+    side = np.zeros(G, np.uint8)
+    for g in range(G):  # short random playouts with the oracle
+        b, s = boards[g].copy(), 0
+        for _ in range(int(rng.integers(0, 60))):
+            mv = O.legal_moves(b, s)
+            if len(mv) == 0:
+                break
+            nb, cap, term = O.apply_move(b, int(mv[rng.integers(len(mv))]))
+            if term:
+                break
+            b, s = nb, s ^ 1
+        boards[g], side[g] = b, s
+    w = PolicyValueModule(blocks, seed=0).export_tf_layout()
+    s = O.Search(G, 20000)
+    s.reset(boards, side, None)
+    ctxm = threadpool_limits(limits=cores) if threadpool_limits else None
+    t0 = time.perf_counter()
+    sims = 0
+    step = 0
+    while True:
+        planes, need = s.select(0 if step == 0 else 1)
+        logits, v = net_numpy.forward(w, planes, blocks)
+        s.expand_backup(logits, v)
+        if step > 0:
+            sims += G
+        step += 1
+        if time.perf_counter() - t0 > seconds_target and step > 2:
+            break
+    dt = time.perf_counter() - t0
+    if ctxm is not None:
+        ctxm.__exit__(None, None, None)
+    return {"value": sims / dt, "unit": "sims/s", "cores": cores, "kind": "port",
+            "sample": "%d games x %d lock-step simulations, C oracle search + NumPy fp32 %d-block net, %.1f s" % (G, step - 1, blocks, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1600)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--games", type=int, default=8192, help="game trees per GPU")
+    ap.add_argument("--playout", type=int, default=1600)
+    ap.add_argument("--blocks", type=int, default=7)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    dev = torch.device("cuda", local_rank)
+
+    from cchess_zero_amd.engine import Context, SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet, flops_per_position
+    from cchess_zero_amd.rules import Rules
+
+    G, playout = args.games, args.playout
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    cap = (playout + 2) * 80
+    ctx = Context(G, cap, local_rank)
+    rules = Rules(ctx)
+    eng = SearchEngine(G, cap, local_rank, plane_dtype=torch.float32, channels=14, ctx=ctx)
+    net = PolicyValueNet(args.blocks, dev, tdt, seed=0)
+    boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
+    eng.reset(boards, side, rr)
+
+    ev_net = []  # (start, end) events around the net forward of every timed step
+
+    def one_step(mode, timed):
+        planes, _ = eng.select(mode)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        logits, value = net.forward_device(planes)
+        if timed:
+            e1.record()
+            ev_net.append((e0, e1))
+        eng.expand_backup(logits, value)
+
+    def advance_ply():
+        st = eng.root_stats()
+        n = st["N"].clone()
+        cnt = (st["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
+        n[torch.arange(128, device=dev).unsqueeze(0) >= cnt] = -1
+        best = n.argmax(dim=1, keepdim=True)
+        played = st["label"].gather(1, best).squeeze(1)
+        eng.advance(played)
+        one_step(0, False)  # expand roots that were never visited
+
+    sims_in_ply = 0
+
+    def run(nsteps, timed):
+        nonlocal sims_in_ply
+        for _ in range(nsteps):
+            if sims_in_ply >= playout:
+                advance_ply()
+                sims_in_ply = 0
+            one_step(1, timed)
+            sims_in_ply += 1
+
+    one_step(0, False)          # MCTS_tree.main root expansion (not a simulation)
+    run(args.warmup, False)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    st, nodes, sims, depth = eng.status()
+    bad = int((st & ~8).ne(0).sum().item())
+    st_bits = {name: int(((st & bit) != 0).sum().item()) for name, bit in
+               (("pool_exhausted", 1), ("no_moves", 2), ("move_overflow", 4), ("bad_advance", 8))}
+    net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net])) if ev_net else float("nan")
+    total_sims = float(G) * args.steps * world
+    flops = flops_per_position(args.blocks) * G
+    achieved = flops / (net_ms * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    out = {
+        "metric": "MCTS simulations/sec (whole node), playout=%d, %d-block net" % (playout, args.blocks),
+        "value": total_sims / dt, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (BASELINE.json configs[2])" % (G, playout, args.blocks, args.dtype),
+                   "games_per_gpu": G, "playout": playout, "res_block_nums": args.blocks, "search_threads": 1,
+                   "positions": "seeded random playouts from the start position, ply~U[0,80]",
+                   "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),
+                   "trees_with_error_status": bad, "status_bits": st_bits},
+        "roofline": {"bound": "mfma", "kernel": "net forward (conv tower + heads), all launches of one step",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "ms_per_launch_group": net_ms, "flops_per_step": flops},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.blocks, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

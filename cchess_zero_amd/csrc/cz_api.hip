@@ -1,0 +1,281 @@
+// cz_api.hip — the extern "C" boundary of libcchess_hip.so (declared in include/cchess_hip.h).
+#include "cz_internal.h"
+
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void cz_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// carve helper over one device allocation
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T> T *take(size_t n) {
+        T *p = base ? (T *)(base + off) : nullptr;
+        off = align_up(off + n * sizeof(T));
+        return p;
+    }
+};
+
+void carve_pool(Carver &c, CzPool &p, size_t n) {
+    p.P = c.take<float>(n); p.W = c.take<float>(n); p.Q = c.take<float>(n);
+    p.N = c.take<int32_t>(n); p.parent = c.take<int32_t>(n); p.child_begin = c.take<int32_t>(n);
+    p.child_count = c.take<uint16_t>(n); p.move = c.take<uint16_t>(n);
+}
+
+void carve_trees(Carver &c, CzTrees &t, size_t G) {
+    t.cur = c.take<int32_t>(G);
+    t.root_board = c.take<uint8_t>(G * CZD_BOARD_LDS);
+    t.root_side = c.take<uint8_t>(G);
+    t.root_rr = c.take<int32_t>(G); t.root_node = c.take<int32_t>(G); t.n_nodes = c.take<int32_t>(G);
+    t.status = c.take<int32_t>(G); t.sims = c.take<int32_t>(G); t.last_depth = c.take<int32_t>(G);
+    t.pend_kind = c.take<int32_t>(G); t.pend_leaf = c.take<int32_t>(G);
+    t.pend_value = c.take<float>(G);
+    t.pend_side = c.take<uint8_t>(G);
+    t.pend_nmoves = c.take<uint16_t>(G);
+    t.pend_moves = c.take<uint16_t>(G * CZD_MAXMOVES);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cz_last_error(void) { return g_err; }
+int cz_version(void) { return 100; }
+
+int cz_tables(const int16_t **lut, const int16_t **unflip, const char **labels, const uint16_t **srcdst) {
+    const CzHostTables &t = cz_host_tables();
+    if (lut) *lut = t.lut;
+    if (unflip) *unflip = t.unflip;
+    if (labels) *labels = t.labels;
+    if (srcdst) *srcdst = t.srcdst;
+    return CZ_OK;
+}
+
+int cz_zobrist(const uint64_t **keys, uint64_t *side_key) {
+    const CzHostTables &t = cz_host_tables();
+    if (keys) *keys = t.zob;
+    if (side_key) *side_key = t.zob[15 * CZ_NSQ];
+    return CZ_OK;
+}
+
+int cz_create(int device, int max_games, int max_nodes_per_tree, cz_ctx **out) {
+    CZ_REQUIRE(out != nullptr, "cz_create: out is NULL");
+    CZ_REQUIRE(max_games > 0 && max_nodes_per_tree >= 2, "cz_create: max_games > 0 and max_nodes_per_tree >= 2 required");
+    int ndev = 0;
+    CZ_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { cz_set_error("cz_create: device %d not available (%d HIP devices)", device, ndev); return CZ_EINVAL; }
+    CZ_HIP(hipSetDevice(device));
+    cz_ctx *c = new cz_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device; c->stream = nullptr; c->max_games = max_games; c->cap = max_nodes_per_tree; c->G = 0;
+
+    // tables
+    const CzHostTables &ht = cz_host_tables();
+    {
+        Carver m{nullptr};
+        m.take<int16_t>(CZ_NSQ * CZ_NSQ); m.take<int16_t>(CZ_NLABELS); m.take<uint16_t>(CZ_NLABELS); m.take<uint64_t>(15 * CZ_NSQ + 1);
+        if (hipMalloc(&c->tab_block, m.off) != hipSuccess) { cz_set_error("cz_create: hipMalloc(tables) failed"); delete c; return CZ_ENOMEM; }
+        Carver k{(char *)c->tab_block};
+        int16_t *lut = k.take<int16_t>(CZ_NSQ * CZ_NSQ);
+        int16_t *unf = k.take<int16_t>(CZ_NLABELS);
+        uint16_t *sd = k.take<uint16_t>(CZ_NLABELS);
+        uint64_t *zb = k.take<uint64_t>(15 * CZ_NSQ + 1);
+        CZ_HIP(hipMemcpy(lut, ht.lut, sizeof(ht.lut), hipMemcpyHostToDevice));
+        CZ_HIP(hipMemcpy(unf, ht.unflip, sizeof(ht.unflip), hipMemcpyHostToDevice));
+        CZ_HIP(hipMemcpy(sd, ht.srcdst, sizeof(ht.srcdst), hipMemcpyHostToDevice));
+        CZ_HIP(hipMemcpy(zb, ht.zob, sizeof(ht.zob), hipMemcpyHostToDevice));
+        c->tab.lut = lut; c->tab.unflip = unf; c->tab.srcdst = sd; c->tab.zob = zb;
+    }
+    // per-tree arrays
+    {
+        Carver m{nullptr};
+        CzTrees dummy;
+        carve_trees(m, dummy, (size_t)max_games);
+        if (hipMalloc(&c->tree_block, m.off) != hipSuccess) { cz_set_error("cz_create: hipMalloc(trees, %zu B) failed", m.off); cz_destroy(c); return CZ_ENOMEM; }
+        CZ_HIP(hipMemset(c->tree_block, 0, m.off));
+        Carver k{(char *)c->tree_block};
+        carve_trees(k, c->t, (size_t)max_games);
+        c->t.cap = max_nodes_per_tree;
+    }
+    // node pools (live + compaction target)
+    const size_t n = (size_t)max_games * (size_t)max_nodes_per_tree;
+    for (int w = 0; w < 2; ++w) {
+        Carver m{nullptr};
+        CzPool dummy;
+        carve_pool(m, dummy, n);
+        if (hipMalloc(&c->pool_block[w], m.off) != hipSuccess) {
+            cz_set_error("cz_create: hipMalloc(node pool %d, %zu B) failed", w, m.off);
+            cz_destroy(c);
+            return CZ_ENOMEM;
+        }
+        Carver k{(char *)c->pool_block[w]};
+        carve_pool(k, c->t.pool[w], n);
+    }
+    *out = c;
+    return CZ_OK;
+}
+
+void cz_destroy(cz_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->tab_block) (void)hipFree(c->tab_block);
+    if (c->tree_block) (void)hipFree(c->tree_block);
+    for (int w = 0; w < 2; ++w)
+        if (c->pool_block[w]) (void)hipFree(c->pool_block[w]);
+    delete c;
+}
+
+int cz_set_stream(cz_ctx *c, void *s) {
+    CZ_REQUIRE(c, "null ctx");
+    c->stream = (hipStream_t)s;
+    return CZ_OK;
+}
+
+int cz_synchronize(cz_ctx *c) {
+    CZ_REQUIRE(c, "null ctx");
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    return CZ_OK;
+}
+
+int cz_malloc(cz_ctx *c, size_t bytes, void **dptr) {
+    CZ_REQUIRE(c && dptr, "cz_malloc: null argument");
+    CZ_HIP(hipSetDevice(c->device));
+    if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) { cz_set_error("cz_malloc: %zu bytes failed", bytes); return CZ_ENOMEM; }
+    return CZ_OK;
+}
+int cz_free(cz_ctx *c, void *dptr) {
+    CZ_REQUIRE(c, "null ctx");
+    CZ_HIP(hipFree(dptr));
+    return CZ_OK;
+}
+int cz_upload(cz_ctx *c, void *dst, const void *src, size_t bytes) {
+    CZ_REQUIRE(c, "null ctx");
+    CZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    return CZ_OK;
+}
+int cz_download(cz_ctx *c, void *dst, const void *src, size_t bytes) {
+    CZ_REQUIRE(c, "null ctx");
+    CZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    return CZ_OK;
+}
+
+int cz_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves, uint16_t *count, uint32_t *mask) {
+    CZ_REQUIRE(c && G >= 0, "cz_movegen: null ctx / negative G");
+    if (G == 0) return CZ_OK;
+    CZ_REQUIRE(boards && side && count, "cz_movegen: boards, side, count required");
+    return czk_movegen(c, boards, side, G, moves, count, mask);
+}
+int cz_apply_move(cz_ctx *c, uint8_t *boards, uint8_t *side, const uint16_t *label, int G, uint64_t *hash, uint8_t *captured, int8_t *terminal) {
+    CZ_REQUIRE(c && G >= 0, "cz_apply_move: null ctx / negative G");
+    if (G == 0) return CZ_OK;
+    CZ_REQUIRE(boards && side && label, "cz_apply_move: boards, side, move_label required");
+    return czk_apply_move(c, boards, side, label, G, hash, captured, terminal);
+}
+int cz_hash(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint64_t *hash) {
+    CZ_REQUIRE(c && G >= 0, "cz_hash: null ctx / negative G");
+    if (G == 0) return CZ_OK;
+    CZ_REQUIRE(boards && side && hash, "cz_hash: null argument");
+    return czk_hash(c, boards, side, G, hash);
+}
+int cz_encode_planes(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, void *planes, int dtype, int channels, int quirk) {
+    CZ_REQUIRE(c && G >= 0, "cz_encode_planes: null ctx / negative G");
+    if (G == 0) return CZ_OK;
+    CZ_REQUIRE(boards && side && planes, "cz_encode_planes: null argument");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_encode_planes: dtype must be CZ_F32 or CZ_BF16");
+    CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_encode_planes: 14 <= channels <= 64");
+    return czk_encode_planes(c, boards, side, G, planes, dtype, channels, quirk);
+}
+
+int cz_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const int32_t *rr, int G) {
+    CZ_REQUIRE(c && boards && side, "cz_search_reset: null argument");
+    if (G <= 0 || G > c->max_games) { cz_set_error("cz_search_reset: G=%d outside 1..%d", G, c->max_games); return CZ_EINVAL; }
+    c->G = G;
+    return czk_search_reset(c, boards, side, rr, G);
+}
+int cz_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int channels, uint8_t *needs_eval) {
+    CZ_REQUIRE(c && c->G > 0, "cz_search_select: call cz_search_reset first");
+    CZ_REQUIRE(mode == 0 || mode == 1, "cz_search_select: mode must be 0 or 1");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_search_select: dtype must be CZ_F32 or CZ_BF16");
+    CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_search_select: 14 <= channels <= 64");
+    return czk_search_select(c, mode, active, planes, dtype, channels, needs_eval);
+}
+int cz_search_expand_backup(cz_ctx *c, const void *logits, const void *value, int dtype) {
+    CZ_REQUIRE(c && c->G > 0 && logits && value, "cz_search_expand_backup: null argument / no search");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_search_expand_backup: dtype must be CZ_F32 or CZ_BF16");
+    return czk_search_expand_backup(c, logits, value, dtype);
+}
+int cz_search_root_stats(cz_ctx *c, uint16_t *label, int32_t *N, float *Q, float *P, float *W, uint16_t *count) {
+    CZ_REQUIRE(c && c->G > 0, "cz_search_root_stats: no search");
+    return czk_search_root_stats(c, label, N, Q, P, W, count);
+}
+int cz_search_advance(cz_ctx *c, const uint16_t *played) {
+    CZ_REQUIRE(c && c->G > 0 && played, "cz_search_advance: null argument / no search");
+    return czk_search_advance(c, played);
+}
+int cz_search_status(cz_ctx *c, int32_t *status, int32_t *nodes, int32_t *sims, int32_t *depth) {
+    CZ_REQUIRE(c && c->G > 0, "cz_search_status: no search");
+    const size_t b = sizeof(int32_t) * (size_t)c->G;
+    if (status) CZ_HIP(hipMemcpyAsync(status, c->t.status, b, hipMemcpyDeviceToDevice, c->stream));
+    if (nodes) CZ_HIP(hipMemcpyAsync(nodes, c->t.n_nodes, b, hipMemcpyDeviceToDevice, c->stream));
+    if (sims) CZ_HIP(hipMemcpyAsync(sims, c->t.sims, b, hipMemcpyDeviceToDevice, c->stream));
+    if (depth) CZ_HIP(hipMemcpyAsync(depth, c->t.last_depth, b, hipMemcpyDeviceToDevice, c->stream));
+    return CZ_OK;
+}
+
+int cz_search_tree_dump(cz_ctx *c, int g, int32_t *out, int max_records) {
+    CZ_REQUIRE(c && c->G > 0 && g >= 0 && g < c->G, "cz_search_tree_dump: bad tree index");
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    int32_t cur = 0, root = 0, n = 0;
+    CZ_HIP(hipMemcpy(&cur, c->t.cur + g, 4, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(&root, c->t.root_node + g, 4, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(&n, c->t.n_nodes + g, 4, hipMemcpyDeviceToHost));
+    const CzPool &p = c->t.pool[cur];
+    const size_t base = (size_t)g * (size_t)c->cap;
+    std::vector<float> P(n), W(n), Q(n);
+    std::vector<int32_t> N(n), cb(n);
+    std::vector<uint16_t> cc(n), mv(n);
+    CZ_HIP(hipMemcpy(P.data(), p.P + base, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(W.data(), p.W + base, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(Q.data(), p.Q + base, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(N.data(), p.N + base, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(cb.data(), p.child_begin + base, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(cc.data(), p.child_count + base, 2 * (size_t)n, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(mv.data(), p.move + base, 2 * (size_t)n, hipMemcpyDeviceToHost));
+    // iterative pre-order
+    struct Frame { int node, next; int depth; };
+    std::vector<Frame> st;
+    int nrec = 0;
+    if (cb[root] >= 0) st.push_back({root, 0, 0});
+    auto bits = [](float f) { int32_t i; memcpy(&i, &f, 4); return i; };
+    while (!st.empty()) {
+        Frame &f = st.back();
+        if (f.next >= cc[f.node]) { st.pop_back(); continue; }
+        const int ch = cb[f.node] + f.next++;
+        const int depth = f.depth;
+        if (nrec < max_records && out) {
+            int32_t *r = out + (size_t)nrec * 7;
+            r[0] = depth; r[1] = mv[ch]; r[2] = N[ch]; r[3] = bits(W[ch]); r[4] = bits(Q[ch]); r[5] = bits(P[ch]);
+            r[6] = cb[ch] < 0 ? -1 : cc[ch];
+        }
+        ++nrec;
+        if (cb[ch] >= 0) st.push_back({ch, 0, depth + 1});
+    }
+    return nrec;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// cz_rules.hip — stand-alone rules kernels K1 (move generation), K2 (make move + hash + flags),
+// K3 (input planes).  One wave64 workgroup per position; boards are staged in LDS with one
+// coalesced 90-byte read, results leave with coalesced stores.  These are HBM/issue-bound byte
+// kernels: no MFMA here by design.
+#include "cz_internal.h"
+
+namespace {
+
+__device__ __forceinline__ void load_board(const uint8_t *__restrict__ g, uint8_t *lds, int lane) {
+    // 90 bytes: lanes 0..44 move 2 bytes each (boards are only byte-aligned in the ABI)
+    if (lane < 45) {
+        lds[2 * lane] = g[2 * lane];
+        lds[2 * lane + 1] = g[2 * lane + 1];
+    } else if (lane < 48) {
+        lds[2 * lane] = 0;
+        lds[2 * lane + 1] = 0;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_movegen(CzTables tab, const uint8_t *__restrict__ boards,
+                                                const uint8_t *__restrict__ side, int G,
+                                                uint16_t *__restrict__ moves, uint16_t *__restrict__ count,
+                                                uint32_t *__restrict__ mask) {
+    __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
+    __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
+    __shared__ uint16_t out[CZD_MAXMOVES];
+    __shared__ uint32_t m[CZ_MASK_WORDS + 2];
+    const int lane = threadIdx.x;
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        load_board(boards + (size_t)g * CZ_NSQ, b, lane);
+        const int sd = side[g] ? 1 : 0;
+        const int n = czd_wave_movegen(b, sd, tab.lut, stage, out, lane);
+        const int nn = n < 0 ? 0 : n;
+        if (lane == 0) count[g] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
+        if (moves) {
+            for (int i = lane; i < CZD_MAXMOVES; i += 64) moves[(size_t)g * CZD_MAXMOVES + i] = i < nn ? out[i] : (uint16_t)0xFFFF;
+        }
+        if (mask) {
+            for (int i = lane; i < CZ_MASK_WORDS; i += 64) m[i] = 0;
+            __syncthreads();
+            for (int i = lane; i < nn; i += 64) atomicOr(&m[out[i] >> 5], 1u << (out[i] & 31));
+            __syncthreads();
+            for (int i = lane; i < CZ_MASK_WORDS; i += 64) mask[(size_t)g * CZ_MASK_WORDS + i] = m[i];
+        }
+        __syncthreads();
+    }
+}
+
+// K2: thread per game (the work per game is a handful of byte moves)
+__global__ void k_apply_move(CzTables tab, uint8_t *__restrict__ boards, uint8_t *__restrict__ side,
+                             const uint16_t *__restrict__ label, int G, uint64_t *__restrict__ hash,
+                             uint8_t *__restrict__ captured, int8_t *__restrict__ terminal) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint16_t l = label[g];
+    uint8_t *b = boards + (size_t)g * CZ_NSQ;
+    uint8_t cap = 0;
+    if (l < CZ_NLABELS) {
+        const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+        const uint8_t pc = b[src];
+        cap = b[dst];
+        b[dst] = pc;  // sim_do_action, main.py:671-672
+        b[src] = 0;
+        if (hash) {
+            uint64_t h = hash[g];
+            if (pc) h ^= tab.zob[pc * CZ_NSQ + src] ^ tab.zob[pc * CZ_NSQ + dst];
+            if (cap) h ^= tab.zob[cap * CZ_NSQ + dst];
+            h ^= tab.zob[15 * CZ_NSQ];
+            hash[g] = h;
+        }
+        side[g] = side[g] ? 0 : 1;
+    }
+    if (captured) captured[g] = cap;  // is_kill_move != 0, main.py:219-227
+    if (terminal) {
+        bool K = false, k = false;
+        for (int i = 0; i < CZ_NSQ; ++i) { K |= (b[i] == 1); k |= (b[i] == 8); }
+        terminal[g] = (int8_t)((K ? 0 : 1) | (k ? 0 : 2));  // find('K') == -1 / find('k') == -1, main.py:409-413
+    }
+}
+
+__global__ void k_hash(CzTables tab, const uint8_t *__restrict__ boards, const uint8_t *__restrict__ side, int G,
+                       uint64_t *__restrict__ hash) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint8_t *b = boards + (size_t)g * CZ_NSQ;
+    uint64_t h = side[g] ? tab.zob[15 * CZ_NSQ] : 0ull;
+    for (int q = 0; q < CZ_NSQ; ++q) { const int c = b[q]; if (c) h ^= tab.zob[c * CZ_NSQ + q]; }
+    hash[g] = h;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_encode_planes(const uint8_t *__restrict__ boards, const uint8_t *__restrict__ side,
+                                                      int G, T *__restrict__ planes, int C, int quirk, T one) {
+    __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
+    const int lane = threadIdx.x;
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        load_board(boards + (size_t)g * CZ_NSQ, b, lane);
+        czd_wave_encode_planes<T>(b, side[g] ? 1 : 0, quirk, planes + (size_t)g * 90 * C, C, one, lane);
+        __syncthreads();
+    }
+}
+
+inline int grid_for(int G) { return G < 65536 ? G : 65536; }
+
+}  // namespace
+
+int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves, uint16_t *count, uint32_t *mask) {
+    if (G == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_movegen, dim3(grid_for(G)), dim3(64), 0, c->stream, c->tab, boards, side, G, moves, count, mask);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_apply_move(cz_ctx *c, uint8_t *boards, uint8_t *side, const uint16_t *label, int G, uint64_t *hash, uint8_t *captured, int8_t *terminal) {
+    if (G == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_apply_move, dim3((G + 255) / 256), dim3(256), 0, c->stream, c->tab, boards, side, label, G, hash, captured, terminal);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_hash(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint64_t *hash) {
+    if (G == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_hash, dim3((G + 255) / 256), dim3(256), 0, c->stream, c->tab, boards, side, G, hash);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_encode_planes(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, void *planes, int dtype, int C, int quirk) {
+    if (G == 0) return CZ_OK;
+    if (dtype == CZ_F32)
+        hipLaunchKernelGGL(k_encode_planes<float>, dim3(grid_for(G)), dim3(64), 0, c->stream, boards, side, G, (float *)planes, C, quirk, 1.0f);
+    else
+        hipLaunchKernelGGL(k_encode_planes<uint16_t>, dim3(grid_for(G)), dim3(64), 0, c->stream, boards, side, G, (uint16_t *)planes, C, quirk, (uint16_t)0x3F80);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}

@@ -1,0 +1,400 @@
+// cz_search.hip — lock-step MCTS over G independent game trees, one wave64 workgroup per tree.
+//
+// Restates (chengstone/cchess-zero main.py, search_threads = 1 semantics):
+//   leaf_node                :93-206    MCTS_tree.main      :473-493
+//   start_tree_search        :350-435   update_tree         :272-276
+// Arithmetic follows the reference under NumPy >= 2 scalar promotion:
+//   priors   float32, tot_p = float32(1e-8) + sequential float32 adds in move order
+//   W, Q     float32; virtual loss applied as (W + -3) + 3 in float32 before W += v
+//   score    float64: Q + float64(float32(5*P)) * sqrt(float64(parent.N [+3 below the root])) / (1+N)
+//   argmax   first maximum in generation order (Python max()), NaN never wins unless it is first
+// The HBM traffic per simulation is a few KB (three coalesced sibling loads per level, one board,
+// one 2086-logit gather); everything a wave re-reads sits in LDS.
+#include "cz_internal.h"
+
+#include <math.h>
+
+namespace {
+
+struct TreeView {
+    float *P, *W, *Q;
+    int32_t *N, *parent, *child_begin;
+    uint16_t *child_count, *move;
+};
+
+__device__ __forceinline__ TreeView view_of(const CzTrees &t, int g, int which) {
+    const CzPool &p = t.pool[which];
+    const size_t base = (size_t)g * (size_t)t.cap;
+    TreeView v;
+    v.P = p.P + base; v.W = p.W + base; v.Q = p.Q + base;
+    v.N = p.N + base; v.parent = p.parent + base; v.child_begin = p.child_begin + base;
+    v.child_count = p.child_count + base; v.move = p.move + base;
+    return v;
+}
+
+__device__ __forceinline__ void init_root(TreeView v, int idx) {
+    v.P[idx] = 1.0f;  // p_ = 0.75 + 0.25 * dirichlet([0.3]) == 1 (quirk Q4), main.py:238
+    v.W[idx] = 0.f; v.Q[idx] = 0.f; v.N[idx] = 0; v.parent[idx] = -1; v.child_begin[idx] = -1;
+    v.child_count[idx] = 0; v.move[idx] = 0xFFFF;
+}
+
+// ---- reset: MCTS_tree.__init__ / reload, main.py:235-259 ---------------------------------------
+__global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restrict__ boards,
+                                              const uint8_t *__restrict__ side, const int32_t *__restrict__ rr, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    for (int i = lane; i < CZD_BOARD_LDS; i += 64)
+        t.root_board[(size_t)g * CZD_BOARD_LDS + i] = i < CZ_NSQ ? boards[(size_t)g * CZ_NSQ + i] : 0;
+    if (lane == 0) {
+        t.cur[g] = 0;
+        t.root_side[g] = side[g] ? 1 : 0;
+        t.root_rr[g] = rr ? rr[g] : 0;
+        t.root_node[g] = 0; t.n_nodes[g] = 1; t.status[g] = 0; t.sims[g] = 0; t.last_depth[g] = 0;
+        t.pend_kind[g] = 0; t.pend_leaf[g] = 0; t.pend_value[g] = 0.f; t.pend_side[g] = 0; t.pend_nmoves[g] = 0;
+        init_root(view_of(t, g, 0), 0);
+    }
+}
+
+// ---- K4: selection descent + leaf preparation ----------------------------------------------------
+struct Cand { double s; int i; };
+__device__ __forceinline__ Cand better(Cand a, Cand b) {
+    // first maximum wins: larger score, ties to the smaller index
+    if (b.s > a.s || (b.s == a.s && b.i < a.i)) return b;
+    return a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, int mode,
+                                               const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                               T one, uint8_t *__restrict__ needs_eval) {
+    __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
+    __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
+    __shared__ uint16_t mv[CZD_MAXMOVES];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    T *pl = planes ? planes + (size_t)g * 90 * C : nullptr;
+    const bool parked = (active && !active[g]) || (t.status[g] & ~CZ_ST_BAD_ADVANCE) != 0;
+    int kind = 0, leaf = 0, depth = 0;
+    float pend = 0.f;
+    int side = t.root_side[g];
+    if (!parked) {
+        for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64)
+            ((uint32_t *)b)[i] = ((const uint32_t *)(t.root_board + (size_t)g * CZD_BOARD_LDS))[i];
+        __syncthreads();
+        const TreeView v = view_of(t, g, t.cur[g]);
+        const int root = t.root_node[g];
+        int rr = t.root_rr[g];
+        int node = root;
+        // kings present on the root board ('K' = 1, 'k' = 8)
+        const int c0 = b[lane], c1 = (lane + 64 < CZ_NSQ) ? b[lane + 64] : 0;
+        bool Kmiss = (__ballot(c0 == 1) | __ballot(c1 == 1)) == 0ull;
+        bool kmiss = (__ballot(c0 == 8) | __ballot(c1 == 8)) == 0ull;
+        if (v.child_begin[root] < 0) {
+            kind = 3; leaf = root;  // MCTS_tree.main root expansion, main.py:475-487
+        } else if (mode != 0) {
+            for (;;) {
+                const int cb = v.child_begin[node];
+                if (cb < 0) { kind = 1; leaf = node; break; }  // not in `expanded`, main.py:357
+                const int cc = v.child_count[node];
+                if (cc == 0) { if (lane == 0) t.status[g] |= CZ_ST_NO_MOVES; break; }  // max() of empty, quirk Q7
+                // select_new / get_Q_plus_U_new, main.py:108-116,158-159.  Non-root nodes on the path
+                // carry their virtual loss (N += 3, main.py:403) while their children are scored.
+                const double sq = sqrt((double)(v.N[node] + (node != root ? 3 : 0)));
+                Cand best; best.s = -INFINITY; best.i = 0x7FFFFFFF;
+                bool first_nan = false;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i = lane + 64 * r;
+                    if (i < cc) {
+                        const float cp = 5.0f * v.P[cb + i];
+                        const double u = (double)cp * sq / (double)(1 + v.N[cb + i]);
+                        double s = (double)v.Q[cb + i] + u;
+                        if (s != s) { if (i == 0) first_nan = true; s = -INFINITY; }
+                        Cand c; c.s = s; c.i = i;
+                        best = better(best, c);
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    Cand o; o.s = __shfl_xor(best.s, d, 64); o.i = __shfl_xor(best.i, d, 64);
+                    best = better(best, o);
+                }
+                int bi = best.i;
+                if (__shfl((int)first_nan, 0, 64)) bi = 0;  // a NaN first element is never displaced by `>`
+                const int c = cb + bi;
+                const int l = v.move[c];
+                const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+                const int cap = b[dst];
+                __syncthreads();
+                if (lane == 0) { b[dst] = b[src]; b[src] = 0; }  // sim_do_action, main.py:671-672
+                __syncthreads();
+                side ^= 1;                  // main.py:392
+                rr = cap ? 0 : rr + 1;      // main.py:393-396
+                ++depth;
+                if (cap == 1) Kmiss = true;
+                if (cap == 8) kmiss = true;
+                if (Kmiss || kmiss) {
+                    // main.py:409-414; `side` is the player to move at the child
+                    float value = 0.f;
+                    if (Kmiss) value = side ? 1.0f : -1.0f;
+                    if (kmiss) value = side ? -1.0f : 1.0f;
+                    kind = 2; leaf = c; pend = value * -1.0f; break;
+                } else if (rr >= 60) {      // main.py:415-416
+                    kind = 2; leaf = c; pend = 0.f; break;
+                }
+                node = c;
+            }
+        }
+    }
+    int nmoves = 0;
+    if (kind == 1 || kind == 3) {
+        nmoves = czd_wave_movegen(b, side, tab.lut, stage, mv, lane);  // main.py:374 / :483
+        if (nmoves < 0) { if (lane == 0) t.status[g] |= CZ_ST_MOVE_OVERFLOW; kind = 0; nmoves = 0; }
+    }
+    if (kind == 1 || kind == 3) {
+        for (int i = lane; i < nmoves; i += 64) t.pend_moves[(size_t)g * CZD_MAXMOVES + i] = mv[i];
+        if (pl) czd_wave_encode_planes<T>(b, side, 1, pl, C, one, lane);  // generate_inputs, main.py:362 / :477
+    } else if (pl) {
+        for (int e = lane; e < 90 * C; e += 64) pl[e] = (T)0;
+    }
+    if (lane == 0) {
+        t.pend_kind[g] = kind; t.pend_leaf[g] = leaf; t.pend_value[g] = pend;
+        t.pend_side[g] = (uint8_t)side; t.pend_nmoves[g] = (uint16_t)nmoves;
+        if (!parked) t.last_depth[g] = depth;
+        if (needs_eval) needs_eval[g] = (kind == 1 || kind == 3) ? 1 : 0;
+    }
+}
+
+// ---- K5 + K6: expansion and value backup ---------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<uint16_t>(uint16_t x) { return czd_bf16_bits_to_f32(x); }
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, int G, const T *__restrict__ logits,
+                                                      const T *__restrict__ value) {
+    __shared__ float pr[CZD_MAXMOVES];
+    __shared__ float tot_s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const int kind = t.pend_kind[g];
+    if (kind == 0) return;
+    const TreeView v = view_of(t, g, t.cur[g]);
+    const int leaf = t.pend_leaf[g];
+    float val;
+    if (kind == 1 || kind == 3) {
+        // leaf_node.expand, main.py:175-187; flip_policy for black, main.py:371-372,1153-1155
+        const int n = t.pend_nmoves[g];
+        const int sd = t.pend_side[g];
+        const int begin = t.n_nodes[g];
+        const bool fits = begin + n <= t.cap;
+        if (fits) {
+            const T *lg = logits + (size_t)g * CZ_NLABELS;
+            uint16_t lab[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = lane + 64 * r;
+                lab[r] = 0;
+                if (i < n) {
+                    lab[r] = t.pend_moves[(size_t)g * CZD_MAXMOVES + i];
+                    pr[i] = to_f32<T>(lg[sd ? tab.unflip[lab[r]] : lab[r]]);
+                }
+            }
+            __syncthreads();
+            if (lane == 0) {
+                float tot = (float)1e-8;  // tot_p = 1e-8; tot_p += mov_p (np.float32), main.py:176,184
+                for (int i = 0; i < n; ++i) tot = tot + pr[i];
+                tot_s = tot;
+            }
+            __syncthreads();
+            const float tot = tot_s;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = lane + 64 * r;
+                if (i < n) {
+                    const int c = begin + i;
+                    v.P[c] = pr[i] / tot;  // n.P /= tot_p, main.py:186-187
+                    v.W[c] = 0.f; v.Q[c] = 0.f; v.N[c] = 0; v.parent[c] = leaf; v.child_begin[c] = -1;
+                    v.child_count[c] = 0; v.move[c] = lab[r];
+                }
+            }
+            if (lane == 0) { v.child_begin[leaf] = begin; v.child_count[leaf] = (uint16_t)n; t.n_nodes[g] = begin + n; }
+        } else if (lane == 0) {
+            t.status[g] |= CZ_ST_POOL_EXHAUSTED;
+        }
+        if (kind == 3) { if (lane == 0) t.pend_kind[g] = 0; return; }
+        val = to_f32<T>(value[g]) * -1.0f;  // return value[0] * -1, main.py:384
+    } else {
+        val = t.pend_value[g];
+    }
+    if (lane == 0) {
+        // back_up_value on every selected node of the path, main.py:189-194,426-435; the root is
+        // never updated (quirk Q2).  (W + -3) + 3 reproduces the float32 rounding of the virtual loss.
+        const int root = t.root_node[g];
+        int n = leaf;
+        float x = val;
+        while (n != root) {
+            float w = v.W[n];
+            w = w + -3.0f;
+            w = w + 3.0f;
+            const int cnt = v.N[n] + 1;
+            w = w + x;
+            v.N[n] = cnt; v.W[n] = w; v.Q[n] = w / (float)cnt;
+            x = x * -1.0f;
+            n = v.parent[n];
+        }
+        t.sims[g] += 1;
+        t.pend_kind[g] = 0;
+    }
+}
+
+// ---- root children: root.child.items(), main.py:1339 ----------------------------------------------
+__global__ __launch_bounds__(64) void k_root_stats(CzTrees t, int G, uint16_t *__restrict__ label, int32_t *__restrict__ N,
+                                                   float *__restrict__ Q, float *__restrict__ P, float *__restrict__ W,
+                                                   uint16_t *__restrict__ count) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const TreeView v = view_of(t, g, t.cur[g]);
+    const int root = t.root_node[g];
+    const int cb = v.child_begin[root];
+    const int n = cb < 0 ? 0 : v.child_count[root];
+    if (lane == 0 && count) count[g] = (uint16_t)n;
+    for (int i = lane; i < CZD_MAXMOVES; i += 64) {
+        const size_t o = (size_t)g * CZD_MAXMOVES + i;
+        const bool ok = i < n;
+        if (label) label[o] = ok ? v.move[cb + i] : (uint16_t)0xFFFF;
+        if (N) N[o] = ok ? v.N[cb + i] : 0;
+        if (Q) Q[o] = ok ? v.Q[cb + i] : 0.f;
+        if (P) P[o] = ok ? v.P[cb + i] : 0.f;
+        if (W) W[o] = ok ? v.W[cb + i] : 0.f;
+    }
+}
+
+// ---- K7: update_tree (main.py:272-276) with subtree compaction ------------------------------------
+// The played child's subtree is copied breadth-first into the spare pool (sibling groups stay
+// contiguous and keep their order, so selection is unchanged), then the pools swap roles for this
+// tree.  Board / side / restrict_round follow selfplay's bookkeeping, main.py:1522-1528.
+__global__ __launch_bounds__(64) void k_advance(CzTrees t, CzTables tab, int G, const uint16_t *__restrict__ played) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const uint16_t l = played[g];
+    if (l >= CZ_NLABELS) return;
+    const int cur = t.cur[g];
+    const TreeView s = view_of(t, g, cur), d = view_of(t, g, cur ^ 1);
+    const int root = t.root_node[g];
+    // find the played child (first match, children are unique)
+    const int cb = s.child_begin[root];
+    const int cc = cb < 0 ? 0 : s.child_count[root];
+    int found = -1;
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        const bool hit = i < cc && s.move[cb + i] == l;
+        const unsigned long long m = __ballot(hit);
+        if (found < 0 && m) found = cb + 64 * r + (__ffsll((long long)m) - 1);
+    }
+    // board bookkeeping
+    uint8_t *rb = t.root_board + (size_t)g * CZD_BOARD_LDS;
+    const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+    const int cap = rb[dst];
+    __syncthreads();
+    if (lane == 0) {
+        rb[dst] = rb[src]; rb[src] = 0;
+        t.root_side[g] ^= 1;
+        t.root_rr[g] = cap ? 0 : t.root_rr[g] + 1;
+        t.sims[g] = 0;
+        t.pend_kind[g] = 0;
+    }
+    if (found < 0) {
+        if (lane == 0) {
+            t.status[g] |= CZ_ST_BAD_ADVANCE;
+            init_root(d, 0);
+            t.root_node[g] = 0; t.n_nodes[g] = 1; t.cur[g] = cur ^ 1;
+        }
+        return;
+    }
+    if (lane == 0) {
+        d.P[0] = s.P[found]; d.W[0] = s.W[found]; d.Q[0] = s.Q[found]; d.N[0] = s.N[found];
+        d.parent[0] = -1; d.move[0] = s.move[found];
+        d.child_begin[0] = s.child_begin[found];  // still a SOURCE index until node 0 is processed
+        d.child_count[0] = s.child_count[found];
+    }
+    __syncthreads();
+    __threadfence_block();
+    // breadth-first copy, 64 destination nodes per sweep; only expanded ones own a sibling group
+    int n = 1, i0 = 0;
+    while (i0 < n) {
+        const int lim = (n - i0) < 64 ? (n - i0) : 64;
+        const int mycb = lane < lim ? d.child_begin[i0 + lane] : -1;  // SOURCE-pool index of the group
+        const int mycc = lane < lim ? (int)d.child_count[i0 + lane] : 0;
+        unsigned long long m = __ballot(mycb >= 0);
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int scb = __shfl(mycb, k, 64), scc = __shfl(mycc, k, 64);
+            for (int j = lane; j < scc; j += 64) {
+                const int a = scb + j, o = n + j;  // o >= i0 + lim: never inside the sweep window
+                d.P[o] = s.P[a]; d.W[o] = s.W[a]; d.Q[o] = s.Q[a]; d.N[o] = s.N[a];
+                d.parent[o] = i0 + k; d.move[o] = s.move[a];
+                d.child_begin[o] = s.child_begin[a]; d.child_count[o] = s.child_count[a];
+            }
+            if (lane == 0) d.child_begin[i0 + k] = n;
+            n += scc;
+        }
+        __syncthreads();
+        i0 += lim;
+    }
+    if (lane == 0) { t.root_node[g] = 0; t.n_nodes[g] = n; t.cur[g] = cur ^ 1; }
+}
+
+__global__ void k_root_state(CzTrees t, int G, uint8_t *__restrict__ boards, uint8_t *__restrict__ side, int32_t *__restrict__ rr) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    if (boards) for (int i = lane; i < CZ_NSQ; i += 64) boards[(size_t)g * CZ_NSQ + i] = t.root_board[(size_t)g * CZD_BOARD_LDS + i];
+    if (lane == 0) { if (side) side[g] = t.root_side[g]; if (rr) rr[g] = t.root_rr[g]; }
+}
+
+}  // namespace
+
+int czk_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const int32_t *rr, int G) {
+    hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, c->stream, c->t, boards, side, rr, G);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int C, uint8_t *needs_eval) {
+    if (dtype == CZ_F32)
+        hipLaunchKernelGGL(k_select<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (float *)planes, C, 1.0f, needs_eval);
+    else
+        hipLaunchKernelGGL(k_select<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (uint16_t *)planes, C, (uint16_t)0x3F80, needs_eval);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_expand_backup(cz_ctx *c, const void *logits, const void *value, int dtype) {
+    if (dtype == CZ_F32)
+        hipLaunchKernelGGL(k_expand_backup<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const float *)logits, (const float *)value);
+    else
+        hipLaunchKernelGGL(k_expand_backup<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const uint16_t *)logits, (const uint16_t *)value);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_root_stats(cz_ctx *c, uint16_t *label, int32_t *N, float *Q, float *P, float *W, uint16_t *count) {
+    hipLaunchKernelGGL(k_root_stats, dim3(c->G), dim3(64), 0, c->stream, c->t, c->G, label, N, Q, P, W, count);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_advance(cz_ctx *c, const uint16_t *played) {
+    hipLaunchKernelGGL(k_advance, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, played);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int cz_search_root_state(cz_ctx *c, uint8_t *boards, uint8_t *side, int32_t *rr) {
+    if (!c) { cz_set_error("null ctx"); return CZ_EINVAL; }
+    if (c->G == 0) return CZ_OK;
+    hipLaunchKernelGGL(k_root_state, dim3(c->G), dim3(64), 0, c->stream, c->t, c->G, boards, side, rr);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}

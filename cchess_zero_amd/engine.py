@@ -1,0 +1,161 @@
+"""Lock-step search engine over G game trees (host side of K1-K7).
+
+PyTorch is used only for device memory / streams; every search operation is one HIP kernel
+launched through the C-ABI (include/cchess_hip.h).  Mirrors, for G trees at once, what the
+reference's MCTS_tree (main.py:234-577) does for one.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, MAXMOVES, NLABELS, NSQ, check, lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """Owns a cz_ctx bound to one GPU and to torch's current stream on it."""
+
+    def __init__(self, max_games, max_nodes_per_tree, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.CchessHipError("no HIP device visible: the cchess_hip path needs an MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        self.max_games = int(max_games)
+        self.cap = int(max_nodes_per_tree)
+        h = C.c_void_p()
+        check(lib().cz_create(device, self.max_games, self.cap, C.byref(h)), "cz_create")
+        self.h = h
+        self.bind_stream()
+
+    def bind_stream(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(lib().cz_set_stream(self.h, C.c_void_p(s.cuda_stream)), "cz_set_stream")
+
+    def synchronize(self):
+        check(lib().cz_synchronize(self.h), "cz_synchronize")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cz_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SearchEngine:
+    """G trees searched in lock-step: select -> (batched net) -> expand_backup."""
+
+    def __init__(self, max_games, max_nodes_per_tree, device=0, plane_dtype=torch.float32, channels=14, ctx=None):
+        self.ctx = ctx or Context(max_games, max_nodes_per_tree, device)
+        self.dev = self.ctx.device
+        self.G = 0
+        self.channels = int(channels)
+        self.plane_dtype = plane_dtype
+        self._pd = BF16 if plane_dtype == torch.bfloat16 else F32
+        self.planes = None
+        self.need = None
+
+    # -- tree lifecycle ------------------------------------------------------------------------
+    def reset(self, boards, side, rr=None):
+        boards = torch.as_tensor(np.ascontiguousarray(boards, np.uint8) if not torch.is_tensor(boards) else boards).to(self.dev).reshape(-1, NSQ).contiguous()
+        side = torch.as_tensor(np.ascontiguousarray(side, np.uint8) if not torch.is_tensor(side) else side).to(self.dev).contiguous()
+        G = boards.shape[0]
+        rr_t = None
+        if rr is not None:
+            rr_t = torch.as_tensor(np.ascontiguousarray(rr, np.int32) if not torch.is_tensor(rr) else rr).to(self.dev).to(torch.int32).contiguous()
+        check(lib().cz_search_reset(self.ctx.h, _ptr(boards), _ptr(side), _ptr(rr_t), G), "cz_search_reset")
+        if self.G != G or self.planes is None:
+            self.G = G
+            self.planes = torch.zeros((G, 9, 10, self.channels), dtype=self.plane_dtype, device=self.dev)
+            self.need = torch.zeros(G, dtype=torch.uint8, device=self.dev)
+        self._keep = (boards, side, rr_t)
+
+    def select(self, mode=1, active=None):
+        """-> (leaf planes [G,9,10,C] device tensor, needs_eval [G] u8 device tensor)."""
+        act = None
+        if active is not None:
+            act = torch.as_tensor(active).to(self.dev).to(torch.uint8).contiguous()
+        check(lib().cz_search_select(self.ctx.h, int(mode), _ptr(act), _ptr(self.planes), self._pd, self.channels,
+                                     _ptr(self.need)), "cz_search_select")
+        self._act = act
+        return self.planes, self.need
+
+    def expand_backup(self, logits, value):
+        """logits [G,2086], value [G,1] or [G]: float32 or bfloat16 device tensors."""
+        if logits.dtype != value.dtype:
+            value = value.to(logits.dtype)
+        dt = BF16 if logits.dtype == torch.bfloat16 else F32
+        if dt == F32 and logits.dtype != torch.float32:
+            logits, value = logits.float(), value.float()
+        logits = logits.contiguous()
+        value = value.contiguous()
+        assert logits.shape == (self.G, NLABELS) and value.numel() == self.G
+        check(lib().cz_search_expand_backup(self.ctx.h, _ptr(logits), _ptr(value), dt), "cz_search_expand_backup")
+
+    def root_stats(self):
+        G, dev = self.G, self.dev
+        out = dict(label=torch.empty((G, MAXMOVES), dtype=torch.int16, device=dev),
+                   N=torch.empty((G, MAXMOVES), dtype=torch.int32, device=dev),
+                   Q=torch.empty((G, MAXMOVES), dtype=torch.float32, device=dev),
+                   P=torch.empty((G, MAXMOVES), dtype=torch.float32, device=dev),
+                   W=torch.empty((G, MAXMOVES), dtype=torch.float32, device=dev),
+                   count=torch.empty(G, dtype=torch.int16, device=dev))
+        check(lib().cz_search_root_stats(self.ctx.h, _ptr(out["label"]), _ptr(out["N"]), _ptr(out["Q"]), _ptr(out["P"]),
+                                         _ptr(out["W"]), _ptr(out["count"])), "cz_search_root_stats")
+        return out
+
+    def root_stats_host(self):
+        st = self.root_stats()
+        return dict(label=st["label"].cpu().numpy().view(np.uint16), N=st["N"].cpu().numpy(), Q=st["Q"].cpu().numpy(),
+                    P=st["P"].cpu().numpy(), W=st["W"].cpu().numpy(), count=st["count"].cpu().numpy().view(np.uint16))
+
+    def advance(self, played):
+        if not torch.is_tensor(played):
+            played = torch.from_numpy(np.ascontiguousarray(played, np.uint16).view(np.int16))
+        played = played.to(self.dev).contiguous()
+        check(lib().cz_search_advance(self.ctx.h, _ptr(played)), "cz_search_advance")
+
+    def status(self):
+        G, dev = self.G, self.dev
+        st, nodes, sims, depth = (torch.empty(G, dtype=torch.int32, device=dev) for _ in range(4))
+        check(lib().cz_search_status(self.ctx.h, _ptr(st), _ptr(nodes), _ptr(sims), _ptr(depth)), "cz_search_status")
+        return st, nodes, sims, depth
+
+    def root_state(self):
+        G, dev = self.G, self.dev
+        b = torch.empty((G, NSQ), dtype=torch.uint8, device=dev)
+        s = torch.empty(G, dtype=torch.uint8, device=dev)
+        rr = torch.empty(G, dtype=torch.int32, device=dev)
+        check(lib().cz_search_root_state(self.ctx.h, _ptr(b), _ptr(s), _ptr(rr)), "cz_search_root_state")
+        return b, s, rr
+
+    def tree_dump(self, g, max_records=1 << 20):
+        out = np.zeros((max_records, 7), np.int32)
+        n = lib().cz_search_tree_dump(self.ctx.h, int(g), out.ctypes.data_as(C.c_void_p), int(max_records))
+        if n < 0:
+            check(n, "cz_search_tree_dump")
+        if n > max_records:
+            raise _lib.CchessHipError("tree_dump: %d records > %d" % (n, max_records))
+        return out[:n].copy()
+
+    # -- the hot loop ------------------------------------------------------------------------------
+    def step(self, forward, mode=1, active=None):
+        """One lock-step simulation for every tree: select -> forward(planes) -> expand_backup.
+        `forward` maps the device planes tensor to (logits [G,2086], value [G,1]) device tensors."""
+        planes, _ = self.select(mode, active)
+        logits, value = forward(planes)
+        self.expand_backup(logits, value)
+
+    def search(self, forward, playouts, active=None):
+        """MCTS_tree.main (main.py:473-493) for all trees: expand unexpanded roots, then `playouts` simulations."""
+        self.step(forward, mode=0, active=active)
+        for _ in range(int(playouts)):
+            self.step(forward, mode=1, active=active)

@@ -1,0 +1,207 @@
+"""Residual policy/value network of cchess-zero re-expressed in PyTorch-ROCm.
+
+Graph (policy_value_network.py:45-74,151-162 of the reference, TF1):
+  conv3x3(14->128, bias) -> BN(no gamma/beta, eps 1e-5) -> ReLU
+  N x [conv3x3+BN+ReLU, conv3x3+BN, add, ReLU]
+  policy: conv1x1(128->2)+BN+ReLU -> flatten (h,w,c) 180 -> FC 2086 (raw logits, no softmax)
+  value : conv1x1(128->1)+BN+ReLU -> flatten 90 -> FC 256 ReLU -> FC 1 tanh
+Input is NHWC [B,9,10,14] (TF sees H=9, W=10; the board-to-plane indexing quirk Q1 lives in the
+encoder, not here).  Inference folds BN into the conv (x - mean) / sqrt(var + eps); with the
+reference's never-updated moving statistics (quirk Q5) that is x / sqrt(1 + 1e-5).
+
+Weights are kept in torch layout (OIHW / [out,in]); export_tf_layout()/load_tf_layout() convert to
+the reference's HWIO / [in,out] so a cchess-zero checkpoint's arrays can be dropped in.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+FILTERS = 128     # policy_value_network.py:23
+PROB_SIZE = 2086  # policy_value_network.py:24
+BN_EPS = 1e-5
+
+
+def _glorot_(w, fan_in, fan_out, gen):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    with torch.no_grad():
+        w.copy_((torch.rand(w.shape, generator=gen, dtype=torch.float32) * 2 - 1) * lim)
+
+
+class ConvBN(nn.Module):
+    """tf.layers.conv2d(padding='SAME', bias) + tf.contrib.layers.batch_norm(center=False, scale=False)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=k // 2, bias=True)
+        self.register_buffer("moving_mean", torch.zeros(cout))
+        self.register_buffer("moving_var", torch.ones(cout))
+
+    def folded(self):
+        s = torch.rsqrt(self.moving_var.float() + BN_EPS)
+        w = self.conv.weight.float() * s.view(-1, 1, 1, 1)
+        b = (self.conv.bias.float() - self.moving_mean.float()) * s
+        return w, b
+
+    def forward(self, x, training=False):
+        y = self.conv(x)
+        if training:  # TF is_training=True: batch statistics; the moving averages are never updated (Q5)
+            m = y.mean(dim=(0, 2, 3), keepdim=True)
+            v = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            return (y - m) * torch.rsqrt(v + BN_EPS)
+        return (y - self.moving_mean.view(1, -1, 1, 1)) * torch.rsqrt(self.moving_var.view(1, -1, 1, 1) + BN_EPS)
+
+
+class PolicyValueModule(nn.Module):
+    def __init__(self, res_block_nums=7, seed=0):
+        super().__init__()
+        self.res_block_nums = res_block_nums
+        self.conv_in = ConvBN(14, FILTERS, 3)
+        self.blocks = nn.ModuleList([nn.ModuleList([ConvBN(FILTERS, FILTERS, 3), ConvBN(FILTERS, FILTERS, 3)])
+                                     for _ in range(res_block_nums)])
+        self.policy_conv = ConvBN(FILTERS, 2, 1)
+        self.policy_fc = nn.Linear(180, PROB_SIZE)
+        self.value_conv = ConvBN(FILTERS, 1, 1)
+        self.value_fc1 = nn.Linear(90, 256)
+        self.value_fc2 = nn.Linear(256, 1)
+        self.reset_parameters(seed)
+
+    def reset_parameters(self, seed=0):
+        """TF defaults: glorot_uniform kernels, zero biases."""
+        gen = torch.Generator().manual_seed(seed)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                k = m.kernel_size[0] * m.kernel_size[1]
+                _glorot_(m.weight, m.in_channels * k, m.out_channels * k, gen)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                _glorot_(m.weight, m.in_features, m.out_features, gen)
+                nn.init.zeros_(m.bias)
+
+    def convbns(self):
+        out = [self.conv_in]
+        for a, b in self.blocks:
+            out += [a, b]
+        return out + [self.policy_conv, self.value_conv]
+
+    def forward(self, x_nchw, training=False):
+        """Straight fp32/any-dtype module forward (used for training and as the torch reference)."""
+        h = F.relu(self.conv_in(x_nchw, training))
+        for a, b in self.blocks:
+            t = F.relu(a(h, training))
+            h = F.relu(h + b(t, training))
+        p = F.relu(self.policy_conv(h, training)).permute(0, 2, 3, 1).reshape(h.shape[0], 180)
+        logits = self.policy_fc(p)
+        v = F.relu(self.value_conv(h, training)).permute(0, 2, 3, 1).reshape(h.shape[0], 90)
+        v = torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
+        return logits, v
+
+    # -- reference (TF) layout ----------------------------------------------------------------------
+    def export_tf_layout(self):
+        d = {}
+        for i, cb in enumerate(self.convbns()):
+            d["conv%d/kernel" % i] = cb.conv.weight.detach().float().permute(2, 3, 1, 0).contiguous().cpu().numpy()  # HWIO
+            d["conv%d/bias" % i] = cb.conv.bias.detach().float().cpu().numpy()
+            d["bn%d/moving_mean" % i] = cb.moving_mean.float().cpu().numpy()
+            d["bn%d/moving_variance" % i] = cb.moving_var.float().cpu().numpy()
+        for name, fc in (("policy_fc", self.policy_fc), ("value_fc1", self.value_fc1), ("value_fc2", self.value_fc2)):
+            d[name + "/weights"] = fc.weight.detach().float().t().contiguous().cpu().numpy()  # [in,out]
+            d[name + "/biases"] = fc.bias.detach().float().cpu().numpy()
+        return d
+
+    def load_tf_layout(self, d):
+        with torch.no_grad():
+            for i, cb in enumerate(self.convbns()):
+                cb.conv.weight.copy_(torch.from_numpy(np.asarray(d["conv%d/kernel" % i])).permute(3, 2, 0, 1))
+                cb.conv.bias.copy_(torch.from_numpy(np.asarray(d["conv%d/bias" % i])))
+                cb.moving_mean.copy_(torch.from_numpy(np.asarray(d["bn%d/moving_mean" % i])))
+                cb.moving_var.copy_(torch.from_numpy(np.asarray(d["bn%d/moving_variance" % i])))
+            for name, fc in (("policy_fc", self.policy_fc), ("value_fc1", self.value_fc1), ("value_fc2", self.value_fc2)):
+                fc.weight.copy_(torch.from_numpy(np.asarray(d[name + "/weights"])).t())
+                fc.bias.copy_(torch.from_numpy(np.asarray(d[name + "/biases"])))
+
+
+class PolicyValueNet:
+    """Inference engine around PolicyValueModule: BN folded, tower in `dtype` (bf16/fp16/fp32, fp32
+    accumulate on MFMA), heads in fp32.  forward_device() is the device-to-device path the search
+    loop uses; forward() has the reference signature (policy_value_network.forward)."""
+
+    def __init__(self, res_block_nums=7, device="cuda:0", dtype=torch.bfloat16, seed=0, module=None):
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.module = (module or PolicyValueModule(res_block_nums, seed)).to(self.device)
+        self.res_block_nums = self.module.res_block_nums
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        """Re-fold BN and re-cast after a weight change."""
+        m, dt = self.module, self.dtype
+        cl = torch.channels_last
+
+        def conv_pack(cb):
+            w, b = cb.folded()
+            return w.to(dt).contiguous(memory_format=cl), b.to(dt)
+        self.w_in = conv_pack(m.conv_in)
+        self.w_blocks = [(conv_pack(a), conv_pack(b)) for a, b in m.blocks]
+        # heads: 1x1 convs as fp32 matmuls over [B*90,128]
+        wp, bp = m.policy_conv.folded()
+        wv, bv = m.value_conv.folded()
+        self.head_w = torch.cat([wp.view(2, FILTERS), wv.view(1, FILTERS)], 0).t().contiguous()  # [128,3]
+        self.head_b = torch.cat([bp, bv], 0)
+        self.pfc_w = m.policy_fc.weight.float().t().contiguous()
+        self.pfc_b = m.policy_fc.bias.float()
+        self.v1_w = m.value_fc1.weight.float().t().contiguous()
+        self.v1_b = m.value_fc1.bias.float()
+        self.v2_w = m.value_fc2.weight.float().t().contiguous()
+        self.v2_b = m.value_fc2.bias.float()
+
+    @torch.no_grad()
+    def tower(self, planes):
+        """planes [B,9,10,C>=14] (NHWC, any float dtype) -> trunk activations [B,128,9,10] channels_last."""
+        x = planes[..., :14] if planes.shape[-1] != 14 else planes
+        x = x.to(self.dtype).permute(0, 3, 1, 2)  # NHWC memory == NCHW channels_last view
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        h = F.relu_(F.conv2d(x, self.w_in[0], self.w_in[1], padding=1))
+        for (w1, b1), (w2, b2) in self.w_blocks:
+            t = F.relu_(F.conv2d(h, w1, b1, padding=1))
+            h = F.relu_(F.conv2d(t, w2, b2, padding=1).add_(h))
+        return h
+
+    @torch.no_grad()
+    def heads(self, h):
+        B = h.shape[0]
+        hw = h.permute(0, 2, 3, 1).reshape(B * 90, FILTERS).float()   # (b,h,w) rows, NHWC order
+        z = torch.relu_(torch.addmm(self.head_b, hw, self.head_w))    # [B*90,3]: 2 policy + 1 value channel
+        p = z[:, :2].reshape(B, 180)                                   # flatten in (h,w,c) order
+        logits = torch.addmm(self.pfc_b, p, self.pfc_w)
+        v = z[:, 2].reshape(B, 90)
+        v = torch.relu_(torch.addmm(self.v1_b, v, self.v1_w))
+        v = torch.tanh(torch.addmm(self.v2_b, v, self.v2_w))
+        return logits, v
+
+    @torch.no_grad()
+    def forward_device(self, planes):
+        """Device planes [B,9,10,C] -> (logits [B,2086] f32, value [B,1] f32), all on the device."""
+        return self.heads(self.tower(planes))
+
+    @torch.no_grad()
+    def forward(self, positions):
+        """Reference signature (policy_value_network.py:202-214): ndarray or list of [9,10,14] ->
+        (logits [B,2086] float32 ndarray, value [B,1] float32 ndarray)."""
+        x = torch.as_tensor(np.asarray(positions, dtype=np.float32)).to(self.device)
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        logits, v = self.forward_device(x)
+        return logits.cpu().numpy(), v.cpu().numpy()
+
+
+def flops_per_position(res_block_nums):
+    """2 x MACs with SAME-padding taps counted densely."""
+    conv_in = 90 * 9 * 14 * 128
+    res = 90 * 9 * 128 * 128
+    heads = 90 * 128 * 2 + 180 * 2086 + 90 * 128 + 90 * 256 + 256
+    return 2 * (conv_in + 2 * res_block_nums * res + heads)

@@ -1,0 +1,139 @@
+/*
+ * cchess_hip.h — C-ABI of libcchess_hip.so: the MI355X (gfx950) hot path of cchess-zero.
+ *
+ * The reference (chengstone/cchess-zero) is pure Python and has no FFI layer; its boundary
+ * for this path is the class surface of main.py.  Each entry point below names the
+ * reference interface it replaces (file:line, relative to the reference repo).  The Python
+ * façade that keeps the reference's class/CLI names (main.py, policy_value_network.py at the
+ * repo root of this project) binds exactly these symbols through ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative CZ_E* code on failure;
+ *     cz_last_error() returns a thread-local message for the last failure.
+ *   - cz_ctx owns one HIP device, one stream and all device buffers of G game trees.  A ctx is
+ *     not thread-safe; distinct ctxs are independent (one per GPU / process).
+ *   - all array arguments are DEVICE pointers (e.g. torch tensors' data_ptr()); they are
+ *     borrowed for the duration of the enqueued work, never freed by the library.  Work is
+ *     enqueued on the ctx stream (cz_set_stream) and is asynchronous; cz_synchronize waits.
+ *     cz_malloc/cz_upload/cz_download exist for callers without a tensor library.
+ *
+ * Data formats (shared with the CPU oracle, oracle/cchess_oracle.h)
+ *   board   uint8[90], sq = y*9 + x; y = rank 0..9 (rank 0 = first row of the reference's
+ *           state string = red / upper-case / 'w' home, main.py:585), x = file 'a'..'i'.
+ *           code 0 = empty, 1..14 = 1 + index in pieces_order "KARBNPCkarbnpc" (main.py:208).
+ *   side    uint8: 0 = 'w' (red, upper case) to move, 1 = 'b' (black).
+ *   label   uint16 index into the 2086-entry move vocabulary labels_array (main.py:30-65,211).
+ *   planes  [G][9][10][C] (C >= 14), element (h,w,c) = 1 iff the side-to-move-canonical board
+ *           has piece code c+1 on cell h*9+w — the reference's 9-stride quirk (SURVEY Q1,
+ *           main.py:547-557) is reproduced; channels >= 14 are zero padding.
+ */
+#ifndef CCHESS_HIP_H
+#define CCHESS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CZ_NLABELS 2086
+#define CZ_MAXMOVES 128
+#define CZ_NSQ 90
+#define CZ_MASK_WORDS 66 /* ceil(2086/32) */
+
+#define CZ_OK 0
+#define CZ_EINVAL (-1)
+#define CZ_EHIP (-2)
+#define CZ_ENOMEM (-3)
+
+#define CZ_F32 0
+#define CZ_BF16 1
+
+/* status bits reported by cz_search_status */
+#define CZ_ST_POOL_EXHAUSTED 1 /* node pool of the tree is full: expansion skipped */
+#define CZ_ST_NO_MOVES 2       /* an expanded node with zero legal moves was selected (reference raises, quirk Q7) */
+#define CZ_ST_MOVE_OVERFLOW 4  /* > 128 moves or a move without a label */
+#define CZ_ST_BAD_ADVANCE 8    /* played move is not a child of the root (reference: KeyError) */
+
+typedef struct cz_ctx cz_ctx;
+
+const char *cz_last_error(void);
+int cz_version(void);
+
+/* ---- static tables (host pointers, valid for the process lifetime) --------------------------
+ * replaces: create_uci_labels / labels_array / label2i / unflipped_index, main.py:23-65,211-217.
+ *   lut90x90[src*90+dst] -> label or -1;  unflip2086[i] = unflipped_index[i];
+ *   labels = 2086 x 5 chars ("a0a1\0");   srcdst[i] = src | dst << 8. */
+int cz_tables(const int16_t **lut90x90, const int16_t **unflip2086, const char **labels,
+              const uint16_t **srcdst);
+/* Zobrist keys used by cz_hash / cz_apply_move: keys[15][90] (row 0 unused), side key.
+ * The reference has no state hash (identity = the state string); this format is ours. */
+int cz_zobrist(const uint64_t **keys15x90, uint64_t *side_key);
+
+/* ---- context ------------------------------------------------------------------------------
+ * replaces: cchess_main.__init__ building GameBoard + MCTS_tree, main.py:1140-1144. */
+int cz_create(int device, int max_games, int max_nodes_per_tree, cz_ctx **out);
+void cz_destroy(cz_ctx *);
+int cz_set_stream(cz_ctx *, void *hip_stream /* hipStream_t, NULL = default stream */);
+int cz_synchronize(cz_ctx *);
+int cz_malloc(cz_ctx *, size_t bytes, void **dptr);
+int cz_free(cz_ctx *, void *dptr);
+int cz_upload(cz_ctx *, void *dst_device, const void *src_host, size_t bytes);
+int cz_download(cz_ctx *, void *dst_host, const void *src_device, size_t bytes);
+
+/* ---- rules kernels (stand-alone, G positions per launch) -----------------------------------
+ * K1  replaces GameBoard.get_legal_moves, main.py:743-1109.
+ *     moves [G][128] labels in the reference's generation order (0xFFFF padding), count [G];
+ *     mask [G][66] 2086-bit legality mask (bit i of word i/32).  moves or mask may be NULL. */
+int cz_movegen(cz_ctx *, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves,
+               uint16_t *count, uint32_t *mask);
+/* K2  replaces GameBoard.sim_do_action (main.py:647-702), is_kill_move (:226) and the king test
+ *     (:409-413).  Updates boards/side in place.  hash: in/out incremental Zobrist (may be NULL);
+ *     captured [G] = captured piece code or 0; terminal [G]: bit0 'K' missing, bit1 'k' missing.
+ *     move_label 0xFFFF leaves the game untouched. */
+int cz_apply_move(cz_ctx *, uint8_t *boards, uint8_t *side, const uint16_t *move_label, int G,
+                  uint64_t *hash, uint8_t *captured, int8_t *terminal);
+int cz_hash(cz_ctx *, const uint8_t *boards, const uint8_t *side, int G, uint64_t *hash);
+/* K3  replaces MCTS_tree.generate_inputs = try_flip + state_to_positions, main.py:531-574.
+ *     planes [G][9][10][channels] of dtype CZ_F32 / CZ_BF16.  quirk_q1 = 1 reproduces the
+ *     reference bit for bit; 0 gives the transposed encoding its shapes suggest. */
+int cz_encode_planes(cz_ctx *, const uint8_t *boards, const uint8_t *side, int G, void *planes,
+                     int dtype, int channels, int quirk_q1);
+
+/* ---- lock-step search over G trees, one wavefront per tree ---------------------------------
+ * replaces: MCTS_tree.__init__/reload (main.py:235-259): fresh, unexpanded roots. */
+int cz_search_reset(cz_ctx *, const uint8_t *root_boards, const uint8_t *root_side,
+                    const int32_t *restrict_round /* may be NULL = 0 */, int G);
+/* K4 (+K1,K2,K3 on the leaf)  replaces one start_tree_search descent, main.py:350-418
+ *   (select_new :158, get_Q_plus_U_new :108-116, kill-move/restrict_round :393-396, terminal
+ *   tests :409-416, generate_inputs :362, get_legal_moves :374) with search_threads = 1.
+ *   mode 0: root expansion only (MCTS_tree.main, main.py:475-487); mode 1: one simulation.
+ *   active [G] (may be NULL): trees with 0 idle this step.
+ *   leaf_planes [G][9][10][channels]; needs_eval [G] = 1 where the net must be evaluated. */
+int cz_search_select(cz_ctx *, int mode, const uint8_t *active, void *leaf_planes, int dtype,
+                     int channels, uint8_t *needs_eval);
+/* K5+K6  replaces leaf_node.expand (main.py:175-187) with flip_policy (:1153-1155) and
+ *   back_up_value (:189-194) along the unwind (:426-435), including the float32 effect of the
+ *   virtual-loss add/remove (:403-404,426-427).  logits [G][2086], value [G] of `dtype`. */
+int cz_search_expand_backup(cz_ctx *, const void *logits, const void *value, int dtype);
+/* replaces: reading root.child.items() in get_action, main.py:1339 (+ MCTS_tree.Q :261).
+ *   arrays [G][128] (any may be NULL), count [G]. */
+int cz_search_root_stats(cz_ctx *, uint16_t *move_label, int32_t *N, float *Q, float *P, float *W,
+                         uint16_t *count);
+/* K7  replaces MCTS_tree.update_tree (main.py:272-276) + the board bookkeeping of selfplay
+ *   (:1522-1528): re-root on the played child keeping its subtree (compacted into the spare
+ *   pool).  played_label 0xFFFF leaves the tree untouched. */
+int cz_search_advance(cz_ctx *, const uint16_t *played_label);
+int cz_search_status(cz_ctx *, int32_t *status, int32_t *nodes_used, int32_t *sims,
+                     int32_t *last_depth); /* device [G] arrays, any may be NULL */
+int cz_search_root_state(cz_ctx *, uint8_t *boards, uint8_t *side, int32_t *restrict_round);
+/* parity/debug: pre-order dump of tree g into HOST memory; record = 7 int32
+ *   {depth, label, N, bits(W), bits(Q), bits(P), child_count or -1}.  Returns the record count
+ *   (>= 0; at most max_records are written) or a negative error. */
+int cz_search_tree_dump(cz_ctx *, int g, int32_t *host_out, int max_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

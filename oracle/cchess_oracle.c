@@ -421,7 +421,7 @@ int czo_search_select(czo_search *s, int mode, float *planes, uint8_t *needs_eva
         if (pl) memset(pl, 0, sizeof(float) * CZO_PLANE_ELEMS);
         if (needs_eval) needs_eval[g] = 0;
         t->kind = 0;
-        if (t->status) continue; /* a failed tree stays parked */
+        if (t->status & ~8) continue; /* a failed tree stays parked (bit 3 is informational) */
         uint8_t b[CZO_NSQ];
         memcpy(b, t->board, CZO_NSQ);
         int side = t->side, rr = t->rr, node = t->root, depth = 0;

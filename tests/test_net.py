@@ -1,0 +1,77 @@
+"""Net parity.  CPU: the torch module graph == the NumPy restatement of the TF graph (fp32).
+GPU: the inference engine (BN folded, channels_last, MFMA convs) within 1e-3 of the fp32
+restatement in fp32 mode; bf16 mode checked on softmax probabilities and value."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_numpy
+
+
+def _positions(n, seed=0):
+    """Real encoder outputs: planes of corpus positions (one-hot, with quirk Q1)."""
+    from oracle import oracle as O
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rules.npz"))
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(len(g["boards"]), n, replace=False)
+    return np.stack([O.encode_planes(g["boards"][i], int(g["side"][i])) for i in idx])
+
+
+@pytest.mark.parametrize("blocks", [1, 2])
+def test_module_matches_numpy_restatement_cpu(blocks):
+    from cchess_zero_amd.net import PolicyValueModule, flops_per_position
+    assert flops_per_position(7) == 375358832 and flops_per_position(19) == 2 * 506184376
+    m = PolicyValueModule(blocks, seed=3)
+    # non-trivial BN statistics and biases so that every term of the graph is exercised
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for cb in m.convbns():
+            cb.moving_mean.copy_(torch.randn(cb.moving_mean.shape, generator=gen) * 0.1)
+            cb.moving_var.copy_(torch.rand(cb.moving_var.shape, generator=gen) + 0.5)
+            cb.conv.bias.copy_(torch.randn(cb.conv.bias.shape, generator=gen) * 0.1)
+    x = _positions(6)
+    with torch.no_grad():
+        lt, vt = m(torch.from_numpy(x).permute(0, 3, 1, 2))
+    ln, vn = net_numpy.forward(m.export_tf_layout(), x, blocks)
+    assert np.abs(lt.numpy() - ln).max() < 1e-4
+    assert np.abs(vt.numpy() - vn).max() < 1e-5
+    # TF-layout round trip
+    m2 = PolicyValueModule(blocks, seed=9)
+    m2.load_tf_layout(m.export_tf_layout())
+    with torch.no_grad():
+        l2, v2 = m2(torch.from_numpy(x).permute(0, 3, 1, 2))
+    assert torch.equal(l2, lt) and torch.equal(v2, vt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [2, 7])
+def test_inference_engine_fp32_within_1e3(blocks):
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(blocks, "cuda:0", torch.float32, seed=1)
+    x = _positions(32, 1)
+    logits, v = net.forward(x)
+    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, blocks)
+    assert logits.shape == (32, 2086) and v.shape == (32, 1) and logits.dtype == np.float32
+    assert np.abs(logits - ln).max() < 1e-3   # north_star tolerance: 1e-3 fp32
+    assert np.abs(v - vn).max() < 1e-3
+    # list-of-arrays input, as policy_update passes it (main.py:1170)
+    l2, v2 = net.forward([x[i] for i in range(4)])
+    assert np.allclose(l2, logits[:4], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_inference_engine_bf16_probabilities():
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(7, "cuda:0", torch.bfloat16, seed=1)
+    x = _positions(64, 2)
+    logits, v = net.forward(x)
+    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, 7)
+
+    def softmax(a):
+        e = np.exp(a - a.max(axis=1, keepdims=True))
+        return e / e.sum(axis=1, keepdims=True)
+    perr = np.abs(softmax(logits) - softmax(ln)).max()
+    print("bf16 tower: max|dlogit| %.4g  max|dprob| %.4g  max|dvalue| %.4g" % (np.abs(logits - ln).max(), perr, np.abs(v - vn).max()))
+    assert perr < 1e-3            # policy compared as probabilities
+    assert np.abs(v - vn).max() < 2e-2   # bf16 storage of 15 conv layers; value head itself is fp32
