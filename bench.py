@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--playout", type=int, default=1600)
     ap.add_argument("--blocks", type=int, default=7)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -148,13 +149,19 @@ def main():
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
     eng = SearchEngine(G, cap, local_rank, plane_dtype=torch.float32, channels=14, ctx=ctx)
-    net = PolicyValueNet(args.blocks, dev, tdt, seed=0)
+    net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
     eng.reset(boards, side, rr)
 
     ev_net = []  # (start, end) events around the net forward of every timed step
+    conv_ev = []  # (start, end) events around single launches of the dominant kernel
+
+    step_no = [0]
 
     def one_step(mode, timed):
+        # HIP events around every conv launch of every 8th timed step (same stream as the launches)
+        net.conv_events = conv_ev if (timed and step_no[0] % 8 == 0) else None
+        step_no[0] += 1
         planes, _ = eng.select(mode)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -211,21 +218,32 @@ def main():
     net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net])) if ev_net else float("nan")
     total_sims = float(G) * args.steps * world
     flops = flops_per_position(args.blocks) * G
-    achieved = flops / (net_ms * 1e-3) / 1e12
     peak = MFMA_PEAK_TFLOPS[args.dtype]
+    if conv_ev:
+        # dominant kernel: k_conv3x3_c128 (one launch = one fused tower layer over the whole batch)
+        conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
+        conv_flops = 2.0 * G * 90 * 1152 * 128
+        roof = {"bound": "mfma", "kernel": "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)",
+                "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                "us_per_launch": conv_ms * 1e3, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops,
+                "net_forward_ms_per_step": net_ms, "net_forward_tflops": flops / (net_ms * 1e-3) / 1e12}
+    else:
+        achieved = flops / (net_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "net forward via torch/MIOpen (conv tower + heads), all launches of one step",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "ms_per_launch_group": net_ms, "flops_per_step": flops}
     out = {
         "metric": "MCTS simulations/sec (whole node), playout=%d, %d-block net" % (playout, args.blocks),
         "value": total_sims / dt, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (BASELINE.json configs[2])" % (G, playout, args.blocks, args.dtype),
-                   "games_per_gpu": G, "playout": playout, "res_block_nums": args.blocks, "search_threads": 1,
+                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "res_block_nums": args.blocks, "search_threads": 1,
                    "positions": "seeded random playouts from the start position, ply~U[0,80]",
                    "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),
                    "trees_with_error_status": bad, "status_bits": st_bits},
-        "roofline": {"bound": "mfma", "kernel": "net forward (conv tower + heads), all launches of one step",
-                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                     "ms_per_launch_group": net_ms, "flops_per_step": flops},
+        "roofline": roof,
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

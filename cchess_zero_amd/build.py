@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcchess_hip.so")
-SOURCES = ["cz_api.hip", "cz_tables.hip", "cz_rules.hip", "cz_search.hip"]
+SOURCES = ["cz_api.hip", "cz_tables.hip", "cz_rules.hip", "cz_search.hip", "cz_conv.hip"]
 # -ffp-contract=off and correctly rounded f32 divide: the tree statistics are bit-exact
 # restatements of the reference's float32/float64 arithmetic.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -34,10 +34,11 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra=()):
+    extra = list(extra)
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc()] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

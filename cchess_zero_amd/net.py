@@ -128,11 +128,22 @@ class PolicyValueNet:
     accumulate on MFMA), heads in fp32.  forward_device() is the device-to-device path the search
     loop uses; forward() has the reference signature (policy_value_network.forward)."""
 
-    def __init__(self, res_block_nums=7, device="cuda:0", dtype=torch.bfloat16, seed=0, module=None):
+    def __init__(self, res_block_nums=7, device="cuda:0", dtype=torch.bfloat16, seed=0, module=None, backend="auto", ctx=None):
+        """backend: "hip"  = tower convs by the hand-written MFMA kernel cz_conv3x3_c128_bf16 (bf16 only),
+                    "torch" = tower convs by torch/MIOpen (any dtype; the fp32 parity path),
+                    "auto"  = hip for bf16 on a GPU, else torch."""
         self.device = torch.device(device)
         self.dtype = dtype
         self.module = (module or PolicyValueModule(res_block_nums, seed)).to(self.device)
         self.res_block_nums = self.module.res_block_nums
+        if backend == "auto":
+            backend = "hip" if (dtype == torch.bfloat16 and self.device.type == "cuda") else "torch"
+        if backend == "hip" and dtype != torch.bfloat16:
+            raise ValueError("the hip conv backend computes in bf16 (fp32 accumulate); use backend='torch' for %s" % dtype)
+        self.backend = backend
+        self._ctx = ctx
+        self._bufs = None
+        self.conv_events = None  # set to a list to collect (start, end) HIP events around each conv launch
         self.refresh()
 
     @torch.no_grad()
@@ -146,6 +157,13 @@ class PolicyValueNet:
             return w.to(dt).contiguous(memory_format=cl), b.to(dt)
         self.w_in = conv_pack(m.conv_in)
         self.w_blocks = [(conv_pack(a), conv_pack(b)) for a, b in m.blocks]
+        if self.backend == "hip":
+            def hip_pack(cb):
+                w, b = cb.folded()  # [O,I,3,3] fp32 with the BN scale folded in
+                # -> [tap = dy*3+dx][ci/8][co][ci%8] bf16: the LDS image of the B operand, slab by slab
+                wp = w.permute(2, 3, 1, 0).reshape(9, 16, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+                return wp, b.float().contiguous()
+            self.hip_blocks = [(hip_pack(a), hip_pack(b)) for a, b in m.blocks]
         # heads: 1x1 convs as fp32 matmuls over [B*90,128]
         wp, bp = m.policy_conv.folded()
         wv, bv = m.value_conv.folded()
@@ -158,6 +176,46 @@ class PolicyValueNet:
         self.v2_w = m.value_fc2.weight.float().t().contiguous()
         self.v2_b = m.value_fc2.bias.float()
 
+    def _hip_ctx(self):
+        if self._ctx is None:
+            from .engine import Context
+            self._ctx = Context(1, 2, self.device.index or 0)
+        return self._ctx
+
+    def _hip_conv(self, x, wb, res, out, relu=True):
+        """x, res, out: [B,90,128] bf16 contiguous device tensors; one launch = one fused layer."""
+        import ctypes as C
+        from ._lib import check, lib
+        wp, b = wb
+        ev = None
+        if self.conv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        check(lib().cz_conv3x3_c128_bf16(self._hip_ctx().h, C.c_void_p(x.data_ptr()), C.c_void_p(wp.data_ptr()),
+                                         C.c_void_p(b.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
+                                         C.c_void_p(out.data_ptr()), x.shape[0], 1 if relu else 0), "cz_conv3x3_c128_bf16")
+        if ev is not None:
+            ev[1].record()
+            self.conv_events.append(ev)
+        return out
+
+    def _hip_blocks_forward(self, h):
+        """h: [B,128,9,10] channels_last bf16 (first conv output) -> same shape after all residual blocks."""
+        B = h.shape[0]
+        if not h.is_contiguous(memory_format=torch.channels_last):
+            h = h.contiguous(memory_format=torch.channels_last)
+        cur = h.permute(0, 2, 3, 1).reshape(B, 90, FILTERS)  # same memory viewed as NHWC rows
+        if self._bufs is None or self._bufs[0].shape[0] != B:
+            self._bufs = [torch.empty((B, 90, FILTERS), dtype=torch.bfloat16, device=self.device) for _ in range(3)]
+        self._hip_ctx().bind_stream()
+        t = self._bufs[0]
+        for i, (w1, w2) in enumerate(self.hip_blocks):
+            y = self._bufs[1 + (i & 1)]           # never the buffer `cur` lives in
+            self._hip_conv(cur, w1, None, t)      # conv + BN + ReLU
+            self._hip_conv(t, w2, cur, y)         # conv + BN + residual + ReLU
+            cur = y
+        return cur.reshape(B, 9, 10, FILTERS).permute(0, 3, 1, 2)
+
     @torch.no_grad()
     def tower(self, planes):
         """planes [B,9,10,C>=14] (NHWC, any float dtype) -> trunk activations [B,128,9,10] channels_last."""
@@ -166,6 +224,8 @@ class PolicyValueNet:
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         h = F.relu_(F.conv2d(x, self.w_in[0], self.w_in[1], padding=1))
+        if self.backend == "hip":
+            return self._hip_blocks_forward(h)
         for (w1, b1), (w2, b2) in self.w_blocks:
             t = F.relu_(F.conv2d(h, w1, b1, padding=1))
             h = F.relu_(F.conv2d(t, w2, b2, padding=1).add_(h))

@@ -133,6 +133,17 @@ int cz_search_root_state(cz_ctx *, uint8_t *boards, uint8_t *side, int32_t *rest
  *   (>= 0; at most max_records are written) or a negative error. */
 int cz_search_tree_dump(cz_ctx *, int g, int32_t *host_out, int max_records);
 
+/* ---- N1: policy/value network kernels ---------------------------------------------------------
+ * One residual-tower layer: 3x3 SAME convolution 128->128 over [B][9][10] boards, NHWC bf16, with the
+ * (BN-folded) bias, optional residual add and optional ReLU fused in.
+ * replaces: tf.layers.conv2d(128,3,'SAME') + tf.contrib.layers.batch_norm(center=False) [+ tf.add(orig,.)]
+ *           + tf.nn.relu, policy_value_network.py:45-47 and residual_block :151-162.
+ *   in, residual, out : [B][90][128] bf16 (residual may be NULL; out must not alias in)
+ *   wpk  : [9 taps = dy*3+dx][16 = ci/8][128 co][8 = ci%8] bf16, BN scale folded in (net.py packs it)
+ *   bias : [128] float32, BN folded */
+int cz_conv3x3_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float *bias,
+                         const void *residual, void *out, int B, int relu);
+
 #ifdef __cplusplus
 }
 #endif

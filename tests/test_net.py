@@ -75,3 +75,53 @@ def test_inference_engine_bf16_probabilities():
     print("bf16 tower: max|dlogit| %.4g  max|dprob| %.4g  max|dvalue| %.4g" % (np.abs(logits - ln).max(), perr, np.abs(v - vn).max()))
     assert perr < 1e-3            # policy compared as probabilities
     assert np.abs(v - vn).max() < 2e-2   # bf16 storage of 15 conv layers; value head itself is fp32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,residual,relu", [(4, False, True), (7, True, True), (64, True, False), (513, False, False), (1, True, True)])
+def test_hip_conv3x3_kernel_vs_torch(B, residual, relu):
+    """cz_conv3x3_c128_bf16 (MFMA implicit GEMM, fused bias/residual/ReLU) vs an fp32 torch conv on the
+    same bf16-rounded operands.  Tolerance: one bf16 rounding of the output (2^-8 relative) plus the
+    bf16 rounding before the residual add; accumulation order differs (fp32)."""
+    import torch.nn.functional as F
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(1, "cuda:0", torch.bfloat16, seed=4, backend="hip")
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    x = torch.randn((B, 90, 128), generator=gen, device="cuda").to(torch.bfloat16)
+    # asymmetric, tap- and channel-dependent weights so that any tap/channel/transposition mix-up shows
+    w = (torch.randn((128, 128, 3, 3), generator=gen, device="cuda") * 0.05)
+    w[:, :, 0, 1] += 0.02
+    w[:, :, 2, 0] -= 0.03
+    bias = torch.randn(128, generator=gen, device="cuda")
+    res = torch.randn((B, 90, 128), generator=gen, device="cuda").to(torch.bfloat16) if residual else None
+    wp = w.permute(2, 3, 1, 0).reshape(9, 16, 8, 128).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+    out = torch.full((B, 90, 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+    net._hip_conv(x, (wp, bias.float().contiguous()), res, out, relu)
+    torch.cuda.synchronize()
+    xr = x.float().reshape(B, 9, 10, 128).permute(0, 3, 1, 2)
+    ref = F.conv2d(xr, w.to(torch.bfloat16).float(), bias, padding=1)
+    ref = ref.to(torch.bfloat16).float()  # the kernel rounds to bf16 before the residual add
+    if residual:
+        ref = ref + res.float().reshape(B, 9, 10, 128).permute(0, 3, 1, 2)
+    if relu:
+        ref = torch.relu(ref)
+    got = out.float().reshape(B, 9, 10, 128).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 2e-2
+    assert bool((err <= tol).all()), "max err %.4g at %s" % (float(err.max()), tuple(int(i) for i in (err == err.max()).nonzero()[0]))
+
+
+@pytest.mark.gpu
+def test_hip_tower_matches_torch_tower():
+    """Whole 7-block tower: hip backend vs torch/MIOpen backend in bf16 (same folded weights)."""
+    from cchess_zero_amd.net import PolicyValueNet
+    a = PolicyValueNet(7, "cuda:0", torch.bfloat16, seed=1, backend="hip")
+    b = PolicyValueNet(7, "cuda:0", torch.bfloat16, seed=1, backend="torch")
+    x = torch.from_numpy(_positions(37, 3)).cuda()
+    la, va = a.forward_device(x)
+    lb, vb = b.forward_device(x)
+    pa, pb = torch.softmax(la, 1), torch.softmax(lb, 1)
+    print("hip vs torch bf16 tower: max|dlogit| %.4g max|dprob| %.4g max|dv| %.4g" %
+          (float((la - lb).abs().max()), float((pa - pb).abs().max()), float((va - vb).abs().max())))
+    assert float((pa - pb).abs().max()) < 1e-3 and float((va - vb).abs().max()) < 2e-2
