@@ -222,8 +222,11 @@ def main():
     if conv_ev:
         # dominant kernel: k_conv3x3_c128 (one launch = one fused tower layer over the whole batch)
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
-        conv_flops = 2.0 * G * 90 * 1152 * 128
-        roof = {"bound": "mfma", "kernel": "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)",
+        nl = 2 * args.blocks if net.backend == "hip" else 1   # fused tower: one launch = all 2*blocks conv layers
+        conv_flops = 2.0 * G * 90 * 1152 * 128 * nl
+        kname = ("k_tower_c128 (whole residual tower, %d fused conv3x3+BN(+residual)+ReLU layers, LDS-resident activations, bf16 MFMA, fp32 acc)" % nl
+                 if net.backend == "hip" else "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)")
+        roof = {"bound": "mfma", "kernel": kname,
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / peak, "traffic": None,
                 "us_per_launch": conv_ms * 1e3, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops,

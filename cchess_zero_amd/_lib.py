@@ -44,6 +44,7 @@ _SIGS = {
     "cz_search_root_state": (C.c_int, [C.c_void_p, _u8p, _u8p, _i32p]),
     "cz_search_tree_dump": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cz_conv3x3_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
+    "cz_tower_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
 }
 
 EXPORTS = tuple(sorted(_SIGS))

@@ -129,16 +129,17 @@ class PolicyValueNet:
     loop uses; forward() has the reference signature (policy_value_network.forward)."""
 
     def __init__(self, res_block_nums=7, device="cuda:0", dtype=torch.bfloat16, seed=0, module=None, backend="auto", ctx=None):
-        """backend: "hip"  = tower convs by the hand-written MFMA kernel cz_conv3x3_c128_bf16 (bf16 only),
-                    "torch" = tower convs by torch/MIOpen (any dtype; the fp32 parity path),
-                    "auto"  = hip for bf16 on a GPU, else torch."""
+        """backend: "hip"       = the whole residual tower in ONE fused MFMA launch, cz_tower_c128_bf16 (bf16 only),
+                    "hip-layer" = one fused conv launch per layer, cz_conv3x3_c128_bf16 (bf16 only),
+                    "torch"     = tower convs by torch/MIOpen (any dtype; the fp32 parity path),
+                    "auto"      = hip for bf16 on a GPU, else torch."""
         self.device = torch.device(device)
         self.dtype = dtype
         self.module = (module or PolicyValueModule(res_block_nums, seed)).to(self.device)
         self.res_block_nums = self.module.res_block_nums
         if backend == "auto":
             backend = "hip" if (dtype == torch.bfloat16 and self.device.type == "cuda") else "torch"
-        if backend == "hip" and dtype != torch.bfloat16:
+        if backend.startswith("hip") and dtype != torch.bfloat16:
             raise ValueError("the hip conv backend computes in bf16 (fp32 accumulate); use backend='torch' for %s" % dtype)
         self.backend = backend
         self._ctx = ctx
@@ -157,13 +158,16 @@ class PolicyValueNet:
             return w.to(dt).contiguous(memory_format=cl), b.to(dt)
         self.w_in = conv_pack(m.conv_in)
         self.w_blocks = [(conv_pack(a), conv_pack(b)) for a, b in m.blocks]
-        if self.backend == "hip":
+        if self.backend.startswith("hip"):
             def hip_pack(cb):
                 w, b = cb.folded()  # [O,I,3,3] fp32 with the BN scale folded in
                 # -> [tap = dy*3+dx][ci/8][co][ci%8] bf16: the LDS image of the B operand, slab by slab
                 wp = w.permute(2, 3, 1, 0).reshape(9, 16, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
                 return wp, b.float().contiguous()
             self.hip_blocks = [(hip_pack(a), hip_pack(b)) for a, b in m.blocks]
+            layers = [x for blk in self.hip_blocks for x in blk]
+            self.hip_tower_w = torch.stack([w for w, _ in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.bfloat16, device=self.device)
+            self.hip_tower_b = torch.stack([b for _, b in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.float32, device=self.device)
         # heads: 1x1 convs as fp32 matmuls over [B*90,128]
         wp, bp = m.policy_conv.folded()
         wv, bv = m.value_conv.folded()
@@ -199,6 +203,29 @@ class PolicyValueNet:
             self.conv_events.append(ev)
         return out
 
+    def _hip_tower_forward(self, h):
+        """h: [B,128,9,10] channels_last bf16 -> all residual blocks in one launch (activations stay in LDS)."""
+        import ctypes as C
+        from ._lib import check, lib
+        B = h.shape[0]
+        if not h.is_contiguous(memory_format=torch.channels_last):
+            h = h.contiguous(memory_format=torch.channels_last)
+        x = h.permute(0, 2, 3, 1).reshape(B, 90, FILTERS)
+        if self.res_block_nums == 0:
+            return h
+        self._hip_ctx().bind_stream()
+        ev = None
+        if self.conv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        check(lib().cz_tower_c128_bf16(self._hip_ctx().h, C.c_void_p(x.data_ptr()), C.c_void_p(self.hip_tower_w.data_ptr()),
+                                       C.c_void_p(self.hip_tower_b.data_ptr()), C.c_void_p(x.data_ptr()), B, self.res_block_nums),
+              "cz_tower_c128_bf16")
+        if ev is not None:
+            ev[1].record()
+            self.conv_events.append(ev)
+        return x.reshape(B, 9, 10, FILTERS).permute(0, 3, 1, 2)
+
     def _hip_blocks_forward(self, h):
         """h: [B,128,9,10] channels_last bf16 (first conv output) -> same shape after all residual blocks."""
         B = h.shape[0]
@@ -225,6 +252,8 @@ class PolicyValueNet:
             x = x.contiguous(memory_format=torch.channels_last)
         h = F.relu_(F.conv2d(x, self.w_in[0], self.w_in[1], padding=1))
         if self.backend == "hip":
+            return self._hip_tower_forward(h)
+        if self.backend == "hip-layer":
             return self._hip_blocks_forward(h)
         for (w1, b1), (w2, b2) in self.w_blocks:
             t = F.relu_(F.conv2d(h, w1, b1, padding=1))

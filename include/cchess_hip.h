@@ -144,6 +144,15 @@ int cz_search_tree_dump(cz_ctx *, int g, int32_t *host_out, int max_records);
 int cz_conv3x3_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float *bias,
                          const void *residual, void *out, int B, int relu);
 
+/* The whole residual tower (nblocks x [conv3x3+BN+ReLU, conv3x3+BN, add, ReLU]) in ONE launch:
+ * activations stay in LDS across all 2*nblocks layers, only `in` and `out` touch HBM.
+ * replaces: the `for _ in range(res_block_nums): residual_block(...)` loop, policy_value_network.py:50-53,151-162.
+ *   in, out : [B][90][128] bf16 (may alias)
+ *   wpk  : [2*nblocks][9][16][128][8] bf16 (layer-major, same per-layer packing as cz_conv3x3_c128_bf16)
+ *   bias : [2*nblocks][128] float32 */
+int cz_tower_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float *bias, void *out, int B,
+                       int nblocks);
+
 #ifdef __cplusplus
 }
 #endif

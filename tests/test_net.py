@@ -85,7 +85,7 @@ def test_hip_conv3x3_kernel_vs_torch(B, residual, relu):
     bf16 rounding before the residual add; accumulation order differs (fp32)."""
     import torch.nn.functional as F
     from cchess_zero_amd.net import PolicyValueNet
-    net = PolicyValueNet(1, "cuda:0", torch.bfloat16, seed=4, backend="hip")
+    net = PolicyValueNet(1, "cuda:0", torch.bfloat16, seed=4, backend="hip-layer")
     gen = torch.Generator(device="cuda").manual_seed(B)
     x = torch.randn((B, 90, 128), generator=gen, device="cuda").to(torch.bfloat16)
     # asymmetric, tap- and channel-dependent weights so that any tap/channel/transposition mix-up shows
@@ -113,15 +113,52 @@ def test_hip_conv3x3_kernel_vs_torch(B, residual, relu):
 
 
 @pytest.mark.gpu
-def test_hip_tower_matches_torch_tower():
-    """Whole 7-block tower: hip backend vs torch/MIOpen backend in bf16 (same folded weights)."""
+@pytest.mark.parametrize("backend,blocks,n", [("hip", 7, 37), ("hip-layer", 7, 37), ("hip", 2, 1), ("hip", 19, 130)])
+def test_hip_tower_matches_torch_tower(backend, blocks, n):
+    """Whole tower: fused single-launch kernel / per-layer kernel vs torch/MIOpen in bf16 (same folded
+    weights); odd batch sizes exercise the partial last workgroup."""
     from cchess_zero_amd.net import PolicyValueNet
-    a = PolicyValueNet(7, "cuda:0", torch.bfloat16, seed=1, backend="hip")
-    b = PolicyValueNet(7, "cuda:0", torch.bfloat16, seed=1, backend="torch")
-    x = torch.from_numpy(_positions(37, 3)).cuda()
+    a = PolicyValueNet(blocks, "cuda:0", torch.bfloat16, seed=1, backend=backend)
+    b = PolicyValueNet(blocks, "cuda:0", torch.bfloat16, seed=1, backend="torch")
+    x = torch.from_numpy(_positions(n, 3)).cuda()
     la, va = a.forward_device(x)
     lb, vb = b.forward_device(x)
     pa, pb = torch.softmax(la, 1), torch.softmax(lb, 1)
-    print("hip vs torch bf16 tower: max|dlogit| %.4g max|dprob| %.4g max|dv| %.4g" %
-          (float((la - lb).abs().max()), float((pa - pb).abs().max()), float((va - vb).abs().max())))
+    print("%s vs torch bf16 tower (%d blocks): max|dlogit| %.4g max|dprob| %.4g max|dv| %.4g" %
+          (backend, blocks, float((la - lb).abs().max()), float((pa - pb).abs().max()), float((va - vb).abs().max())))
     assert float((pa - pb).abs().max()) < 1e-3 and float((va - vb).abs().max()) < 2e-2
+    # trunk activations themselves (before the heads), elementwise in bf16 units
+    ta, tb = a.tower(x).float(), b.tower(x).float()
+    assert float((ta - tb).abs().max()) <= 0.05 * float(tb.abs().max()) + 1e-2
+
+
+@pytest.mark.gpu
+def test_fused_tower_with_structured_weights():
+    """Tap/channel-asymmetric weights, non-zero BN statistics and biases through the fused tower vs the
+    fp32 NumPy restatement of the TF graph (catches tap, channel-order and residual mix-ups that
+    symmetric Glorot weights could hide)."""
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(3, "cuda:0", torch.bfloat16, seed=2, backend="hip")
+    gen = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for cb in net.module.convbns():
+            cb.moving_mean.copy_((torch.randn(cb.moving_mean.shape, generator=gen) * 0.05).to(cb.moving_mean.device))
+            cb.moving_var.copy_((torch.rand(cb.moving_var.shape, generator=gen) + 0.5).to(cb.moving_var.device))
+            cb.conv.bias.copy_((torch.randn(cb.conv.bias.shape, generator=gen) * 0.05).to(cb.conv.bias.device))
+            w = cb.conv.weight
+            if w.shape[-1] == 3:
+                w[:, :, 0, 1] += 0.01
+                w[:, :, 2, 0] -= 0.015
+                w[:, : w.shape[1] // 2, 1, 2] += 0.02
+    net.refresh()
+    x = _positions(16, 5)
+    logits, v = net.forward(x)
+    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, 3)
+
+    def softmax(a):
+        e = np.exp(a - a.max(axis=1, keepdims=True))
+        return e / e.sum(axis=1, keepdims=True)
+    print("structured weights: max|dlogit| %.4g, max|dprob| %.4g, max|dv| %.4g" % (np.abs(logits - ln).max(), np.abs(softmax(logits) - softmax(ln)).max(), np.abs(v - vn).max()))
+    assert np.abs(softmax(logits) - softmax(ln)).max() < 1e-3
+    assert np.abs(logits - ln).max() < 0.05 * np.abs(ln).max() + 1e-2
+    assert np.abs(v - vn).max() < 2e-2

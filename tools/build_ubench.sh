@@ -1,0 +1,27 @@
+#!/bin/bash
+# builds tools/ubench/conv_<tag> variants (cross-compiles here, runs on the GPU box)
+set -e
+cd "$(dirname "$0")"
+mkdir -p ubench
+build() { tag=$1; shift; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" -o ubench/conv_$tag conv_ubench.hip & }
+build base
+build noact -DCZ_ABL=1
+build noepi -DCZ_ABL=2
+build noactepi -DCZ_ABL=3
+build nomfma -DCZ_ABL=4
+build nolds -DCZ_ABL=8
+build nowstream -DCZ_ABL=16
+build mfmaonly -DCZ_ABL=27
+build_t() { tag=$1; shift; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" -o ubench/tower_$tag tower_ubench.hip & }
+build_t base
+build_t nomfma -DCZ_TABL=1
+build_t nofrag -DCZ_TABL=2
+build_t nowstream -DCZ_TABL=4
+build_t noepi -DCZ_TABL=8
+build_t mfmaonly -DCZ_TABL=14
+build_t trace -DCZ_TTRACE=1
+build_t dmaonly -DCZ_TABL=11
+build_t fragonly -DCZ_TABL=13
+build_t epionly -DCZ_TABL=7
+wait
+ls -la ubench
