@@ -1,0 +1,106 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard games by rank and all-gather packed (s, pi, z)
+records; record packing round-trips and expands to the reference's dense training tuples."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_records(rank, n, seed=0):
+    """Records produced by playing random games with the C oracle (stand-in for the GPU self-play)."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from cchess_zero_amd import selfplay as SP
+    rng = np.random.default_rng(seed + 17 * rank)
+    B, S, L, P, C, Z = [], [], [], [], [], []
+    b, s = O.fen_to_board(O.START_FEN), 0
+    for i in range(n):
+        mv = O.legal_moves(b, s)
+        k = len(mv)
+        pr = rng.random(k).astype(np.float32)
+        pr /= pr.sum()
+        l2 = np.full(128, 0xFFFF, np.uint16); l2[:k] = mv
+        p2 = np.zeros(128, np.float32); p2[:k] = pr
+        B.append(b.copy()); S.append(s); L.append(l2); P.append(p2); C.append(k); Z.append(int(rng.integers(-1, 2)))
+        nb, cap, term = O.apply_move(b, int(mv[rng.integers(k)]))
+        if term:
+            b, s = O.fen_to_board(O.START_FEN), 0
+        else:
+            b, s = nb, s ^ 1
+    return SP.pack_records(np.stack(B), np.asarray(S, np.uint8), np.stack(L), np.stack(P), np.asarray(C, np.uint8), np.asarray(Z, np.int8))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cchess_zero_amd import parallel as PL
+    games = PL.shard_games(11, rank, world)
+    rec = _fake_records(rank, 5 + 3 * rank)         # ragged shards: 5 and 8 records
+    allrec = PL.gather_records(rec)
+    empty = PL.gather_records(np.zeros((0, rec.shape[1]), np.uint8) if rank == 0 else rec)  # one empty shard
+    # weight broadcast + gradient all-reduce
+    lin = torch.nn.Linear(4, 3)
+    torch.manual_seed(rank)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 1))
+    PL.broadcast_weights(lin, src=0)
+    lin.weight.grad = torch.full_like(lin.weight, float(rank))
+    lin.bias.grad = torch.full_like(lin.bias, float(2 * rank))
+    PL.allreduce_gradients(lin)
+    q.put((rank, games.tolist(), rec.tobytes(), allrec.tobytes(), allrec.shape, empty.shape,
+           float(lin.weight[0, 0]), float(lin.weight.grad[0, 0]), float(lin.bias.grad[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_shard_and_gather():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, g0, rec0, all0, shape0, e0, w0, gw0, gb0), (r1, g1, rec1, all1, shape1, e1, w1, gw1, gb1) = res
+    assert g0 == [0, 2, 4, 6, 8, 10] and g1 == [1, 3, 5, 7, 9]          # games sharded g % world
+    assert all0 == all1 and shape0 == shape1 == (13, shape0[1])          # same gathered buffer everywhere
+    assert all0 == rec0 + rec1                                           # rank order, padding stripped
+    assert e0 == e1 == (8, shape0[1])                                    # an empty shard is fine
+    assert w0 == w1 == 1.0                                               # broadcast from rank 0
+    assert gw0 == gw1 == 0.5 and gb0 == gb1 == 1.0                       # averaged gradients
+
+
+def test_record_roundtrip_and_dense_expansion():
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from cchess_zero_amd import selfplay as SP
+    from cchess_zero_amd import _lib
+    rec = _fake_records(0, 40, seed=3)
+    u = SP.unpack_records(rec)
+    assert rec.shape[1] == SP.REC_BYTES
+    planes, pi, z = SP.to_dense(rec)
+    unflip = _lib.tables()["unflip"]
+    for i in range(len(z)):
+        k = int(u["counts"][i])
+        assert np.array_equal(u["labels"][i, :k], O.legal_moves(u["boards"][i], int(u["side"][i])))
+        # planes == generate_inputs of the recorded position (oracle = reference restatement)
+        assert np.array_equal(planes[i], O.encode_planes(u["boards"][i], int(u["side"][i])))
+        # pi lives on canonical labels: rank-flipped for black (main.py:1507-1512)
+        lab = u["labels"][i, :k].astype(np.int64)
+        if u["side"][i]:
+            lab = unflip[lab]
+        assert abs(float(pi[i].sum()) - 1.0) < 2e-2          # fp16 storage of the probabilities
+        assert np.count_nonzero(pi[i]) <= k and np.all(pi[i, lab] >= 0)
+        assert z[i] in (-1.0, 0.0, 1.0)
