@@ -48,6 +48,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CZ_TTRACE
 #define CZ_TTRACE 0
 #endif
+#ifndef CZ_TOWER_SGB
+#define CZ_TOWER_SGB 1
+#endif
 // tower ablations: 1 = no MFMA, 2 = no fragment reads, 4 = no weight stream, 8 = no layer epilogue
 #ifndef CZ_TABL
 #define CZ_TABL 0
@@ -281,6 +284,61 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {  // one v_
 
 struct TwFrag { bf16x8 a[CV_RT]; bf16x8 b[CV_CT]; };
 
+// One k-step (16 input channels) of the slab loop, hand-scheduled: waits until fragment set Y has
+// landed (LGKM = number of newer LDS reads allowed in flight), then issues the 6 MFMAs of Y with the
+// address math (2 VALU per row tile) and the five ds_read_b128 of set X — needed two k-steps later —
+// in their issue shadow.  CA = 16-byte chunk index of the A rows to fetch (without the lane's k-half,
+// which is folded into the swizzle key), OB0/OB1 = byte offsets of the two B columns in the slab.
+// Weights are the MFMA A operand: D[channel][cell].
+#define TW_KSTEP(LGKM, CA, OB0, OB1, Y, X, AB, KEY, VB, TAIL)                                        \
+    asm volatile(                                                                                    \
+        "s_waitcnt lgkmcnt(" #LGKM ")\n\t"                                                           \
+        "v_xor_b32 %[t0], " #CA ", %[k0]\n\t"                                                        \
+        "v_mfma_f32_32x32x16_bf16 %[c00], %[yb0], %[ya0], %[c00]\n\t"                                \
+        "v_xor_b32 %[t1], " #CA ", %[k1]\n\t"                                                        \
+        "v_xor_b32 %[t2], " #CA ", %[k2]\n\t"                                                        \
+        "v_lshl_add_u32 %[t0], %[t0], 4, %[b0]\n\t"                                                  \
+        "v_lshl_add_u32 %[t1], %[t1], 4, %[b1]\n\t"                                                  \
+        "v_lshl_add_u32 %[t2], %[t2], 4, %[b2]\n\t"                                                  \
+        "v_mfma_f32_32x32x16_bf16 %[c01], %[yb1], %[ya0], %[c01]\n\t"                                \
+        "ds_read_b128 %[xa0], %[t0]\n\t"                                                             \
+        "ds_read_b128 %[xa1], %[t1]\n\t"                                                             \
+        "v_mfma_f32_32x32x16_bf16 %[c10], %[yb0], %[ya1], %[c10]\n\t"                                \
+        "ds_read_b128 %[xa2], %[t2]\n\t"                                                             \
+        "ds_read_b128 %[xb0], %[vb] offset:" #OB0 "\n\t"                                             \
+        "v_mfma_f32_32x32x16_bf16 %[c11], %[yb1], %[ya1], %[c11]\n\t"                                \
+        "ds_read_b128 %[xb1], %[vb] offset:" #OB1 "\n\t"                                             \
+        "v_mfma_f32_32x32x16_bf16 %[c20], %[yb0], %[ya2], %[c20]\n\t"                                \
+        "v_mfma_f32_32x32x16_bf16 %[c21], %[yb1], %[ya2], %[c21]\n\t" TAIL                            \
+        : [c00] "+a"(acc[0][0]), [c01] "+a"(acc[0][1]), [c10] "+a"(acc[1][0]), [c11] "+a"(acc[1][1]),  \
+          [c20] "+a"(acc[2][0]), [c21] "+a"(acc[2][1]), [xa0] "=&v"(X.a[0]), [xa1] "=&v"(X.a[1]),      \
+          [xa2] "=&v"(X.a[2]), [xb0] "=&v"(X.b[0]), [xb1] "=&v"(X.b[1]), [t0] "=&v"(t0), [t1] "=&v"(t1), \
+          [t2] "=&v"(t2)                                                                              \
+        : [ya0] "v"(Y.a[0]), [ya1] "v"(Y.a[1]), [ya2] "v"(Y.a[2]), [yb0] "v"(Y.b[0]), [yb1] "v"(Y.b[1]), \
+          [k0] "v"(KEY[0]), [k1] "v"(KEY[1]), [k2] "v"(KEY[2]), [b0] "v"(AB[0]), [b1] "v"(AB[1]),      \
+          [b2] "v"(AB[2]), [vb] "v"(VB)                                                               \
+        : "memory")
+
+// the five fragment reads of one k-step, no MFMAs (layer prologue)
+#define TW_LOADSET(CA, OB0, OB1, X, AB, KEY, VB)                                                     \
+    asm volatile(                                                                                    \
+        "v_xor_b32 %[t0], " #CA ", %[k0]\n\t"                                                        \
+        "v_xor_b32 %[t1], " #CA ", %[k1]\n\t"                                                        \
+        "v_xor_b32 %[t2], " #CA ", %[k2]\n\t"                                                        \
+        "v_lshl_add_u32 %[t0], %[t0], 4, %[b0]\n\t"                                                  \
+        "v_lshl_add_u32 %[t1], %[t1], 4, %[b1]\n\t"                                                  \
+        "v_lshl_add_u32 %[t2], %[t2], 4, %[b2]\n\t"                                                  \
+        "ds_read_b128 %[xa0], %[t0]\n\t"                                                             \
+        "ds_read_b128 %[xa1], %[t1]\n\t"                                                             \
+        "ds_read_b128 %[xa2], %[t2]\n\t"                                                             \
+        "ds_read_b128 %[xb0], %[vb] offset:" #OB0 "\n\t"                                             \
+        "ds_read_b128 %[xb1], %[vb] offset:" #OB1 "\n\t"                                             \
+        : [xa0] "=&v"(X.a[0]), [xa1] "=&v"(X.a[1]), [xa2] "=&v"(X.a[2]), [xb0] "=&v"(X.b[0]),         \
+          [xb1] "=&v"(X.b[1]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)                          \
+        : [k0] "v"(KEY[0]), [k1] "v"(KEY[1]), [k2] "v"(KEY[2]), [b0] "v"(AB[0]), [b1] "v"(AB[1]),      \
+          [b2] "v"(AB[2]), [vb] "v"(VB)                                                               \
+        : "memory")
+
 __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__restrict__ in,
                                                               const uint16_t *__restrict__ wpk,   // [L][9][16][128][8]
                                                               const float *__restrict__ bias,     // [L][128]
@@ -294,82 +352,66 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
     const int npos = (B - pos0) < TW_P ? (B - pos0) : TW_P;
     const int nrows = npos * 90;
     const int nslabs = nlayers * 18;
-    const uint4 *wg = reinterpret_cast<const uint4 *>(wpk) + tid;
+    // LDS addressing: rows of 256 B; the 16-byte chunk c of a row lives at chunk c ^ (absolute row & 15)
+    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
 
-    // a wave-instruction of LDS-DMA moves 1 KB to [wave-uniform LDS base + lane*16]; 4 per thread and slab
+    // a wave-instruction of LDS-DMA moves 1 KB to [wave-uniform LDS base + lane*16]; 4 per thread and slab.
+    // Past the end of the stream the last slab is re-fetched into a free buffer (never read): the slab body
+    // stays branch-free and the vmcnt accounting constant.
+    static_assert(TW_NBUF == 4, "ring index is computed with & 3");
+    const unsigned dma_voff = (unsigned)tid << 4;   // this lane's 16 bytes inside a 4 KB quarter-slab
     auto dma_slab = [&](int slab) {
-        if (CZ_TABL & 4) return;
-        const uint4 *src = wg + (size_t)slab * TW_SLAB_U4;
-        unsigned char *dst = wbuf + (slab % TW_NBUF) * TW_SLAB_BYTES + (wave << 10);
+        const int gs = slab < nslabs ? slab : nslabs - 1;
+        // uniform 64-bit base + 32-bit lane offset: selects the SGPR-base form of global_load_lds
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gs * TW_SLAB_BYTES;
+        unsigned char *dst = wbuf + ((unsigned)slab & 3u) * TW_SLAB_BYTES + (wave << 10);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + q * TW_THREADS),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + q * 4096 + dma_voff),
                                              (__attribute__((address_space(3))) void *)(dst + q * 4096), 16, 0, 0);
     };
-    for (int q = 0; q < 3 && q < nslabs; ++q) dma_slab(q);
+    for (int q = 0; q < 3; ++q) dma_slab(q);
     {   // stage x into U (swizzled rows), clear the zero row
         const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
         for (int idx = tid; idx < TW_ROWS * 16; idx += TW_THREADS) {
             const int r = idx >> 4, c = idx & 15;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < nrows) v = g[idx];
-            *reinterpret_cast<uint4 *>(smem + r * CV_ROWB + ((c ^ (r & 15)) << 4)) = v;
+            *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
         }
         if (tid < 16) *reinterpret_cast<uint4 *>(smem + TW_ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int hh[CV_RT], ww[CV_RT], rown[CV_RT];
+    // per-lane geometry of the 3 row tiles this wave owns: byte offset of the cell's row inside a buffer and
+    // a 9-bit mask of the taps that stay on the 9x10 board
+    int rowb[CV_RT], tapmask[CV_RT];
 #pragma unroll
     for (int i = 0; i < CV_RT; ++i) {
         const int r = 32 * (wr * CV_RT + i) + l31;
-        rown[i] = r;
-        const int pix = r % 90;
-        hh[i] = pix / 10;
-        ww[i] = pix - hh[i] * 10;
-        if (r >= TW_ROWS) hh[i] = -100;
+        const int pix = r % 90, h = pix / 10, w = pix - h * 10;
+        rowb[i] = r * CV_ROWB;
+        int m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
+            if (r < TW_ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+        }
+        tapmask[i] = m;
     }
-    const int bcol = (wc * 64 + l31) << 4;
-
-    // activation-row addressing of one tap: out-of-board taps read the zero row
-    auto tap_addr = [&](int tap, int src_off, int (&abase)[CV_RT], int (&asw)[CV_RT]) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    // activation-row addressing of one tap: out-of-board taps (and padding rows) read the zero row.
+    // key = swizzle key of the source row with the lane's k-half folded in.
+    auto tap_addr = [&](int tap, int src_off, int (&ab)[CV_RT], int (&key)[CV_RT]) {
+        const int delta = src_off + ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
-            const int y = hh[i] + dy, x = ww[i] + dx;
-            const bool ok = (y >= 0) && (y < 9) && (x >= 0) && (x < 10);
-            const int rr = rown[i] + dy * 10 + dx;
-            abase[i] = ok ? src_off + rr * CV_ROWB : TW_ZERO_OFF;
-            asw[i] = ok ? (rr & 15) : 0;
+            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : TW_ZERO_OFF;
+            ab[i] = a;
+            key[i] = ((a >> 8) & 15) ^ khalf;
         }
     };
-    // fragments of k-step kk (0..3) of a slab: 8 channels per lane from 3 cells + 2 weight columns
-    auto load_frag = [&](TwFrag &f, const int (&abase)[CV_RT], const int (&asw)[CV_RT], int half, int kk,
-                         const unsigned char *wb) {
-        const int c = half * 8 + kk * 2 + khalf;
-        if (CZ_TABL & 2) {
-#pragma unroll
-            for (int i = 0; i < CV_RT; ++i) asm volatile("" : "+v"(f.a[i]) : "v"(abase[i] + c));
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j) asm volatile("" : "+v"(f.b[j]) : "v"(bcol + kk));
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < CV_RT; ++i)
-            f.a[i] = *reinterpret_cast<const bf16x8 *>(smem + abase[i] + ((c ^ asw[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < CV_CT; ++j)
-            f.b[j] = *reinterpret_cast<const bf16x8 *>(wb + (kk * 2 + khalf) * 2048 + bcol + j * 512);
-    };
+    const int vb0 = TW_W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);   // this lane's B column in slab buffer 0
 
-#if CZ_TTRACE
-    unsigned long long *trace = reinterpret_cast<unsigned long long *>(out) + (size_t)(blockIdx.x == 1500 ? 0 : (1 << 20));
-    const bool tr = (blockIdx.x == 1500) && tid == 0;
-#define TW_STAMP(slot) if (tr) trace[slot] = __builtin_amdgcn_s_memtime();
-#else
-#define TW_STAMP(slot)
-#endif
     int g = 0;  // running slab index over all layers
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
@@ -382,15 +424,6 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
             for (int j = 0; j < CV_CT; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        auto mma = [&](const TwFrag &f) {
-#pragma unroll
-            for (int i = 0; i < CV_RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CV_CT; ++j) {
-                    if (CZ_TABL & 1) { asm volatile("" :: "v"(f.a[i]), "v"(f.b[j])); acc[i][j][0] += 1.0f; }
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
-                }
-        };
         // this layer's bias for the 2 x 4 channel quads a lane owns: in flight during the whole main loop
         float4 breg[CV_CT][4];
 #pragma unroll
@@ -398,63 +431,55 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 breg[j][q] = *reinterpret_cast<const float4 *>(bias + layer * 128 + wc * 64 + j * 32 + 8 * q + 4 * khalf);
-        int abase[CV_RT], asw[CV_RT];
-        TwFrag f0 = {}, f1 = {}, f2 = {}, f3 = {};
-        tap_addr(0, src_off, abase, asw);
-        {   // the only exposed fragment loads of the layer
-            const unsigned char *wb0 = wbuf + (g % TW_NBUF) * TW_SLAB_BYTES;
-            load_frag(f0, abase, asw, 0, 0, wb0);
-            load_frag(f1, abase, asw, 0, 1, wb0);
+        int ab[CV_RT], key[CV_RT], nab[CV_RT], nkey[CV_RT], t0, t1, t2;
+        TwFrag f0, f1, f2, f3;
+        tap_addr(0, src_off, ab, key);
+        {   // the only exposed fragment loads of the layer.  Issued from asm as well: LDS reads the compiler
+            // knows about would make it drain lgkmcnt(0) in front of the first k-steps of every iteration.
+            const int vb = vb0 + (((unsigned)g & 3u) << 14);
+            TW_LOADSET(0, 0, 512, f0, ab, key, vb);
+            TW_LOADSET(2, 4096, 4608, f1, ab, key, vb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        // mid-slab: slab g+1 (DMA issued two barriers ago) must have landed for this wave — at most the 4 DMA
+        // instructions of slab g+2 may still be in flight; the barrier publishes it and proves every wave has
+        // left slab g-1, whose buffer the DMA of slab g+3 refills.  No lgkmcnt drain here.
+#define TW_MID()                                                  \
+        if (!(CZ_TABL & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
+        if (!(CZ_TABL & 32)) __builtin_amdgcn_s_barrier();                             \
+        asm volatile("" ::: "memory");                            \
+        if (!(CZ_TABL & 4)) dma_slab(g + 3);
 
 #pragma unroll 1
-        for (int s = 0; s < 18; ++s, ++g) {
-            const int half = s & 1;
-            const unsigned char *wb = wbuf + (g % TW_NBUF) * TW_SLAB_BYTES;
-            TW_STAMP(8 + g * 4 + 0)
-            load_frag(f2, abase, asw, half, 2, wb);
-            mma(f0);
-            load_frag(f3, abase, asw, half, 3, wb);
-            mma(f1);
-            TW_STAMP(8 + g * 4 + 1)
-            // middle of the slab.  Slab g+1 (DMA issued two barriers ago) must have landed for this wave:
-            // at most the 4 DMA instructions of slab g+2 may still be in flight.  The barrier publishes
-            // slab g+1 and proves every wave has left slab g-1, whose buffer the DMA of slab g+3 refills.
-            // No lgkmcnt drain: the fragment reads in flight belong to the current slab.
-            // Everything below is branch-free on purpose (see the note on MFMAs under branches; a branch
-            // here also lets the compiler sink the next slab's fragment reads to the top of the loop).
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            TW_STAMP(8 + g * 4 + 2)
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            TW_STAMP(8 + g * 4 + 3)
-            {
-                const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;   // past the end: re-fetch the last slab (unused)
-                const uint4 *src = wg + (size_t)gn * TW_SLAB_U4;
-                unsigned char *dst = wbuf + ((g + 3) % TW_NBUF) * TW_SLAB_BYTES + (wave << 10);
-                if (!(CZ_TABL & 4)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + q * TW_THREADS),
-                                                         (__attribute__((address_space(3))) void *)(dst + q * 4096), 16, 0, 0);
-                }
+        for (int tap = 0; tap < 9; ++tap) {
+            {   // ---- slab (tap, channels 0..63): the next slab reads the same cells ----
+                const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);
+                TW_KSTEP(5, 4, 8192, 8704, f0, f2, ab, key, vb, "");
+                TW_KSTEP(5, 6, 12288, 12800, f1, f3, ab, key, vb, "");
+                TW_MID()
+                TW_KSTEP(5, 8, 0, 512, f2, f0, ab, key, vbn, "");
+                TW_KSTEP(5, 10, 4096, 4608, f3, f1, ab, key, vbn, "s_waitcnt lgkmcnt(0)\n\t");
+                ++g;
             }
-            // fragments of the next slab's first two k-steps (its buffer was just published); after the last
-            // slab of a layer they fetch in-bounds garbage that the next layer's prologue overwrites.
-            {
-                const unsigned char *nb = wbuf + ((g + 1) % TW_NBUF) * TW_SLAB_BYTES;
-                tap_addr((s + 1) >> 1, src_off, abase, asw);
-                load_frag(f0, abase, asw, half ^ 1, 0, nb);
-                mma(f2);
-                load_frag(f1, abase, asw, half ^ 1, 1, nb);
-                mma(f3);
+            {   // ---- slab (tap, channels 64..127): the next slab belongs to the next tap ----
+                const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);
+                TW_KSTEP(5, 12, 8192, 8704, f0, f2, ab, key, vb, "");
+                TW_KSTEP(5, 14, 12288, 12800, f1, f3, ab, key, vb, "");
+                TW_MID()
+                tap_addr(tap + 1, src_off, nab, nkey);   // tap 9 after the last tap: in-bounds garbage, unused
+                TW_KSTEP(5, 0, 0, 512, f2, f0, nab, nkey, vbn, "");
+                TW_KSTEP(5, 2, 4096, 4608, f3, f1, nab, nkey, vbn, "s_waitcnt lgkmcnt(0)\n\t");
+#pragma unroll
+                for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+                ++g;
             }
         }
+        // the MFMAs were issued from inline asm: give the last ones time to retire before the accumulators are read
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
         // layer epilogue, entirely in LDS.  Odd layers (second conv of a block) add the block input x,
         // which still sits in U at exactly the cells this lane is about to overwrite.
-        TW_STAMP(4096 + layer * 2)
 #pragma unroll
-        for (int i = 0; i < ((CZ_TABL & 8) ? 0 : CV_RT); ++i) {
+        for (int i = 0; i < CV_RT; ++i) {
             const int r = 32 * (wr * CV_RT + i) + l31;
             const bool live = r < TW_ROWS;
             const int rc = live ? r : 0;   // padding rows: compute on row 0's address, never store
@@ -465,7 +490,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
-                    cell[j][q] = reinterpret_cast<uint2 *>(smem + dst_off + rc * CV_ROWB + (((n0 >> 3) ^ (rc & 15)) << 4) + ((n0 & 4) << 1));
+                    cell[j][q] = reinterpret_cast<uint2 *>(smem + lds_addr(dst_off + rc * CV_ROWB, n0 >> 3) + ((n0 & 4) << 1));
                     xr[j][q] = (layer & 1) ? *cell[j][q] : make_uint2(0, 0);
                 }
 #pragma unroll
@@ -483,17 +508,14 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
                     if (live) *cell[j][q] = pk;
                 }
         }
-        if (CZ_TABL & 8) { float t = 0.f; for (int i = 0; i < CV_RT; ++i) for (int j = 0; j < CV_CT; ++j) for (int e = 0; e < 16; ++e) t += acc[i][j][e]; if (t == 1234.5f) out[tid] = 1; }
         __syncthreads();
-        TW_STAMP(4096 + layer * 2 + 1)
     }
-    if (CZ_TTRACE) return;
     {   // the tower output sits in U (nlayers is even): full-row coalesced stores
         uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
         const int fin = (nlayers & 1) ? TW_BUF_BYTES : 0;
         for (int idx = tid; idx < nrows * 16; idx += TW_THREADS) {
             const int r = idx >> 4, c = idx & 15;
-            go[idx] = *reinterpret_cast<const uint4 *>(smem + fin + r * CV_ROWB + ((c ^ (r & 15)) << 4));
+            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(fin + r * CV_ROWB, c));
         }
     }
 }
