@@ -19,9 +19,9 @@ extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, 
     return CZ_OK;
 }
 
-extern "C" int cz_tower_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, int B, int nblocks) {
+static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
+                        const float *head_b, float *head_out, int B, int nblocks) {
     using namespace czconv;
-    CZ_REQUIRE(c && in && wpk && bias && out && B >= 0 && nblocks >= 0, "cz_tower_c128_bf16: null argument");
     if (B == 0) return CZ_OK;
     static bool attr_set = false;
     if (!attr_set) {
@@ -30,7 +30,19 @@ extern "C" int cz_tower_c128_bf16(cz_ctx *c, const void *in, const void *wpk, co
     }
     const int grid = (B + TW_P - 1) / TW_P;
     hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
-                       (const uint16_t *)wpk, bias, (uint16_t *)out, B, 2 * nblocks);
+                       (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, B, 2 * nblocks);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
+}
+
+extern "C" int cz_tower_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, int B, int nblocks) {
+    CZ_REQUIRE(c && in && wpk && bias && out && B >= 0 && nblocks >= 1, "cz_tower_c128_bf16: null argument / nblocks < 1");
+    return launch_tower(c, in, wpk, bias, out, nullptr, nullptr, nullptr, B, nblocks);
+}
+
+extern "C" int cz_tower_heads_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *trunk_out,
+                                        const float *head_w, const float *head_b, float *head_out, int B, int nblocks) {
+    CZ_REQUIRE(c && in && wpk && bias && head_w && head_b && head_out && B >= 0 && nblocks >= 1,
+               "cz_tower_heads_c128_bf16: null argument / nblocks < 1");
+    return launch_tower(c, in, wpk, bias, trunk_out, head_w, head_b, head_out, B, nblocks);
 }

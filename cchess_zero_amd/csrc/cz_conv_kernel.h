@@ -342,7 +342,11 @@ struct TwFrag { bf16x8 a[CV_RT]; bf16x8 b[CV_CT]; };
 __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__restrict__ in,
                                                               const uint16_t *__restrict__ wpk,   // [L][9][16][128][8]
                                                               const float *__restrict__ bias,     // [L][128]
-                                                              uint16_t *__restrict__ out, int B, int nlayers) {
+                                                              uint16_t *__restrict__ out,         // trunk [B][90][128] or NULL
+                                                              const float *__restrict__ head_w,   // [3][128] or NULL
+                                                              const float *__restrict__ head_b,   // [3]
+                                                              float *__restrict__ head_out,       // [B][90][3] or NULL
+                                                              int B, int nlayers) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wbuf = smem + TW_W_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -510,12 +514,40 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
         }
         __syncthreads();
     }
-    {   // the tower output sits in U (nlayers is even): full-row coalesced stores
+    const int fin = (nlayers & 1) ? TW_BUF_BYTES : 0;   // the tower output sits in U (nlayers is even)
+    if (out) {   // full-row coalesced stores of the trunk
         uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
-        const int fin = (nlayers & 1) ? TW_BUF_BYTES : 0;
         for (int idx = tid; idx < nrows * 16; idx += TW_THREADS) {
             const int r = idx >> 4, c = idx & 15;
             go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(fin + r * CV_ROWB, c));
+        }
+    }
+    if (head_out) {
+        // Fused head 1x1 convolutions (policy_value_network.py:57-59,68-70: conv1x1(128->2) and conv1x1(128->1),
+        // BN folded, ReLU) straight from the LDS-resident trunk: 3 dot products of length 128 per board cell,
+        // so only 12 B per cell leave the CU instead of the 256 B trunk row.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs of the weight ring
+        __syncthreads();
+        float *hw = reinterpret_cast<float *>(wbuf);
+        for (int i = tid; i < 3 * 128; i += TW_THREADS) hw[i] = head_w[i];
+        __syncthreads();
+        for (int idx = tid; idx < nrows * 3; idx += TW_THREADS) {
+            const int r = idx / 3, c3 = idx - r * 3;
+            const int rowoff = fin + r * CV_ROWB, key = (rowoff >> 8) & 15;
+            const float *w = hw + c3 * 128;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int p = (it + tid) & 15;      // physical 16-byte slot, rotated per lane against bank conflicts
+                const int c = p ^ key;              // logical chunk = channels 8c .. 8c+7
+                const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
+                const float *wc8 = w + c * 8;
+                acc += __uint_as_float(v.x << 16) * wc8[0] + __uint_as_float(v.x & 0xFFFF0000u) * wc8[1]
+                     + __uint_as_float(v.y << 16) * wc8[2] + __uint_as_float(v.y & 0xFFFF0000u) * wc8[3]
+                     + __uint_as_float(v.z << 16) * wc8[4] + __uint_as_float(v.z & 0xFFFF0000u) * wc8[5]
+                     + __uint_as_float(v.w << 16) * wc8[6] + __uint_as_float(v.w & 0xFFFF0000u) * wc8[7];
+            }
+            head_out[((size_t)pos0 * 90 + r) * 3 + c3] = fmaxf(acc + head_b[c3], 0.f);
         }
     }
 }

@@ -171,8 +171,9 @@ class PolicyValueNet:
         # heads: 1x1 convs as fp32 matmuls over [B*90,128]
         wp, bp = m.policy_conv.folded()
         wv, bv = m.value_conv.folded()
-        self.head_w = torch.cat([wp.view(2, FILTERS), wv.view(1, FILTERS)], 0).t().contiguous()  # [128,3]
-        self.head_b = torch.cat([bp, bv], 0)
+        self.head_w_rows = torch.cat([wp.view(2, FILTERS), wv.view(1, FILTERS)], 0).contiguous()  # [3,128]
+        self.head_w = self.head_w_rows.t().contiguous()  # [128,3]
+        self.head_b = torch.cat([bp, bv], 0).contiguous()
         self.pfc_w = m.policy_fc.weight.float().t().contiguous()
         self.pfc_b = m.policy_fc.bias.float()
         self.v1_w = m.value_fc1.weight.float().t().contiguous()
@@ -202,6 +203,30 @@ class PolicyValueNet:
             ev[1].record()
             self.conv_events.append(ev)
         return out
+
+    def _hip_tower_heads_forward(self, h):
+        """h: [B,128,9,10] channels_last bf16 -> z [B,90,3] f32: residual tower + both head 1x1 convs (+BN+ReLU) in
+        one launch; the trunk never leaves the CU."""
+        import ctypes as C
+        from ._lib import check, lib
+        B = h.shape[0]
+        if not h.is_contiguous(memory_format=torch.channels_last):
+            h = h.contiguous(memory_format=torch.channels_last)
+        x = h.permute(0, 2, 3, 1).reshape(B, 90, FILTERS)
+        z = torch.empty((B, 90, 3), dtype=torch.float32, device=self.device)
+        self._hip_ctx().bind_stream()
+        ev = None
+        if self.conv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        check(lib().cz_tower_heads_c128_bf16(self._hip_ctx().h, C.c_void_p(x.data_ptr()), C.c_void_p(self.hip_tower_w.data_ptr()),
+                                             C.c_void_p(self.hip_tower_b.data_ptr()), None, C.c_void_p(self.head_w_rows.data_ptr()),
+                                             C.c_void_p(self.head_b.data_ptr()), C.c_void_p(z.data_ptr()), B, self.res_block_nums),
+              "cz_tower_heads_c128_bf16")
+        if ev is not None:
+            ev[1].record()
+            self.conv_events.append(ev)
+        return z
 
     def _hip_tower_forward(self, h):
         """h: [B,128,9,10] channels_last bf16 -> all residual blocks in one launch (activations stay in LDS)."""
@@ -244,13 +269,18 @@ class PolicyValueNet:
         return cur.reshape(B, 9, 10, FILTERS).permute(0, 3, 1, 2)
 
     @torch.no_grad()
-    def tower(self, planes):
-        """planes [B,9,10,C>=14] (NHWC, any float dtype) -> trunk activations [B,128,9,10] channels_last."""
+    def first_conv(self, planes):
+        """planes [B,9,10,C>=14] (NHWC, any float dtype) -> conv3x3(14->128)+BN+ReLU, [B,128,9,10] channels_last."""
         x = planes[..., :14] if planes.shape[-1] != 14 else planes
         x = x.to(self.dtype).permute(0, 3, 1, 2)  # NHWC memory == NCHW channels_last view
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        h = F.relu_(F.conv2d(x, self.w_in[0], self.w_in[1], padding=1))
+        return F.relu_(F.conv2d(x, self.w_in[0], self.w_in[1], padding=1))
+
+    @torch.no_grad()
+    def tower(self, planes):
+        """planes [B,9,10,C>=14] (NHWC, any float dtype) -> trunk activations [B,128,9,10] channels_last."""
+        h = self.first_conv(planes)
         if self.backend == "hip":
             return self._hip_tower_forward(h)
         if self.backend == "hip-layer":
@@ -273,8 +303,21 @@ class PolicyValueNet:
         return logits, v
 
     @torch.no_grad()
+    def fc_heads(self, z):
+        """z [B,90,3] f32 (post-ReLU head conv outputs) -> (logits, value): the three FC layers."""
+        B = z.shape[0]
+        p = z[:, :, :2].reshape(B, 180)                                # (h,w,c) flatten, policy_value_network.py:62
+        logits = torch.addmm(self.pfc_b, p, self.pfc_w)
+        v = z[:, :, 2]
+        v = torch.relu_(torch.addmm(self.v1_b, v, self.v1_w))
+        v = torch.tanh(torch.addmm(self.v2_b, v, self.v2_w))
+        return logits, v
+
+    @torch.no_grad()
     def forward_device(self, planes):
         """Device planes [B,9,10,C] -> (logits [B,2086] f32, value [B,1] f32), all on the device."""
+        if self.backend == "hip" and self.res_block_nums >= 1:
+            return self.fc_heads(self._hip_tower_heads_forward(self.first_conv(planes)))
         return self.heads(self.tower(planes))
 
     @torch.no_grad()

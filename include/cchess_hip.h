@@ -152,6 +152,13 @@ int cz_conv3x3_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float 
  *   bias : [2*nblocks][128] float32 */
 int cz_tower_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float *bias, void *out, int B,
                        int nblocks);
+/* Same launch with the two head 1x1 convolutions fused in (conv1x1 128->2 policy, 128->1 value, BN folded,
+ * ReLU; policy_value_network.py:57-59,68-70), computed from the LDS-resident trunk:
+ *   head_w [3][128] f32 (rows: policy ch0, policy ch1, value), head_b [3] f32,
+ *   head_out [B][90][3] f32 (post-ReLU; [:, :, 0:2] flattens to the 180 policy-FC inputs in the reference's
+ *   (h, w, c) order, [:, :, 2] to the 90 value-FC inputs).  trunk_out may be NULL (trunk never leaves the CU). */
+int cz_tower_heads_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float *bias, void *trunk_out,
+                             const float *head_w, const float *head_b, float *head_out, int B, int nblocks);
 
 #ifdef __cplusplus
 }
