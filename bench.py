@@ -148,7 +148,9 @@ def main():
     cap = (playout + 2) * 80
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
-    eng = SearchEngine(G, cap, local_rank, plane_dtype=torch.float32, channels=14, ctx=ctx)
+    # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
+    fused = (args.backend in ("auto", "hip")) and args.dtype == "bf16"
+    eng = SearchEngine(G, cap, local_rank, plane_dtype=torch.bfloat16 if fused else torch.float32, channels=16 if fused else 14, ctx=ctx)
     net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
     eng.reset(boards, side, rr)
@@ -224,7 +226,7 @@ def main():
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
         nl = 2 * args.blocks if net.backend == "hip" else 1   # fused tower: one launch = all 2*blocks conv layers
         conv_flops = 2.0 * G * 90 * 1152 * 128 * nl
-        kname = ("k_tower_c128 (whole residual tower, %d fused conv3x3+BN(+residual)+ReLU layers, LDS-resident activations, bf16 MFMA, fp32 acc)" % nl
+        kname = ("k_tower_c128 (first conv + whole residual tower + head 1x1 convs in one launch: %d conv3x3+BN(+residual)+ReLU layers counted, LDS-resident activations, bf16 MFMA, fp32 acc)" % nl
                  if net.backend == "hip" else "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)")
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",

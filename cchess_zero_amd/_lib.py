@@ -45,6 +45,7 @@ _SIGS = {
     "cz_search_tree_dump": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cz_conv3x3_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_tower_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
+    "cz_net_trunk_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_tower_heads_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
 }
 

@@ -20,7 +20,8 @@ extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, 
 }
 
 static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
-                        const float *head_b, float *head_out, int B, int nblocks) {
+                        const float *head_b, float *head_out, int B, int nblocks, const void *planes = nullptr,
+                        const void *w0 = nullptr, const float *b0 = nullptr) {
     using namespace czconv;
     if (B == 0) return CZ_OK;
     static bool attr_set = false;
@@ -30,7 +31,8 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
     }
     const int grid = (B + TW_P - 1) / TW_P;
     hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
-                       (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, B, 2 * nblocks);
+                       (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
+                       (const uint16_t *)w0, b0, B, 2 * nblocks);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
@@ -45,4 +47,13 @@ extern "C" int cz_tower_heads_c128_bf16(cz_ctx *c, const void *in, const void *w
     CZ_REQUIRE(c && in && wpk && bias && head_w && head_b && head_out && B >= 0 && nblocks >= 1,
                "cz_tower_heads_c128_bf16: null argument / nblocks < 1");
     return launch_tower(c, in, wpk, bias, trunk_out, head_w, head_b, head_out, B, nblocks);
+}
+
+extern "C" int cz_net_trunk_bf16(cz_ctx *c, const void *planes16, const void *w0, const float *b0, const void *wpk,
+                                 const float *bias, void *trunk_out, const float *head_w, const float *head_b,
+                                 float *head_out, int B, int nblocks) {
+    CZ_REQUIRE(c && planes16 && w0 && b0 && wpk && bias && B >= 0 && nblocks >= 1 && (trunk_out || head_out),
+               "cz_net_trunk_bf16: null argument / nblocks < 1");
+    CZ_REQUIRE(!head_out || (head_w && head_b), "cz_net_trunk_bf16: head_out needs head_w and head_b");
+    return launch_tower(c, nullptr, wpk, bias, trunk_out, head_w, head_b, head_out, B, nblocks, planes16, w0, b0);
 }

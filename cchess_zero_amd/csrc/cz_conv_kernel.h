@@ -346,6 +346,9 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
                                                               const float *__restrict__ head_w,   // [3][128] or NULL
                                                               const float *__restrict__ head_b,   // [3]
                                                               float *__restrict__ head_out,       // [B][90][3] or NULL
+                                                              const uint16_t *__restrict__ planes,  // [B][90][16] bf16 or NULL
+                                                              const uint16_t *__restrict__ w0,      // [9][2][128][8] bf16
+                                                              const float *__restrict__ b0,         // [128]
                                                               int B, int nlayers) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wbuf = smem + TW_W_OFF;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
                                              (__attribute__((address_space(3))) void *)(dst + q * 4096), 16, 0, 0);
     };
     for (int q = 0; q < 3; ++q) dma_slab(q);
-    {   // stage x into U (swizzled rows), clear the zero row
+    if (planes == nullptr) {   // stage x into U (swizzled rows)
         const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
         for (int idx = tid; idx < TW_ROWS * 16; idx += TW_THREADS) {
             const int r = idx >> 4, c = idx & 15;
@@ -383,8 +386,15 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
             if (r < nrows) v = g[idx];
             *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
         }
-        if (tid < 16) *reinterpret_cast<uint4 *>(smem + TW_ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    } else {                   // stage the 16-channel input planes (32 B per cell) into the V region
+        const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
+        for (int idx = tid; idx < TW_ROWS * 2; idx += TW_THREADS) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < nrows * 2) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + TW_BUF_BYTES + (idx << 4)) = v;
+        }
     }
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + TW_ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -415,6 +425,82 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
         }
     };
     const int vb0 = TW_W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);   // this lane's B column in slab buffer 0
+
+    // Layer epilogue, entirely in LDS: + bias [+ x] -> ReLU -> bf16.  For the second conv of a block the block
+    // input x still sits in U at exactly the cells this lane is about to overwrite.
+    auto layer_epilogue = [&](f32x16 (&acc)[CV_RT][CV_CT], const float4 (&breg)[CV_CT][4], int dst_off, bool residual) {
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int r = 32 * (wr * CV_RT + i) + l31;
+            const bool live = r < TW_ROWS;
+            const int rc = live ? r : 0;   // padding rows: compute on row 0's address, never store
+            uint2 xr[CV_CT][4];
+            uint2 *cell[CV_CT][4];
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
+                    cell[j][q] = reinterpret_cast<uint2 *>(smem + lds_addr(dst_off + rc * CV_ROWB, n0 >> 3) + ((n0 & 4) << 1));
+                    xr[j][q] = residual ? *cell[j][q] : make_uint2(0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bq = breg[j][q];
+                    float v0 = acc[i][j][4 * q + 0] + bq.x + __uint_as_float(xr[j][q].x << 16);
+                    float v1 = acc[i][j][4 * q + 1] + bq.y + __uint_as_float(xr[j][q].x & 0xFFFF0000u);
+                    float v2 = acc[i][j][4 * q + 2] + bq.z + __uint_as_float(xr[j][q].y << 16);
+                    float v3 = acc[i][j][4 * q + 3] + bq.w + __uint_as_float(xr[j][q].y & 0xFFFF0000u);
+                    uint2 pk;
+                    pk.x = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+                    pk.y = pack_bf16x2(fmaxf(v2, 0.f), fmaxf(v3, 0.f));
+                    if (live) *cell[j][q] = pk;
+                }
+        }
+    };
+
+    if (planes != nullptr) {
+        // ---- first layer: conv3x3(14 -> 128, input padded to 16 channels) + BN + ReLU (policy_value_network.py:45-47)
+        // one k-step (16 channels) per tap; planes are in the V region (32 B per cell), the result goes to U.
+        bf16x8 wf[9][CV_CT];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + khalf) * 128 + wc * 64 + j * 32 + l31) << 3));
+        float4 breg[CV_CT][4];
+#pragma unroll
+        for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                breg[j][q] = *reinterpret_cast<const float4 *>(b0 + wc * 64 + j * 32 + 8 * q + 4 * khalf);
+        f32x16 acc[CV_RT][CV_CT];
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
+            bf16x8 af[CV_RT];
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) {
+                const int a = ((tapmask[i] >> t) & 1) ? TW_BUF_BYTES + ((rowb[i] >> 3) + shift * 32) : TW_ZERO_OFF;
+                af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CV_CT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][j], af[i], acc[i][j], 0, 0, 0);
+        }
+        layer_epilogue(acc, breg, 0, false);
+        __syncthreads();
+    }
 
     int g = 0;  // running slab index over all layers
 #pragma unroll 1
@@ -480,38 +566,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
         }
         // the MFMAs were issued from inline asm: give the last ones time to retire before the accumulators are read
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        // layer epilogue, entirely in LDS.  Odd layers (second conv of a block) add the block input x,
-        // which still sits in U at exactly the cells this lane is about to overwrite.
-#pragma unroll
-        for (int i = 0; i < CV_RT; ++i) {
-            const int r = 32 * (wr * CV_RT + i) + l31;
-            const bool live = r < TW_ROWS;
-            const int rc = live ? r : 0;   // padding rows: compute on row 0's address, never store
-            uint2 xr[CV_CT][4];
-            uint2 *cell[CV_CT][4];
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
-                    cell[j][q] = reinterpret_cast<uint2 *>(smem + lds_addr(dst_off + rc * CV_ROWB, n0 >> 3) + ((n0 & 4) << 1));
-                    xr[j][q] = (layer & 1) ? *cell[j][q] : make_uint2(0, 0);
-                }
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bq = breg[j][q];
-                    float v0 = acc[i][j][4 * q + 0] + bq.x + __uint_as_float(xr[j][q].x << 16);
-                    float v1 = acc[i][j][4 * q + 1] + bq.y + __uint_as_float(xr[j][q].x & 0xFFFF0000u);
-                    float v2 = acc[i][j][4 * q + 2] + bq.z + __uint_as_float(xr[j][q].y << 16);
-                    float v3 = acc[i][j][4 * q + 3] + bq.w + __uint_as_float(xr[j][q].y & 0xFFFF0000u);
-                    uint2 pk;
-                    pk.x = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
-                    pk.y = pack_bf16x2(fmaxf(v2, 0.f), fmaxf(v3, 0.f));
-                    if (live) *cell[j][q] = pk;
-                }
-        }
+        layer_epilogue(acc, breg, dst_off, (layer & 1) != 0);
         __syncthreads();
     }
     const int fin = (nlayers & 1) ? TW_BUF_BYTES : 0;   // the tower output sits in U (nlayers is even)

@@ -165,6 +165,12 @@ class PolicyValueNet:
                 wp = w.permute(2, 3, 1, 0).reshape(9, 16, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
                 return wp, b.float().contiguous()
             self.hip_blocks = [(hip_pack(a), hip_pack(b)) for a, b in m.blocks]
+            # first layer 14 -> 128: input channels padded to 16, [tap][ci/8][co][ci%8] bf16
+            w0, b0 = m.conv_in.folded()
+            w0p = torch.zeros((3, 3, 16, FILTERS), dtype=torch.float32, device=w0.device)
+            w0p[:, :, :14, :] = w0.permute(2, 3, 1, 0)
+            self.hip_w0 = w0p.reshape(9, 2, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+            self.hip_b0 = b0.float().contiguous()
             layers = [x for blk in self.hip_blocks for x in blk]
             self.hip_tower_w = torch.stack([w for w, _ in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.bfloat16, device=self.device)
             self.hip_tower_b = torch.stack([b for _, b in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.float32, device=self.device)
@@ -203,6 +209,33 @@ class PolicyValueNet:
             ev[1].record()
             self.conv_events.append(ev)
         return out
+
+    def _hip_net_forward(self, planes):
+        """planes [B,9,10,C] (C = 16 bf16: zero-copy; anything else is repacked) -> z [B,90,3] f32.
+        First conv + residual tower + head 1x1 convs in ONE launch (cz_net_trunk_bf16)."""
+        import ctypes as C
+        from ._lib import check, lib
+        B = planes.shape[0]
+        if planes.dtype == torch.bfloat16 and planes.shape[-1] == 16 and planes.is_contiguous():
+            p16 = planes
+        else:
+            p16 = torch.zeros((B, 9, 10, 16), dtype=torch.bfloat16, device=self.device)
+            p16[..., :14] = planes[..., :14].to(torch.bfloat16)
+        z = torch.empty((B, 90, 3), dtype=torch.float32, device=self.device)
+        self._hip_ctx().bind_stream()
+        ev = None
+        if self.conv_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        check(lib().cz_net_trunk_bf16(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_w0.data_ptr()),
+                                      C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_tower_w.data_ptr()),
+                                      C.c_void_p(self.hip_tower_b.data_ptr()), None, C.c_void_p(self.head_w_rows.data_ptr()),
+                                      C.c_void_p(self.head_b.data_ptr()), C.c_void_p(z.data_ptr()), B, self.res_block_nums),
+              "cz_net_trunk_bf16")
+        if ev is not None:
+            ev[1].record()
+            self.conv_events.append(ev)
+        return z
 
     def _hip_tower_heads_forward(self, h):
         """h: [B,128,9,10] channels_last bf16 -> z [B,90,3] f32: residual tower + both head 1x1 convs (+BN+ReLU) in
@@ -317,7 +350,7 @@ class PolicyValueNet:
     def forward_device(self, planes):
         """Device planes [B,9,10,C] -> (logits [B,2086] f32, value [B,1] f32), all on the device."""
         if self.backend == "hip" and self.res_block_nums >= 1:
-            return self.fc_heads(self._hip_tower_heads_forward(self.first_conv(planes)))
+            return self.fc_heads(self._hip_net_forward(planes))
         return self.heads(self.tower(planes))
 
     @torch.no_grad()

@@ -160,6 +160,16 @@ int cz_tower_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float *b
 int cz_tower_heads_c128_bf16(cz_ctx *, const void *in, const void *wpk, const float *bias, void *trunk_out,
                              const float *head_w, const float *head_b, float *head_out, int B, int nblocks);
 
+/* Input planes to head-conv outputs in ONE launch: conv3x3(14->128)+BN+ReLU (policy_value_network.py:45-47),
+ * the residual tower and (optionally) the head 1x1 convolutions.
+ *   planes16 : [B][90][16] bf16 — the K3 encoding with channels = 16 (14 planes + 2 zero channels), e.g. written by
+ *              cz_search_select(..., CZ_BF16, 16, ...)
+ *   w0 : [9 taps][2 = ci/8][128 co][8 = ci%8] bf16 (input channels 14,15 zero), b0 : [128] f32, BN folded
+ *   other arguments as cz_tower_heads_c128_bf16; trunk_out and head_out may each be NULL (not both). */
+int cz_net_trunk_bf16(cz_ctx *, const void *planes16, const void *w0, const float *b0, const void *wpk,
+                      const float *bias, void *trunk_out, const float *head_w, const float *head_b,
+                      float *head_out, int B, int nblocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,3 +162,26 @@ def test_fused_tower_with_structured_weights():
     assert np.abs(softmax(logits) - softmax(ln)).max() < 1e-3
     assert np.abs(logits - ln).max() < 0.05 * np.abs(ln).max() + 1e-2
     assert np.abs(v - vn).max() < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 37])
+def test_fused_net_kernel_paths_agree(n):
+    """cz_net_trunk_bf16 (planes -> head conv outputs, one launch) vs the unfused route
+    (torch first conv -> cz_tower_c128_bf16 -> torch head convs) and zero-copy bf16x16 planes vs repacked f32x14."""
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(3, "cuda:0", torch.bfloat16, seed=6, backend="hip")
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():   # non-trivial first-layer bias/BN so the fused first conv's epilogue is exercised
+        net.module.conv_in.conv.bias.copy_((torch.randn(128, generator=gen) * 0.1).cuda())
+        net.module.conv_in.moving_var.copy_((torch.rand(128, generator=gen) + 0.5).cuda())
+    net.refresh()
+    x = torch.from_numpy(_positions(n, 7)).cuda()
+    l1, v1 = net.forward_device(x)                       # fused, repacked planes
+    x16 = torch.zeros((n, 9, 10, 16), dtype=torch.bfloat16, device="cuda")
+    x16[..., :14] = x.to(torch.bfloat16)
+    l2, v2 = net.forward_device(x16)                     # fused, zero-copy planes
+    assert torch.equal(l1, l2) and torch.equal(v1, v2)
+    l3, v3 = net.heads(net.tower(x))                     # unfused route
+    assert float((l1 - l3).abs().max()) < 2e-2 * float(l3.abs().max()) + 1e-3
+    assert float((torch.softmax(l1, 1) - torch.softmax(l3, 1)).abs().max()) < 1e-3 and float((v1 - v3).abs().max()) < 1e-2
