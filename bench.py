@@ -71,7 +71,7 @@ def cpu_baseline(blocks, seconds_target=15.0):
     except Exception:  # pragma: no cover
         threadpool_limits = None
     cores = os.cpu_count() or 1
-    G = 16
+    G = 128   # enough rows per net call to keep the BLAS threads of a many-core host busy
     rng = np.random.default_rng(0)
     boards = np.tile(START, (G, 1))
     side = np.zeros(G, np.uint8)
@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
+    ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -131,8 +133,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.all_on_device0:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -209,9 +216,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # outside the timed region: the record exchange of the self-play loop (one all-gather of packed
+        # (s, pi, z) records over RCCL) on a token batch, so the N>1 run exercises the collective path too
+        from cchess_zero_amd import parallel, selfplay
+        tok = np.zeros((4 + rank, selfplay.REC_BYTES), np.uint8)
+        tok[:, 0] = rank + 1
+        allrec = parallel.gather_records(tok, device=dev if args.dist_backend == "nccl" else "cpu")
+        assert allrec.shape[0] == sum(4 + r for r in range(world)) and int(allrec[-1, 0]) == world
 
     st, nodes, sims, depth = eng.status()
     bad = int((st & ~8).ne(0).sum().item())
