@@ -284,40 +284,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {  // one v_
 
 struct TwFrag { bf16x8 a[CV_RT]; bf16x8 b[CV_CT]; };
 
-// One k-step (16 input channels) of the slab loop, hand-scheduled: waits until fragment set Y has
-// landed (LGKM = number of newer LDS reads allowed in flight), then issues the 6 MFMAs of Y with the
-// address math (2 VALU per row tile) and the five ds_read_b128 of set X — needed two k-steps later —
-// in their issue shadow.  CA = 16-byte chunk index of the A rows to fetch (without the lane's k-half,
-// which is folded into the swizzle key), OB0/OB1 = byte offsets of the two B columns in the slab.
-// Weights are the MFMA A operand: D[channel][cell].
-#define TW_KSTEP(LGKM, CA, OB0, OB1, Y, X, AB, KEY, VB, TAIL)                                        \
-    asm volatile(                                                                                    \
-        "s_waitcnt lgkmcnt(" #LGKM ")\n\t"                                                           \
-        "v_xor_b32 %[t0], " #CA ", %[k0]\n\t"                                                        \
-        "v_mfma_f32_32x32x16_bf16 %[c00], %[yb0], %[ya0], %[c00]\n\t"                                \
-        "v_xor_b32 %[t1], " #CA ", %[k1]\n\t"                                                        \
-        "v_xor_b32 %[t2], " #CA ", %[k2]\n\t"                                                        \
-        "v_lshl_add_u32 %[t0], %[t0], 4, %[b0]\n\t"                                                  \
-        "v_lshl_add_u32 %[t1], %[t1], 4, %[b1]\n\t"                                                  \
-        "v_lshl_add_u32 %[t2], %[t2], 4, %[b2]\n\t"                                                  \
-        "v_mfma_f32_32x32x16_bf16 %[c01], %[yb1], %[ya0], %[c01]\n\t"                                \
-        "ds_read_b128 %[xa0], %[t0]\n\t"                                                             \
-        "ds_read_b128 %[xa1], %[t1]\n\t"                                                             \
-        "v_mfma_f32_32x32x16_bf16 %[c10], %[yb0], %[ya1], %[c10]\n\t"                                \
-        "ds_read_b128 %[xa2], %[t2]\n\t"                                                             \
-        "ds_read_b128 %[xb0], %[vb] offset:" #OB0 "\n\t"                                             \
-        "v_mfma_f32_32x32x16_bf16 %[c11], %[yb1], %[ya1], %[c11]\n\t"                                \
-        "ds_read_b128 %[xb1], %[vb] offset:" #OB1 "\n\t"                                             \
-        "v_mfma_f32_32x32x16_bf16 %[c20], %[yb0], %[ya2], %[c20]\n\t"                                \
-        "v_mfma_f32_32x32x16_bf16 %[c21], %[yb1], %[ya2], %[c21]\n\t" TAIL                            \
-        : [c00] "+a"(acc[0][0]), [c01] "+a"(acc[0][1]), [c10] "+a"(acc[1][0]), [c11] "+a"(acc[1][1]),  \
-          [c20] "+a"(acc[2][0]), [c21] "+a"(acc[2][1]), [xa0] "=&v"(X.a[0]), [xa1] "=&v"(X.a[1]),      \
-          [xa2] "=&v"(X.a[2]), [xb0] "=&v"(X.b[0]), [xb1] "=&v"(X.b[1]), [t0] "=&v"(t0), [t1] "=&v"(t1), \
-          [t2] "=&v"(t2)                                                                              \
-        : [ya0] "v"(Y.a[0]), [ya1] "v"(Y.a[1]), [ya2] "v"(Y.a[2]), [yb0] "v"(Y.b[0]), [yb1] "v"(Y.b[1]), \
-          [k0] "v"(KEY[0]), [k1] "v"(KEY[1]), [k2] "v"(KEY[2]), [b0] "v"(AB[0]), [b1] "v"(AB[1]),      \
-          [b2] "v"(AB[2]), [vb] "v"(VB)                                                               \
-        : "memory")
+#include "cz_tower_slab_asm.inc"
 
 // the five fragment reads of one k-step, no MFMAs (layer prologue)
 #define TW_LOADSET(CA, OB0, OB1, X, AB, KEY, VB)                                                     \
@@ -425,10 +392,14 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
         }
     };
     const int vb0 = TW_W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);   // this lane's B column in slab buffer 0
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + 4096u, voff2 = voff0 + 8192u, voff3 = voff0 + 12288u;
+    int keep;
 
     // Layer epilogue, entirely in LDS: + bias [+ x] -> ReLU -> bf16.  For the second conv of a block the block
     // input x still sits in U at exactly the cells this lane is about to overwrite.
-    auto layer_epilogue = [&](f32x16 (&acc)[CV_RT][CV_CT], const float4 (&breg)[CV_CT][4], int dst_off, bool residual) {
+    // The bias is already in the accumulators (they are initialised with it, not with zero).
+    auto layer_epilogue = [&](f32x16 (&acc)[CV_RT][CV_CT], int dst_off, bool residual) {
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
             const int r = 32 * (wr * CV_RT + i) + l31;
@@ -448,17 +419,31 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
             for (int j = 0; j < CV_CT; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 bq = breg[j][q];
-                    float v0 = acc[i][j][4 * q + 0] + bq.x + __uint_as_float(xr[j][q].x << 16);
-                    float v1 = acc[i][j][4 * q + 1] + bq.y + __uint_as_float(xr[j][q].x & 0xFFFF0000u);
-                    float v2 = acc[i][j][4 * q + 2] + bq.z + __uint_as_float(xr[j][q].y << 16);
-                    float v3 = acc[i][j][4 * q + 3] + bq.w + __uint_as_float(xr[j][q].y & 0xFFFF0000u);
+                    float v0 = acc[i][j][4 * q + 0] + __uint_as_float(xr[j][q].x << 16);
+                    float v1 = acc[i][j][4 * q + 1] + __uint_as_float(xr[j][q].x & 0xFFFF0000u);
+                    float v2 = acc[i][j][4 * q + 2] + __uint_as_float(xr[j][q].y << 16);
+                    float v3 = acc[i][j][4 * q + 3] + __uint_as_float(xr[j][q].y & 0xFFFF0000u);
                     uint2 pk;
                     pk.x = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
                     pk.y = pack_bf16x2(fmaxf(v2, 0.f), fmaxf(v3, 0.f));
                     if (live) *cell[j][q] = pk;
                 }
         }
+    };
+
+    // accumulators start at the layer's (BN-folded) bias: acc[i][j][4q+e] belongs to channel wc*64 + j*32 + 8q + 4*khalf + e
+    auto init_acc = [&](f32x16 (&acc)[CV_RT][CV_CT], const float *bl) {
+#pragma unroll
+        for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4 *>(bl + wc * 64 + j * 32 + 8 * q + 4 * khalf);
+#pragma unroll
+                for (int i = 0; i < CV_RT; ++i) {
+                    acc[i][j][4 * q + 0] = bq.x; acc[i][j][4 * q + 1] = bq.y;
+                    acc[i][j][4 * q + 2] = bq.z; acc[i][j][4 * q + 3] = bq.w;
+                }
+            }
     };
 
     if (planes != nullptr) {
@@ -470,19 +455,8 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
 #pragma unroll
             for (int j = 0; j < CV_CT; ++j)
                 wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + khalf) * 128 + wc * 64 + j * 32 + l31) << 3));
-        float4 breg[CV_CT][4];
-#pragma unroll
-        for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                breg[j][q] = *reinterpret_cast<const float4 *>(b0 + wc * 64 + j * 32 + 8 * q + 4 * khalf);
         f32x16 acc[CV_RT][CV_CT];
-#pragma unroll
-        for (int i = 0; i < CV_RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        init_acc(acc, b0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
@@ -498,7 +472,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
                 for (int j = 0; j < CV_CT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][j], af[i], acc[i][j], 0, 0, 0);
         }
-        layer_epilogue(acc, breg, 0, false);
+        layer_epilogue(acc, 0, false);
         __syncthreads();
     }
 
@@ -508,19 +482,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
         const int src_off = (layer & 1) ? TW_BUF_BYTES : 0;   // even layers read U write V, odd read V write U
         const int dst_off = (layer & 1) ? 0 : TW_BUF_BYTES;
         f32x16 acc[CV_RT][CV_CT];
-#pragma unroll
-        for (int i = 0; i < CV_RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        // this layer's bias for the 2 x 4 channel quads a lane owns: in flight during the whole main loop
-        float4 breg[CV_CT][4];
-#pragma unroll
-        for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                breg[j][q] = *reinterpret_cast<const float4 *>(bias + layer * 128 + wc * 64 + j * 32 + 8 * q + 4 * khalf);
+        init_acc(acc, bias + layer * 128);
         int ab[CV_RT], key[CV_RT], nab[CV_RT], nkey[CV_RT], t0, t1, t2;
         TwFrag f0, f1, f2, f3;
         tap_addr(0, src_off, ab, key);
@@ -531,34 +493,42 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
             TW_LOADSET(2, 4096, 4608, f1, ab, key, vb);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        // mid-slab: slab g+1 (DMA issued two barriers ago) must have landed for this wave — at most the 4 DMA
-        // instructions of slab g+2 may still be in flight; the barrier publishes it and proves every wave has
-        // left slab g-1, whose buffer the DMA of slab g+3 refills.  No lgkmcnt drain here.
-#define TW_MID()                                                  \
-        if (!(CZ_TABL & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
-        if (!(CZ_TABL & 32)) __builtin_amdgcn_s_barrier();                             \
-        asm volatile("" ::: "memory");                            \
-        if (!(CZ_TABL & 4)) dma_slab(g + 3);
+        // One asm statement per slab (generated by tools/gen_tower_asm.py): 24 MFMAs with the fragment reads two
+        // k-steps ahead, the mid-slab `s_waitcnt vmcnt(4); s_barrier` (slab g+1 — DMA issued two barriers ago —
+        // has landed and is published; every wave has left slab g-1) and the 4 LDS-DMA instructions that refill
+        // slab g-1's buffer with slab g+3, all hand-placed in MFMA issue shadows.  All LDS byte offsets are
+        // relative to LDS address 0 (the kernel has no static LDS, the dynamic region starts there).
+#define TW_SLAB(ASMSTR, NAB, NKEY)                                                                               \
+        asm volatile(ASMSTR                                                                                      \
+            : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),          \
+              [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),                                                        \
+              [f0a0] "+v"(f0.a[0]), [f0a1] "+v"(f0.a[1]), [f0a2] "+v"(f0.a[2]), [f0b0] "+v"(f0.b[0]), [f0b1] "+v"(f0.b[1]), \
+              [f1a0] "+v"(f1.a[0]), [f1a1] "+v"(f1.a[1]), [f1a2] "+v"(f1.a[2]), [f1b0] "+v"(f1.b[0]), [f1b1] "+v"(f1.b[1]), \
+              [f2a0] "=&v"(f2.a[0]), [f2a1] "=&v"(f2.a[1]), [f2a2] "=&v"(f2.a[2]), [f2b0] "=&v"(f2.b[0]), [f2b1] "=&v"(f2.b[1]), \
+              [f3a0] "=&v"(f3.a[0]), [f3a1] "=&v"(f3.a[1]), [f3a2] "=&v"(f3.a[2]), [f3b0] "=&v"(f3.b[0]), [f3b1] "=&v"(f3.b[1]), \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [keep] "=&s"(keep)                                     \
+            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),          \
+              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
+              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
+              [voff1] "v"(voff1), [voff2] "v"(voff2), [voff3] "v"(voff3), [sbase] "s"(sbase), [ldst] "s"(ldst)        \
+            : "memory")
+#define TW_SLAB_ARGS()                                                                                          \
+        const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);         \
+        const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1; /* past the end: re-fetch the last slab (never read) */ \
+        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * TW_SLAB_BYTES;  \
+        const int ldst = TW_W_OFF + ((((unsigned)g + 3u) & 3u) << 14) + (wave_u << 10);
 
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             {   // ---- slab (tap, channels 0..63): the next slab reads the same cells ----
-                const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);
-                TW_KSTEP(5, 4, 8192, 8704, f0, f2, ab, key, vb, "");
-                TW_KSTEP(5, 6, 12288, 12800, f1, f3, ab, key, vb, "");
-                TW_MID()
-                TW_KSTEP(5, 8, 0, 512, f2, f0, ab, key, vbn, "");
-                TW_KSTEP(5, 10, 4096, 4608, f3, f1, ab, key, vbn, "s_waitcnt lgkmcnt(0)\n\t");
+                TW_SLAB_ARGS()
+                TW_SLAB(TW_SLAB_ASM_H0, ab, key);
                 ++g;
             }
             {   // ---- slab (tap, channels 64..127): the next slab belongs to the next tap ----
-                const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);
-                TW_KSTEP(5, 12, 8192, 8704, f0, f2, ab, key, vb, "");
-                TW_KSTEP(5, 14, 12288, 12800, f1, f3, ab, key, vb, "");
-                TW_MID()
                 tap_addr(tap + 1, src_off, nab, nkey);   // tap 9 after the last tap: in-bounds garbage, unused
-                TW_KSTEP(5, 0, 0, 512, f2, f0, nab, nkey, vbn, "");
-                TW_KSTEP(5, 2, 4096, 4608, f3, f1, nab, nkey, vbn, "s_waitcnt lgkmcnt(0)\n\t");
+                TW_SLAB_ARGS()
+                TW_SLAB(TW_SLAB_ASM_H1, nab, nkey);
 #pragma unroll
                 for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
                 ++g;
@@ -566,9 +536,11 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
         }
         // the MFMAs were issued from inline asm: give the last ones time to retire before the accumulators are read
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        layer_epilogue(acc, breg, dst_off, (layer & 1) != 0);
+        layer_epilogue(acc, dst_off, (layer & 1) != 0);
         __syncthreads();
     }
+    // the ring's tail DMAs (re-fetches of the last slab into free buffers) must land before the LDS is given back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int fin = (nlayers & 1) ? TW_BUF_BYTES : 0;   // the tower output sits in U (nlayers is even)
     if (out) {   // full-row coalesced stores of the trunk
         uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
