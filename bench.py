@@ -227,6 +227,16 @@ def main():
         allrec = parallel.gather_records(tok, device=dev if args.dist_backend == "nccl" else "cpu")
         assert allrec.shape[0] == sum(4 + r for r in range(world)) and int(allrec[-1, 0]) == world
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed
+    # rocprofv3 --pmc measurement of the same launch shape is attached when the configuration matches.
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if tj["config"] == {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype} and args.backend in ("auto", "hip"):
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; algorithmic bytes %d)" % tj["algorithmic_bytes_per_launch"]
+    except Exception:
+        pass
     st, nodes, sims, depth = eng.status()
     bad = int((st & ~8).ne(0).sum().item())
     st_bits = {name: int(((st & bit) != 0).sum().item()) for name, bit in
@@ -244,7 +254,7 @@ def main():
                  if net.backend == "hip" else "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)")
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "us_per_launch": conv_ms * 1e3, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops,
                 "net_forward_ms_per_step": net_ms, "net_forward_tflops": flops / (net_ms * 1e-3) / 1e12}
     else:
