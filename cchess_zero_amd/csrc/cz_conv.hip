@@ -7,10 +7,9 @@ extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, 
     using namespace czconv;
     CZ_REQUIRE(c && in && wpk && bias && out && B >= 0, "cz_conv3x3_c128_bf16: null argument");
     if (B == 0) return CZ_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!c->conv_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_c128), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES));
-        attr_set = true;
+        c->conv_attr_set = true;
     }
     const int grid = (B + CV_P - 1) / CV_P;
     hipLaunchKernelGGL(k_conv3x3_c128, dim3(grid), dim3(CV_THREADS), CV_LDS_BYTES, c->stream, (const uint16_t *)in,
@@ -24,10 +23,9 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
                         const void *w0 = nullptr, const float *b0 = nullptr) {
     using namespace czconv;
     if (B == 0) return CZ_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!c->tower_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
-        attr_set = true;
+        c->tower_attr_set = true;
     }
     const int grid = (B + TW_P - 1) / TW_P;
     hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,

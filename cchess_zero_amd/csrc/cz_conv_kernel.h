@@ -1,24 +1,18 @@
-// cz_conv.hip — N1: the residual tower's 3x3 convolution as a fused MFMA implicit GEMM (gfx950).
+// cz_conv_kernel.h — N1: the policy/value net trunk as fused MFMA implicit-GEMM kernels (gfx950).
 //
-// Replaces, per layer, tf.layers.conv2d(128, 3, 'SAME') + batch_norm(no affine) [+ residual add]
-// + ReLU of the reference (policy_value_network.py:45-47, 151-162).  BN is folded into the packed
-// weights/bias on the host (net.py), so one launch = one conv layer end to end.
+// Replaces tf.layers.conv2d(128, 3, 'SAME') + batch_norm(no affine) [+ residual add] + ReLU of the reference
+// (policy_value_network.py:45-47, 151-162); BN is folded into the packed weights/bias on the host (net.py).
 //
-// GEMM view (per layer):  M = B*90 board cells, N = 128 output channels, K = 9 taps * 128 channels.
-//   - a workgroup owns P whole positions (P = 2: 180 rows -> 6 row tiles of 32, the last 12 rows are
-//     padding): their bf16 activations (45 KB) are loaded ONCE into LDS and stay there for all 9
-//     taps; the im2col shift of a tap is an LDS address offset, out-of-board taps read a zero row.
-//     Two workgroups (77 KB of LDS each) share a CU so one's load/store phases hide under the
-//     other's MFMA loop.
-//   - the weight matrix (288 KB/layer, L2 resident) is streamed through two 16 KB LDS slabs
-//     (64 input channels of one tap), prefetched to registers one slab ahead (issue-early /
-//     write-late) so L2 latency hides under the MFMAs.
-//   - 2P waves = P (row groups of 3 tiles) x 2 (column groups of 2 tiles); each wave keeps
-//     3x2 accumulators of v_mfma_f32_32x32x16_bf16 (96 regs), A/B fragments by ds_read_b128.
-//   - LDS rows are 256 B (128 bf16): the 16-byte chunk c of row r lives at chunk c ^ (r & 15), which
-//     makes the column-slice fragment reads bank-conflict free (guide T2).
-//   - epilogue: + bias, + residual, ReLU, bf16, staged through LDS and written as full 256-byte rows.
-// Roofline: MFMA-bound; algorithmic flops per launch = 2 * B*90 * 1152 * 128.
+//   k_conv3x3_c128   one conv layer per launch: 4 positions per workgroup, activations loaded once into LDS
+//                    for all 9 taps, weights streamed in 32 KB slabs, epilogue through LDS.  Moves 69 KB per
+//                    position per layer — the HBM/MFMA balance point — so it is kept as the simple variant
+//                    (unit tests, fallback); the product path is:
+//   k_tower_c128     first conv + ALL residual blocks + head 1x1 convs in ONE launch, activations resident in
+//                    LDS across layers, weights streamed L2 -> LDS by LDS-DMA, hand-scheduled slab loop
+//                    (see the block comment in front of it).
+// Common: GEMM view per layer M = B*90 board cells, N = 128, K = 9 taps * 128; v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation; LDS rows of 256 B with the 16-byte chunk c of a row stored at chunk c ^ (row & 15)
+// (conflict-free ds_read_b128 fragment reads); weights packed [tap][ci/8][co][ci%8] = the LDS operand image.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,26 +38,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CZ_ABL_NO_MFMA 4
 #define CZ_ABL_NO_LDSREAD 8
 #define CZ_ABL_NO_WSTREAM 16
-// CZ_TTRACE: tools/tower_ubench.hip only — s_memtime stamps of one workgroup into `out` (clobbers it)
-#ifndef CZ_TTRACE
-#define CZ_TTRACE 0
-#endif
-#ifndef CZ_TOWER_SGB
-#define CZ_TOWER_SGB 1
-#endif
-// tower ablations: 1 = no MFMA, 2 = no fragment reads, 4 = no weight stream, 8 = no layer epilogue
-#ifndef CZ_TABL
-#define CZ_TABL 0
-#endif
-constexpr int CV_P = CZ_CONV_P;         // positions per workgroup (2 -> two workgroups share a CU)
-constexpr int CV_ROWS = CV_P * 90;      // 180
+constexpr int CV_P = CZ_CONV_P;         // positions per workgroup of the per-layer kernel
+constexpr int CV_ROWS = CV_P * 90;      // 360 board cells -> 12 row tiles of 32 (24 rows padding)
 constexpr int CV_RT = 3;                // row tiles per wave
 constexpr int CV_CT = 2;                // col tiles per wave
 constexpr int CV_ROWB = 256;            // bytes per LDS activation row
 constexpr int CV_ACT_BYTES = (CV_ROWS + 1) * CV_ROWB;  // + zero row
 constexpr int CV_SLAB_BYTES = 128 * 128 * 2;            // 32 KB: one whole tap
 constexpr int CV_LDS_BYTES = CV_ACT_BYTES + 2 * CV_SLAB_BYTES;
-constexpr int CV_THREADS = 128 * CV_P;  // (CV_P/2 * 2) row groups x 2 column groups of waves
+constexpr int CV_THREADS = 128 * CV_P;  // CV_P row groups x 2 column groups of waves
 constexpr int CV_PRE = (CV_SLAB_BYTES / 16) / CV_THREADS;  // uint4 prefetch registers per thread
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
@@ -579,4 +562,9 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
     }
 }
 
+#undef TW_SLAB
+#undef TW_SLAB_ARGS
+#undef TW_LOADSET
+#undef CV_LD
+#undef CV_ST
 }  // namespace czconv

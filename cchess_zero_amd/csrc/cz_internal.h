@@ -67,6 +67,7 @@ struct cz_ctx {
     CzTrees t;
     void *tree_block;  // single allocation behind the per-tree arrays
     void *pool_block[2];
+    bool conv_attr_set, tower_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
 };
 
 // kernels' launch wrappers (cz_rules.hip / cz_search.hip)

@@ -14,9 +14,5 @@ build nowstream -DCZ_ABL=16
 build mfmaonly -DCZ_ABL=27
 build_t() { tag=$1; shift; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" -o ubench/tower_$tag tower_ubench.hip & }
 build_t base
-build_t nowstream -DCZ_TABL=4
-build_t nodmawait -DCZ_TABL=16
-build_t nobarrier -DCZ_TABL=48
-build_t nodma_nobar -DCZ_TABL=52
 wait
 ls -la ubench

@@ -31,22 +31,6 @@ int main(int argc, char **argv) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * nblocks * 2.0 * B * 90 * 1152 * 128 / (us * 1e-6) / 1e12;
-#if CZ_TTRACE
-    {
-        std::vector<unsigned long long> t(8192);
-        CK(hipMemcpy(t.data(), out, 8192 * 8, hipMemcpyDeviceToHost));
-        const int ns = 2 * nblocks * 18;
-        double h1 = 0, w = 0, b = 0, h2 = 0; int cnt = 0;
-        for (int g = 4; g + 1 < ns; ++g) {
-            h1 += (double)(t[8 + g * 4 + 1] - t[8 + g * 4 + 0]); w += (double)(t[8 + g * 4 + 2] - t[8 + g * 4 + 1]);
-            b += (double)(t[8 + g * 4 + 3] - t[8 + g * 4 + 2]); h2 += (double)(t[8 + (g + 1) * 4 + 0] - t[8 + g * 4 + 3]); ++cnt;
-        }
-        double ep = 0; for (int l = 0; l < 2 * nblocks; ++l) ep += (double)(t[4096 + 2 * l + 1] - t[4096 + 2 * l]);
-        printf("trace WG1500 wave0: per slab: first half %.0f, vmcnt wait %.0f, barrier %.0f, second half(+next) %.0f ticks; epilogue %.0f ticks/layer; whole WG %.0f ticks\n",
-               h1 / cnt, w / cnt, b / cnt, h2 / cnt, ep / (2 * nblocks), (double)(t[4096 + 2 * (2 * nblocks - 1) + 1] - t[8]));
-        for (int g = 30; g < 40; ++g) printf("  slab %d: %llu %llu %llu | next %llu\n", g, t[8+g*4+1]-t[8+g*4+0], t[8+g*4+2]-t[8+g*4+1], t[8+g*4+3]-t[8+g*4+2], t[8+(g+1)*4]-t[8+g*4+3]);
-    }
-#endif
     printf("tower P=%d threads=%d lds=%d B=%d blocks=%d : %9.1f us/launch (%7.1f us/layer) %7.1f TF/s\n", TW_P, TW_THREADS, TW_LDS_BYTES, B, nblocks, us, us / (2 * nblocks), tf);
     return 0;
 }
