@@ -38,6 +38,9 @@ _SIGS = {
     "cz_search_reset": (C.c_int, [C.c_void_p, _u8p, _u8p, _i32p, C.c_int]),
     "cz_search_select": (C.c_int, [C.c_void_p, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup": (C.c_int, [C.c_void_p, _vp, _vp, C.c_int]),
+    "cz_search_set_width": (C.c_int, [C.c_void_p, C.c_int]),
+    "cz_search_select_k": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
+    "cz_search_expand_backup_k": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int]),
     "cz_search_root_stats": (C.c_int, [C.c_void_p, _u16p, _i32p, _f32p, _f32p, _f32p, _u16p]),
     "cz_search_advance": (C.c_int, [C.c_void_p, _u16p]),
     "cz_search_status": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p]),

@@ -81,6 +81,7 @@ int cz_create(int device, int max_games, int max_nodes_per_tree, cz_ctx **out) {
     cz_ctx *c = new cz_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device; c->stream = nullptr; c->max_games = max_games; c->cap = max_nodes_per_tree; c->G = 0;
+    c->width = 1;
 
     // tables
     const CzHostTables &ht = cz_host_tables();
@@ -131,6 +132,7 @@ int cz_create(int device, int max_games, int max_nodes_per_tree, cz_ctx **out) {
 void cz_destroy(cz_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->pend_block) (void)hipFree(c->pend_block);
     if (c->tab_block) (void)hipFree(c->tab_block);
     if (c->tree_block) (void)hipFree(c->tree_block);
     for (int w = 0; w < 2; ++w)
@@ -199,6 +201,41 @@ int cz_encode_planes(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int 
     CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_encode_planes: dtype must be CZ_F32 or CZ_BF16");
     CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_encode_planes: 14 <= channels <= 64");
     return czk_encode_planes(c, boards, side, G, planes, dtype, channels, quirk);
+}
+
+int cz_search_set_width(cz_ctx *c, int width) {
+    CZ_REQUIRE(c, "null ctx");
+    if (width < 1 || width > 64) { cz_set_error("cz_search_set_width: width %d outside 1..64", width); return CZ_EINVAL; }
+    if (width <= c->width) return CZ_OK;
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->max_games * (size_t)width;
+    Carver m{nullptr};
+    m.take<int32_t>(n); m.take<int32_t>(n); m.take<float>(n); m.take<uint8_t>(n); m.take<uint16_t>(n); m.take<uint16_t>(n * CZD_MAXMOVES);
+    void *blk = nullptr;
+    if (hipMalloc(&blk, m.off) != hipSuccess) { cz_set_error("cz_search_set_width: hipMalloc(%zu B) failed", m.off); return CZ_ENOMEM; }
+    CZ_HIP(hipMemset(blk, 0, m.off));
+    Carver k{(char *)blk};
+    c->t.pend_kind = k.take<int32_t>(n); c->t.pend_leaf = k.take<int32_t>(n); c->t.pend_value = k.take<float>(n);
+    c->t.pend_side = k.take<uint8_t>(n); c->t.pend_nmoves = k.take<uint16_t>(n); c->t.pend_moves = k.take<uint16_t>(n * CZD_MAXMOVES);
+    if (c->pend_block) (void)hipFree(c->pend_block);
+    c->pend_block = blk;
+    c->width = width;
+    return CZ_OK;
+}
+
+int cz_search_select_k(cz_ctx *c, int mode, int k, const uint8_t *active, void *planes, int dtype, int channels, uint8_t *needs_eval) {
+    CZ_REQUIRE(c && c->G > 0, "cz_search_select_k: call cz_search_reset first");
+    CZ_REQUIRE(mode == 0 || mode == 1, "cz_search_select_k: mode must be 0 or 1");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_search_select_k: dtype must be CZ_F32 or CZ_BF16");
+    CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_search_select_k: 14 <= channels <= 64");
+    if (k < 1 || k > c->width) { cz_set_error("cz_search_select_k: k=%d outside 1..width=%d (cz_search_set_width)", k, c->width); return CZ_EINVAL; }
+    return czk_search_select_k(c, mode, k, active, planes, dtype, channels, needs_eval);
+}
+int cz_search_expand_backup_k(cz_ctx *c, int k, const void *logits, const void *value, int dtype) {
+    CZ_REQUIRE(c && c->G > 0 && logits && value, "cz_search_expand_backup_k: null argument / no search");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_search_expand_backup_k: dtype must be CZ_F32 or CZ_BF16");
+    if (k < 1 || k > c->width) { cz_set_error("cz_search_expand_backup_k: k=%d outside 1..width=%d", k, c->width); return CZ_EINVAL; }
+    return czk_search_expand_backup_k(c, k, logits, value, dtype);
 }
 
 int cz_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const int32_t *rr, int G) {

@@ -68,6 +68,8 @@ struct cz_ctx {
     void *tree_block;  // single allocation behind the per-tree arrays
     void *pool_block[2];
     bool conv_attr_set, tower_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
+    int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
+    void *pend_block;  // separate allocation of the pending arrays when width > 1
 };
 
 // kernels' launch wrappers (cz_rules.hip / cz_search.hip)
@@ -80,3 +82,5 @@ int czk_search_select(cz_ctx *, int, const uint8_t *, void *, int, int, uint8_t 
 int czk_search_expand_backup(cz_ctx *, const void *, const void *, int);
 int czk_search_root_stats(cz_ctx *, uint16_t *, int32_t *, float *, float *, float *, uint16_t *);
 int czk_search_advance(cz_ctx *, const uint16_t *);
+int czk_search_select_k(cz_ctx *, int, int, const uint8_t *, void *, int, int, uint8_t *);
+int czk_search_expand_backup_k(cz_ctx *, int, const void *, const void *, int);

@@ -248,6 +248,237 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
     }
 }
 
+// ---- K4/K5/K6 with k simulations in flight per tree (the reference's `search_threads`, main.py:250,337-348) ------
+// Each tree runs up to K descents back to back inside one launch; a descent leaves its virtual loss physically in
+// the tree (N += 3, W += -3 on every selected node, main.py:403-404) so that the following descents of the same batch
+// are steered away from it, exactly as concurrently running coroutines are in the reference.  A descent that ends on
+// a terminal / drawn child completes immediately (main.py:409-435 has no await on that path).  A descent that runs
+// into a node whose expansion is already pending in this batch (the reference parks such a coroutine in
+// `while node in now_expanding: await asyncio.sleep`, main.py:354-355) is abandoned: its virtual loss is taken back
+// and the tree issues no further descents in this step.  The net is then evaluated for all pending leaves at once
+// and k_expand_backup_k expands them in descent order and unwinds each path (N -= 3, W += 3, back_up_value).
+// With K = 1 this is arithmetically identical to k_select / k_expand_backup (tested).  The asyncio interleaving of
+// the reference for K > 1 depends on wall-clock sleeps, so K > 1 is checked against the C oracle's restatement of
+// THIS schedule and through invariants, not against reference golden trees.
+template <typename T>
+__global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G, int mode, int K,
+                                                 const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                                 T one, uint8_t *__restrict__ needs_eval) {
+    __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
+    __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
+    __shared__ uint16_t mv[CZD_MAXMOVES];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const bool parked = (active && !active[g]) || (t.status[g] & ~CZ_ST_BAD_ADVANCE) != 0;
+    const TreeView v = view_of(t, g, t.cur[g]);
+    const int root = t.root_node[g];
+    bool stop = parked;
+    int done_now = 0;   // simulations completed inside this launch (terminal / draw)
+    for (int j = 0; j < K; ++j) {
+        const size_t slot = (size_t)g * K + j;
+        T *pl = planes ? planes + slot * 90 * C : nullptr;
+        int kind = 0, leaf = 0, depth = 0, side = t.root_side[g];
+        if (!stop) {
+            __syncthreads();
+            for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64)
+                ((uint32_t *)b)[i] = ((const uint32_t *)(t.root_board + (size_t)g * CZD_BOARD_LDS))[i];
+            __syncthreads();
+            int rr = t.root_rr[g];
+            int node = root;
+            const int c0 = b[lane], c1 = (lane + 64 < CZ_NSQ) ? b[lane + 64] : 0;
+            bool Kmiss = (__ballot(c0 == 1) | __ballot(c1 == 1)) == 0ull;
+            bool kmiss = (__ballot(c0 == 8) | __ballot(c1 == 8)) == 0ull;
+            if (v.child_begin[root] < 0) {
+                kind = 3; leaf = root; stop = true;  // root expansion is a step of its own (main.py:475-487)
+            } else if (mode == 0) {
+                stop = true;
+            } else {
+                for (;;) {
+                    const int cb = v.child_begin[node];
+                    bool abandon = false;
+                    if (cb == -1) {   // not expanded: this descent owns the expansion
+                        kind = 1; leaf = node;
+                        if (lane == 0) v.child_begin[node] = -2;
+                        break;
+                    }
+                    const int cc = cb >= 0 ? (int)v.child_count[node] : 0;
+                    if (cb == -2) abandon = true;                                   // expansion pending in this batch
+                    else if (cc == 0) { if (lane == 0) t.status[g] |= CZ_ST_NO_MOVES; abandon = true; }
+                    if (abandon) {
+                        if (lane == 0)   // take the virtual loss of this descent back (main.py:426-427 without a backup)
+                            for (int n = node; n != root; n = v.parent[n]) { v.N[n] -= 3; v.W[n] = v.W[n] + 3.0f; }
+                        stop = true;
+                        break;
+                    }
+                    const double sq = sqrt((double)v.N[node]);   // includes the virtual losses currently in flight
+                    Cand best; best.s = -INFINITY; best.i = 0x7FFFFFFF;
+                    bool first_nan = false;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < cc) {
+                            const float cp = 5.0f * v.P[cb + i];
+                            const double u = (double)cp * sq / (double)(1 + v.N[cb + i]);
+                            double s = (double)v.Q[cb + i] + u;   // Q is not recomputed under virtual loss (quirk Q6)
+                            if (s != s) { if (i == 0) first_nan = true; s = -INFINITY; }
+                            Cand c; c.s = s; c.i = i;
+                            best = better(best, c);
+                        }
+                    }
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        Cand o; o.s = __shfl_xor(best.s, d, 64); o.i = __shfl_xor(best.i, d, 64);
+                        best = better(best, o);
+                    }
+                    int bi = best.i;
+                    if (__shfl((int)first_nan, 0, 64)) bi = 0;
+                    const int c = cb + bi;
+                    const int l = v.move[c];
+                    const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+                    const int cap = b[dst];
+                    __syncthreads();
+                    if (lane == 0) {
+                        b[dst] = b[src]; b[src] = 0;
+                        v.N[c] += 3; v.W[c] = v.W[c] + -3.0f;   // virtual loss, main.py:403-404
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    side ^= 1;
+                    rr = cap ? 0 : rr + 1;
+                    ++depth;
+                    if (cap == 1) Kmiss = true;
+                    if (cap == 8) kmiss = true;
+                    const bool term = Kmiss || kmiss;
+                    if (term || rr >= 60) {
+                        float value = 0.f;
+                        if (term) {
+                            if (Kmiss) value = side ? 1.0f : -1.0f;
+                            if (kmiss) value = side ? -1.0f : 1.0f;
+                            value = value * -1.0f;
+                        }
+                        if (lane == 0) {   // unwind immediately: main.py:426-435
+                            float x = value;
+                            for (int n = c; n != root; n = v.parent[n]) {
+                                const int cnt = v.N[n] - 3 + 1;
+                                float w = v.W[n] + 3.0f;
+                                w = w + x;
+                                v.N[n] = cnt; v.W[n] = w; v.Q[n] = w / (float)cnt;
+                                x = x * -1.0f;
+                            }
+                        }
+                        __threadfence_block();
+                        __syncthreads();
+                        ++done_now;
+                        kind = 0;
+                        break;
+                    }
+                    node = c;
+                }
+            }
+        }
+        int nmoves = 0;
+        if (kind == 1 || kind == 3) {
+            nmoves = czd_wave_movegen(b, side, tab.lut, stage, mv, lane);
+            if (nmoves < 0) {   // > 128 moves / unlabeled move: report, give the node and the virtual loss back
+                if (lane == 0) {
+                    t.status[g] |= CZ_ST_MOVE_OVERFLOW;
+                    if (kind == 1) {
+                        v.child_begin[leaf] = -1;
+                        for (int n = leaf; n != root; n = v.parent[n]) { v.N[n] -= 3; v.W[n] = v.W[n] + 3.0f; }
+                    }
+                }
+                kind = 0; nmoves = 0; stop = true;
+            }
+        }
+        if (kind == 1 || kind == 3) {
+            for (int i = lane; i < nmoves; i += 64) t.pend_moves[slot * CZD_MAXMOVES + i] = mv[i];
+            if (pl) czd_wave_encode_planes<T>(b, side, 1, pl, C, one, lane);
+        } else if (pl) {
+            for (int e = lane; e < 90 * C; e += 64) pl[e] = (T)0;
+        }
+        if (lane == 0) {
+            t.pend_kind[slot] = kind; t.pend_leaf[slot] = leaf; t.pend_value[slot] = 0.f;
+            t.pend_side[slot] = (uint8_t)side; t.pend_nmoves[slot] = (uint16_t)nmoves;
+            if (kind) t.last_depth[g] = depth;
+            if (needs_eval) needs_eval[slot] = kind ? 1 : 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (lane == 0 && done_now) t.sims[g] += done_now;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_expand_backup_k(CzTrees t, CzTables tab, int G, int K, const T *__restrict__ logits,
+                                                        const T *__restrict__ value) {
+    __shared__ float pr[CZD_MAXMOVES];
+    __shared__ float tot_s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const TreeView v = view_of(t, g, t.cur[g]);
+    const int root = t.root_node[g];
+    for (int j = 0; j < K; ++j) {
+        const size_t slot = (size_t)g * K + j;
+        const int kind = t.pend_kind[slot];
+        if (kind == 0) continue;
+        const int leaf = t.pend_leaf[slot];
+        const int n = t.pend_nmoves[slot];
+        const int sd = t.pend_side[slot];
+        const int begin = t.n_nodes[g];
+        const bool fits = begin + n <= t.cap;
+        __syncthreads();
+        if (fits) {
+            const T *lg = logits + slot * CZ_NLABELS;
+            uint16_t lab[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = lane + 64 * r;
+                lab[r] = 0;
+                if (i < n) {
+                    lab[r] = t.pend_moves[slot * CZD_MAXMOVES + i];
+                    pr[i] = to_f32<T>(lg[sd ? tab.unflip[lab[r]] : lab[r]]);
+                }
+            }
+            __syncthreads();
+            if (lane == 0) {
+                float tot = (float)1e-8;
+                for (int i = 0; i < n; ++i) tot = tot + pr[i];
+                tot_s = tot;
+            }
+            __syncthreads();
+            const float tot = tot_s;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = lane + 64 * r;
+                if (i < n) {
+                    const int c = begin + i;
+                    v.P[c] = pr[i] / tot;
+                    v.W[c] = 0.f; v.Q[c] = 0.f; v.N[c] = 0; v.parent[c] = leaf; v.child_begin[c] = -1;
+                    v.child_count[c] = 0; v.move[c] = lab[r];
+                }
+            }
+            if (lane == 0) { v.child_begin[leaf] = begin; v.child_count[leaf] = (uint16_t)n; t.n_nodes[g] = begin + n; }
+        } else if (lane == 0) {
+            t.status[g] |= CZ_ST_POOL_EXHAUSTED;
+            v.child_begin[leaf] = -1;   // no longer pending
+        }
+        if (kind == 1 && lane == 0) {
+            float x = to_f32<T>(value[slot]) * -1.0f;
+            for (int m = leaf; m != root; m = v.parent[m]) {
+                const int cnt = v.N[m] - 3 + 1;   // virtual loss off, visit on (main.py:426-427,190)
+                float w = v.W[m] + 3.0f;
+                w = w + x;
+                v.N[m] = cnt; v.W[m] = w; v.Q[m] = w / (float)cnt;
+                x = x * -1.0f;
+            }
+            t.sims[g] += 1;
+        }
+        if (lane == 0) t.pend_kind[slot] = 0;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // ---- root children: root.child.items(), main.py:1339 ----------------------------------------------
 __global__ __launch_bounds__(64) void k_root_stats(CzTrees t, int G, uint16_t *__restrict__ label, int32_t *__restrict__ N,
                                                    float *__restrict__ Q, float *__restrict__ P, float *__restrict__ W,
@@ -395,6 +626,24 @@ int cz_search_root_state(cz_ctx *c, uint8_t *boards, uint8_t *side, int32_t *rr)
     if (!c) { cz_set_error("null ctx"); return CZ_EINVAL; }
     if (c->G == 0) return CZ_OK;
     hipLaunchKernelGGL(k_root_state, dim3(c->G), dim3(64), 0, c->stream, c->t, c->G, boards, side, rr);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_select_k(cz_ctx *c, int mode, int K, const uint8_t *active, void *planes, int dtype, int C, uint8_t *needs_eval) {
+    if (dtype == CZ_F32)
+        hipLaunchKernelGGL(k_select_k<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, active, (float *)planes, C, 1.0f, needs_eval);
+    else
+        hipLaunchKernelGGL(k_select_k<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, active, (uint16_t *)planes, C, (uint16_t)0x3F80, needs_eval);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_expand_backup_k(cz_ctx *c, int K, const void *logits, const void *value, int dtype) {
+    if (dtype == CZ_F32)
+        hipLaunchKernelGGL(k_expand_backup_k<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, K, (const float *)logits, (const float *)value);
+    else
+        hipLaunchKernelGGL(k_expand_backup_k<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, K, (const uint16_t *)logits, (const uint16_t *)value);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

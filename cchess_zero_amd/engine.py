@@ -53,8 +53,12 @@ class Context:
 class SearchEngine:
     """G trees searched in lock-step: select -> (batched net) -> expand_backup."""
 
-    def __init__(self, max_games, max_nodes_per_tree, device=0, plane_dtype=torch.float32, channels=14, ctx=None):
+    def __init__(self, max_games, max_nodes_per_tree, device=0, plane_dtype=torch.float32, channels=14, ctx=None, width=1):
+        """width = simulations in flight per tree and step (the reference's search_threads); 1 = sequential."""
         self.ctx = ctx or Context(max_games, max_nodes_per_tree, device)
+        self.width = int(width)
+        if self.width > 1:
+            check(lib().cz_search_set_width(self.ctx.h, self.width), "cz_search_set_width")
         self.dev = self.ctx.device
         self.G = 0
         self.channels = int(channels)
@@ -74,17 +78,26 @@ class SearchEngine:
         check(lib().cz_search_reset(self.ctx.h, _ptr(boards), _ptr(side), _ptr(rr_t), G), "cz_search_reset")
         if self.G != G or self.planes is None:
             self.G = G
-            self.planes = torch.zeros((G, 9, 10, self.channels), dtype=self.plane_dtype, device=self.dev)
-            self.need = torch.zeros(G, dtype=torch.uint8, device=self.dev)
+            self.planes = torch.zeros((G * self.width, 9, 10, self.channels), dtype=self.plane_dtype, device=self.dev)
+            self.need = torch.zeros(G * self.width, dtype=torch.uint8, device=self.dev)
         self._keep = (boards, side, rr_t)
 
-    def select(self, mode=1, active=None):
-        """-> (leaf planes [G,9,10,C] device tensor, needs_eval [G] u8 device tensor)."""
+    def select(self, mode=1, active=None, k=None):
+        """-> (leaf planes [G*k,9,10,C] device tensor, needs_eval [G*k] u8 device tensor); k <= width descents per
+        tree (default: the engine's width)."""
+        k = self.width if k is None else int(k)
+        self._k = k
         act = None
         if active is not None:
             act = torch.as_tensor(active).to(self.dev).to(torch.uint8).contiguous()
-        check(lib().cz_search_select(self.ctx.h, int(mode), _ptr(act), _ptr(self.planes), self._pd, self.channels,
-                                     _ptr(self.need)), "cz_search_select")
+        if self.width > 1:
+            check(lib().cz_search_select_k(self.ctx.h, int(mode), k, _ptr(act), _ptr(self.planes), self._pd, self.channels,
+                                           _ptr(self.need)), "cz_search_select_k")
+            self._act = act
+            return self.planes[:self.G * k], self.need[:self.G * k]
+        else:
+            check(lib().cz_search_select(self.ctx.h, int(mode), _ptr(act), _ptr(self.planes), self._pd, self.channels,
+                                         _ptr(self.need)), "cz_search_select")
         self._act = act
         return self.planes, self.need
 
@@ -97,8 +110,12 @@ class SearchEngine:
             logits, value = logits.float(), value.float()
         logits = logits.contiguous()
         value = value.contiguous()
-        assert logits.shape == (self.G, NLABELS) and value.numel() == self.G
-        check(lib().cz_search_expand_backup(self.ctx.h, _ptr(logits), _ptr(value), dt), "cz_search_expand_backup")
+        k = getattr(self, "_k", self.width)
+        assert logits.shape == (self.G * k, NLABELS) and value.numel() == self.G * k
+        if self.width > 1:
+            check(lib().cz_search_expand_backup_k(self.ctx.h, k, _ptr(logits), _ptr(value), dt), "cz_search_expand_backup_k")
+        else:
+            check(lib().cz_search_expand_backup(self.ctx.h, _ptr(logits), _ptr(value), dt), "cz_search_expand_backup")
 
     def root_stats(self):
         G, dev = self.G, self.dev
@@ -155,7 +172,8 @@ class SearchEngine:
         self.expand_backup(logits, value)
 
     def search(self, forward, playouts, active=None):
-        """MCTS_tree.main (main.py:473-493) for all trees: expand unexpanded roots, then `playouts` simulations."""
+        """MCTS_tree.main (main.py:473-493) for all trees: expand unexpanded roots, then `playouts` simulations
+        (with width k: ceil(playouts / k) lock-step batches of up to k simulations per tree)."""
         self.step(forward, mode=0, active=active)
-        for _ in range(int(playouts)):
+        for _ in range((int(playouts) + self.width - 1) // self.width):
             self.step(forward, mode=1, active=active)

@@ -117,6 +117,16 @@ int cz_search_select(cz_ctx *, int mode, const uint8_t *active, void *leaf_plane
  *   back_up_value (:189-194) along the unwind (:426-435), including the float32 effect of the
  *   virtual-loss add/remove (:403-404,426-427).  logits [G][2086], value [G] of `dtype`. */
 int cz_search_expand_backup(cz_ctx *, const void *logits, const void *value, int dtype);
+/* k simulations in flight per tree and step, with the reference's virtual loss (N += 3, W -= 3 while in flight):
+ * replaces the `search_threads` coroutines of MCTS_tree (asyncio.Semaphore(search_threads), main.py:250,337-348,
+ * virtual loss :231,403-404,426-427, now_expanding :354-360).  cz_search_set_width sizes the pending-leaf arrays
+ * (1 <= width <= 64, default 1; call before the search loop).  leaf_planes / needs_eval / logits / value then have
+ * G*k rows, slot g*k + j = j-th descent of tree g; slots a tree does not use have needs_eval = 0.  k = 1 is
+ * arithmetically identical to cz_search_select / cz_search_expand_backup. */
+int cz_search_set_width(cz_ctx *, int width);
+int cz_search_select_k(cz_ctx *, int mode, int k, const uint8_t *active, void *leaf_planes, int dtype,
+                       int channels, uint8_t *needs_eval);
+int cz_search_expand_backup_k(cz_ctx *, int k, const void *logits, const void *value, int dtype);
 /* replaces: reading root.child.items() in get_action, main.py:1339 (+ MCTS_tree.Q :261).
  *   arrays [G][128] (any may be NULL), count [G]. */
 int cz_search_root_stats(cz_ctx *, uint16_t *move_label, int32_t *N, float *Q, float *P, float *W,

@@ -11,10 +11,12 @@ Where the reference is single-game Python, this façade keeps the one-game call 
 running the batched kernels with G = 1; `cchess_main.run()` — the training loop — plays `--games`
 games in lock-step per GPU (extra flag, default 256), which is where the throughput is.
 
-Semantics notes: search_threads is accepted but the device search is the
-search_threads = 1 behaviour of the reference (one simulation in flight per tree; bit-identical to
-the reference under that setting, see tests/golden); pseudo-legal rules, raw-logit priors, the root
-never being backed up, and the 9-stride plane quirk are all reproduced.
+Semantics notes: with search_threads = 1 the device search is bit-identical to the
+reference (whole trees, see tests/golden).  search_threads = k > 1 keeps k simulations in flight per tree
+with the reference's virtual loss (N += 3, W -= 3), batched deterministically (the reference's own
+interleaving depends on wall-clock asyncio sleeps); the batched `run()` loop uses one simulation in
+flight per tree because thousands of trees already fill the net batch.  Pseudo-legal rules, raw-logit
+priors, the root never being backed up, and the 9-stride plane quirk are all reproduced.
 """
 import argparse
 import os
@@ -187,7 +189,9 @@ class MCTS_tree(object):
         self.forward = in_forward
         self.search_threads = search_threads
         self._cap = int(os.environ.get("CCHESS_TREE_NODES", 400000))
-        self._eng = SearchEngine(1, self._cap)
+        # search_threads coroutines of the reference = that many simulations in flight with virtual loss
+        self._width = max(1, min(int(search_threads), 64))
+        self._eng = SearchEngine(1, self._cap, width=self._width)
         self._state = None
         self._player = None
         self._rr = 0
@@ -217,9 +221,9 @@ class MCTS_tree(object):
         owner = getattr(self.forward, "__self__", None)
         return getattr(owner, "forward_device", None)
 
-    def _step(self, mode):
+    def _step(self, mode, k=None):
         import torch
-        planes, need = self._eng.select(mode)
+        planes, need = self._eng.select(mode, k=k)
         fd = self._device_forward()
         if fd is not None:
             logits, value = fd(planes)
@@ -241,8 +245,17 @@ class MCTS_tree(object):
             self._set_root(state, current_player, restrict_round)
         self._rr = restrict_round
         self._step(0)                       # root expansion if needed (main.py:475-487)
-        for _ in range(int(playouts)):
-            self._step(1)                   # one simulation (main.py:350-435)
+        if self._width == 1:
+            for _ in range(int(playouts)):
+                self._step(1)               # one simulation (main.py:350-435)
+        else:                               # up to `search_threads` simulations in flight, exactly `playouts` in total
+            base = int(self._eng.status()[2].cpu().numpy()[0])
+            done, stall = 0, 0
+            while done < int(playouts) and stall < 4:
+                self._step(1, k=min(self._width, int(playouts) - done))
+                now = int(self._eng.status()[2].cpu().numpy()[0]) - base
+                stall = stall + 1 if now == done else 0
+                done = now
         self._cache = None
         status = int(self._eng.status()[0].cpu().numpy()[0])
         if status & 1:

@@ -349,6 +349,9 @@ typedef struct {
     uint16_t moves[CZO_MAXMOVES];
     int nmoves;
     int status, sims, last_depth;
+    /* k-wide search: pending slots */
+    struct oslot { int kind, leaf, side, nmoves; uint16_t moves[CZO_MAXMOVES]; } *slots;
+    int nslots;
 } otree;
 
 struct czo_search {
@@ -369,7 +372,7 @@ czo_search *czo_search_create(int max_games, int cap) {
 }
 void czo_search_destroy(czo_search *s) {
     if (!s) return;
-    for (int i = 0; i < s->max_games; i++) free(s->t[i].nodes);
+    for (int i = 0; i < s->max_games; i++) { free(s->t[i].nodes); free(s->t[i].slots); }
     free(s->t); free(s);
 }
 
@@ -611,4 +614,134 @@ int czo_search_tree_dump(const czo_search *s, int g, int32_t *out, int max_recor
     int n = 0;
     dump_rec(&s->t[g], s->t[g].root, 0, out, max_records, &n);
     return n;
+}
+
+/* ---- k simulations in flight per tree: restatement of the schedule of k_select_k / k_expand_backup_k
+ * (cchess_zero_amd/csrc/cz_search.hip), which batches the reference's search_threads coroutines
+ * (main.py:250,337-348) with its virtual loss (:231,403-404,426-427).  The reference's own interleaving
+ * depends on wall-clock sleeps (:355,452), so this — not a golden tree — is the parity target for k > 1. */
+static int select_child_vl(const otree *t, int node) {
+    const onode *p = &t->nodes[node];
+    double sq = sqrt((double)p->N); /* physical virtual losses included */
+    int best = -1; double bestv = 0;
+    for (int i = 0; i < p->child_count; i++) {
+        const onode *c = &t->nodes[p->child_begin + i];
+        float cp = 5.0f * c->P;
+        double u = (double)cp * sq / (double)(1 + c->N);
+        double v = (double)c->Q + u;
+        if (best < 0 || v > bestv) { best = p->child_begin + i; bestv = v; }
+    }
+    return best;
+}
+
+int czo_search_select_k(czo_search *s, int mode, int K, float *planes, uint8_t *needs_eval) {
+    for (int g = 0; g < s->G; g++) {
+        otree *t = &s->t[g];
+        if (t->nslots < K) { free(t->slots); t->slots = calloc((size_t)K, sizeof(*t->slots)); t->nslots = K; }
+        int stop = (t->status & ~8) != 0;
+        for (int j = 0; j < K; j++) {
+            size_t slot = (size_t)g * K + j;
+            float *pl = planes ? planes + slot * CZO_PLANE_ELEMS : NULL;
+            if (pl) memset(pl, 0, sizeof(float) * CZO_PLANE_ELEMS);
+            if (needs_eval) needs_eval[slot] = 0;
+            struct oslot *sl = &t->slots[j];
+            sl->kind = 0;
+            if (stop) continue;
+            uint8_t b[CZO_NSQ];
+            memcpy(b, t->board, CZO_NSQ);
+            int side = t->side, rr = t->rr, node = t->root, depth = 0;
+            if (t->nodes[node].child_begin < 0) { sl->kind = 3; sl->leaf = node; stop = 1; }
+            else if (mode == 0) { stop = 1; }
+            else {
+                for (;;) {
+                    onode *p = &t->nodes[node];
+                    int abandon = 0;
+                    if (p->child_begin == -1) { sl->kind = 1; sl->leaf = node; p->child_begin = -2; break; }
+                    if (p->child_begin == -2) abandon = 1;
+                    else if (p->child_count == 0) { t->status |= 2; abandon = 1; }
+                    if (abandon) {
+                        for (int n = node; n != t->root; n = t->nodes[n].parent) { t->nodes[n].N -= 3; t->nodes[n].W = t->nodes[n].W + 3.0f; }
+                        stop = 1; break;
+                    }
+                    int c = select_child_vl(t, node);
+                    uint8_t cap;
+                    int term = czo_apply_move(b, t->nodes[c].move, &cap);
+                    t->nodes[c].N += 3; t->nodes[c].W = t->nodes[c].W + -3.0f;
+                    side ^= 1; rr = cap ? 0 : rr + 1; depth++;
+                    if (term || rr >= 60) {
+                        float value = 0;
+                        if (term) { if (term & 1) value = side ? 1.0f : -1.0f; if (term & 2) value = side ? -1.0f : 1.0f; value = value * -1; }
+                        float x = value;
+                        for (int n = c; n != t->root; n = t->nodes[n].parent) {
+                            onode *q = &t->nodes[n];
+                            int cnt = q->N - 3 + 1;
+                            float w = q->W + 3.0f; w = w + x;
+                            q->N = cnt; q->W = w; q->Q = w / (float)cnt; x = x * -1;
+                        }
+                        t->sims++;
+                        break;
+                    }
+                    node = c;
+                }
+            }
+            if (sl->kind == 1 || sl->kind == 3) {
+                sl->side = side;
+                int n = czo_legal_moves(b, side, sl->moves);
+                if (n < 0) {
+                    t->status |= 4;
+                    if (sl->kind == 1) {
+                        t->nodes[sl->leaf].child_begin = -1;
+                        for (int m = sl->leaf; m != t->root; m = t->nodes[m].parent) { t->nodes[m].N -= 3; t->nodes[m].W = t->nodes[m].W + 3.0f; }
+                    }
+                    sl->kind = 0; stop = 1; continue;
+                }
+                sl->nmoves = n;
+                t->last_depth = depth;
+                if (pl) czo_encode_planes(b, side, 1, pl);
+                if (needs_eval) needs_eval[slot] = 1;
+            }
+        }
+    }
+    return 0;
+}
+
+int czo_search_expand_backup_k(czo_search *s, int K, const float *logits, const float *value) {
+    for (int g = 0; g < s->G; g++) {
+        otree *t = &s->t[g];
+        for (int j = 0; j < K && j < t->nslots; j++) {
+            struct oslot *sl = &t->slots[j];
+            if (!sl->kind) continue;
+            size_t slot = (size_t)g * K + j;
+            const float *lg = logits + slot * CZO_NLABELS;
+            if (t->n_nodes + sl->nmoves > t->cap) {
+                t->status |= 1;
+                t->nodes[sl->leaf].child_begin = -1;
+            } else {
+                int begin = t->n_nodes;
+                float tot = (float)1e-8;
+                for (int i = 0; i < sl->nmoves; i++) {
+                    uint16_t l = sl->moves[i];
+                    float p = lg[sl->side ? g_unflip[l] : l];
+                    onode *c = &t->nodes[begin + i];
+                    c->P = p; c->W = 0; c->Q = 0; c->N = 0; c->parent = sl->leaf; c->child_begin = -1; c->child_count = 0; c->move = l;
+                    tot = tot + p;
+                }
+                for (int i = 0; i < sl->nmoves; i++) t->nodes[begin + i].P = t->nodes[begin + i].P / tot;
+                t->nodes[sl->leaf].child_begin = begin; t->nodes[sl->leaf].child_count = (uint16_t)sl->nmoves;
+                t->n_nodes += sl->nmoves;
+            }
+            if (sl->kind == 1) {
+                float x = value[slot] * -1;
+                for (int n = sl->leaf; n != t->root; n = t->nodes[n].parent) {
+                    onode *q = &t->nodes[n];
+                    int cnt = q->N - 3 + 1;
+                    float w = q->W + 3.0f; w = w + x;
+                    q->N = cnt; q->W = w; q->Q = w / (float)cnt; x = x * -1;
+                }
+                t->sims++;
+            }
+            sl->kind = 0;
+        }
+    }
+    return 0;
 }

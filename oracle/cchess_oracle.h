@@ -94,6 +94,12 @@ int czo_search_root_state(const czo_search *, uint8_t *boards, uint8_t *side, in
 /* debugging/parity: depth (edges from root) of the last selected leaf per tree */
 int czo_search_last_depth(const czo_search *, int32_t *depth);
 
+/* k simulations in flight per tree with physical virtual loss: restates the schedule of the HIP kernels
+ * k_select_k / k_expand_backup_k (see cchess_oracle.c).  planes [G*K][9][10][14], needs_eval [G*K],
+ * logits [G*K][2086], value [G*K]. */
+int czo_search_select_k(czo_search *, int mode, int K, float *planes, uint8_t *needs_eval);
+int czo_search_expand_backup_k(czo_search *, int K, const float *logits, const float *value);
+
 /* pre-order dump of tree g: records of 7 int32 {depth, label, N, bits(W), bits(Q), bits(P),
  * child_count or -1}; returns the record count (writes at most max_records). */
 int czo_search_tree_dump(const czo_search *, int g, int32_t *out, int max_records);

@@ -45,7 +45,7 @@ def lib():
         L.czo_search_destroy.argtypes = [C.c_void_p]
         for name in ("czo_search_reset", "czo_search_select", "czo_search_expand_backup", "czo_search_root_stats",
                      "czo_search_advance", "czo_search_status", "czo_search_root_state", "czo_search_last_depth",
-                     "czo_search_tree_dump"):
+                     "czo_search_tree_dump", "czo_search_select_k", "czo_search_expand_backup_k"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -163,6 +163,17 @@ class Search:
         logits = np.ascontiguousarray(logits, np.float32).reshape(self.G, NLABELS)
         value = np.ascontiguousarray(value, np.float32).reshape(self.G)
         lib().czo_search_expand_backup(self.h, _p(logits), _p(value))
+
+    def select_k(self, mode, K):
+        planes = np.zeros((self.G * K, 9, 10, 14), np.float32)
+        need = np.zeros(self.G * K, np.uint8)
+        lib().czo_search_select_k(self.h, int(mode), int(K), _p(planes), _p(need))
+        return planes, need
+
+    def expand_backup_k(self, K, logits, value):
+        logits = np.ascontiguousarray(logits, np.float32).reshape(self.G * K, NLABELS)
+        value = np.ascontiguousarray(value, np.float32).reshape(self.G * K)
+        lib().czo_search_expand_backup_k(self.h, int(K), _p(logits), _p(value))
 
     def root_stats(self):
         G = self.G

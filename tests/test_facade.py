@@ -66,6 +66,26 @@ def test_gameboard_and_tree_match_reference(tables_golden, mcts_golden, tmp_path
 
 
 @pytest.mark.gpu
+def test_tree_with_search_threads_16(tmp_path, monkeypatch):
+    """MCTS_tree(search_threads=16): exactly `playouts` simulations, visit counts add up, best move plausible."""
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, ROOT)
+    import main as M
+    import fakenet
+    start = M.GameBoard().state
+    t = M.MCTS_tree(start, fakenet.make_forward("pos", 0), 16)
+    t.main(start, "w", 0, 200)
+    ch = t.root.child
+    assert len(ch) == 44 and sum(n.N for n in ch.values()) == 200
+    assert all(n.N >= 0 and abs(n.Q) <= 1 for n in ch.values())
+    best = max(ch.items(), key=lambda kv: kv[1].N)[0]
+    t.update_tree(best)
+    nxt = M.GameBoard.sim_do_action(best, start)
+    t.main(nxt, "b", 1, 64)
+    assert sum(n.N for n in t.root.child.values()) >= 64
+
+
+@pytest.mark.gpu
 def test_cchess_main_selfplay_and_update(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     sys.path.insert(0, ROOT)
