@@ -1,6 +1,7 @@
 // cz_conv.hip — C-ABI wrapper of the fused MFMA conv3x3 kernel (device code: cz_conv_kernel.h).
 #include "cz_internal.h"
 #include "cz_conv_kernel.h"
+#include <stdlib.h>
 
 extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, const void *residual,
                                     void *out, int B, int relu) {
@@ -25,12 +26,22 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
     if (B == 0) return CZ_OK;
     if (!c->tower_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
         c->tower_attr_set = true;
     }
-    const int grid = (B + TW_P - 1) / TW_P;
-    hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
-                       (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                       (const uint16_t *)w0, b0, B, 2 * nblocks);
+    // CCHESS_TOWER_VARIANT=4w selects the 2-position / 4-wave kernel, anything else the 4-position / 8-wave one
+    static const bool use4w = [] { const char *e = getenv("CCHESS_TOWER_VARIANT"); return e && e[0] == '4'; }();
+    if (use4w) {
+        const int grid = (B + TW_P - 1) / TW_P;
+        hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
+                           (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
+                           (const uint16_t *)w0, b0, B, 2 * nblocks);
+    } else {
+        const int grid = (B + T8_P - 1) / T8_P;
+        hipLaunchKernelGGL(k_tower8_c128, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
+                           (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
+                           (const uint16_t *)w0, b0, B, 2 * nblocks);
+    }
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

@@ -562,6 +562,278 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
     }
 }
 
+// =================================================================================================
+// k_tower8_c128: the same one-launch net trunk with FOUR positions per workgroup and EIGHT waves (two per SIMD).
+//
+// The accumulators of the 8 waves hold a layer's complete output (360 cells x 128 channels), so a layer can be
+// written back IN PLACE once every wave has finished reading its input: only one activation buffer U (90 KB for
+// 4 positions) is needed instead of U and V.  The block input x needed by the residual add is kept by each lane
+// in registers (48 packed bf16 pairs) and folded into the accumulator initialisation of the block's second conv.
+// Compared with k_tower_c128 this halves the L2 -> LDS weight stream per position and gives every SIMD a second
+// wave that issues MFMAs while the first one waits, loads or runs its epilogue.
+//   waves   8 = 4 (row groups of 3 tiles) x 2 (column groups of 2 tiles); 3x2 accumulators each; <= 256 registers.
+//   frags   two register sets; each k-step waits for its own set, then interleaves its 6 MFMAs with the reads of
+//           the next k-step.
+//   weights same 4-deep ring of 16 KB slabs by LDS-DMA, 2 pieces per wave and slab, counted vmcnt(2).
+//   layer   main loop -> s_barrier (all reads of U done) -> epilogue writes U in place -> s_barrier.
+// =================================================================================================
+constexpr int T8_P = 4;
+constexpr int T8_ROWS = T8_P * 90;                  // 360 cells = 11.25 row tiles -> 12 (24 rows padding)
+constexpr int T8_THREADS = 512;
+constexpr int T8_ZERO_OFF = T8_ROWS * CV_ROWB;      // 92,160
+constexpr int T8_W_OFF = T8_ZERO_OFF + CV_ROWB;     // 92,416
+constexpr int T8_LDS_BYTES = T8_W_OFF + TW_NBUF * TW_SLAB_BYTES;   // 157,952
+constexpr int T8_PLANES_OFF = T8_W_OFF + 3 * TW_SLAB_BYTES;        // input planes borrow ring buffer 3
+
+__global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *__restrict__ in,
+                                                               const uint16_t *__restrict__ wpk,
+                                                               const float *__restrict__ bias,
+                                                               uint16_t *__restrict__ out,
+                                                               const float *__restrict__ head_w,
+                                                               const float *__restrict__ head_b,
+                                                               float *__restrict__ head_out,
+                                                               const uint16_t *__restrict__ planes,
+                                                               const uint16_t *__restrict__ w0,
+                                                               const float *__restrict__ b0,
+                                                               int B, int nlayers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int pos0 = blockIdx.x * T8_P;
+    const int npos = (B - pos0) < T8_P ? (B - pos0) : T8_P;
+    const int nrows = npos * 90;
+    const int nslabs = nlayers * 18;
+    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
+    const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + 8192u;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * TW_SLAB_BYTES;
+        unsigned char *dst = smem + T8_W_OFF + ((unsigned)slab & 3u) * TW_SLAB_BYTES + (wave_u << 10);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff0),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff1),
+                                         (__attribute__((address_space(3))) void *)(dst + 8192), 16, 0, 0);
+    };
+    for (int q = 0; q < 3; ++q) dma_slab(q < nslabs ? q : nslabs - 1);
+    if (planes == nullptr) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < T8_ROWS * 16; idx += T8_THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < nrows) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
+        }
+    } else {
+        const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
+        for (int idx = tid; idx < T8_ROWS * 2; idx += T8_THREADS) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < nrows * 2) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + T8_PLANES_OFF + (idx << 4)) = v;
+        }
+    }
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + T8_ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int rowb[CV_RT], tapmask[CV_RT];
+#pragma unroll
+    for (int i = 0; i < CV_RT; ++i) {
+        const int r = 32 * (wr * CV_RT + i) + l31;
+        const int pix = r % 90, h = pix / 10, w = pix - h * 10;
+        rowb[i] = r * CV_ROWB;
+        int m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
+            if (r < T8_ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+        }
+        tapmask[i] = m;
+    }
+    auto tap_addr = [&](int tap, int (&ab)[CV_RT], int (&key)[CV_RT]) {
+        const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : T8_ZERO_OFF;
+            ab[i] = a;
+            key[i] = ((a >> 8) & 15) ^ khalf;
+        }
+    };
+    const int vb0 = T8_W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);
+    int keep;
+
+    // the cells / channel quads this lane owns in the accumulator layout
+    auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
+        const int r = 32 * (wr * CV_RT + i) + l31;
+        live = r < T8_ROWS;
+        const int rc = live ? r : 0;
+        const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
+        return reinterpret_cast<uint2 *>(smem + lds_addr(rc * CV_ROWB, n0 >> 3) + ((n0 & 4) << 1));
+    };
+    // acc = bias (+ x): the residual is folded into the initialisation of a block's second conv
+    uint2 xreg[CV_RT][CV_CT][4];   // block input x at this lane's accumulator positions (packed bf16)
+    auto init_acc = [&](f32x16 (&acc)[CV_RT][CV_CT], const float *bl, bool add_x) {
+#pragma unroll
+        for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4 *>(bl + wc * 64 + j * 32 + 8 * q + 4 * khalf);
+#pragma unroll
+                for (int i = 0; i < CV_RT; ++i) {
+                    float a0 = bq.x, a1 = bq.y, a2 = bq.z, a3 = bq.w;
+                    if (add_x) {
+                        const uint2 x = xreg[i][j][q];
+                        a0 += __uint_as_float(x.x << 16); a1 += __uint_as_float(x.x & 0xFFFF0000u);
+                        a2 += __uint_as_float(x.y << 16); a3 += __uint_as_float(x.y & 0xFFFF0000u);
+                    }
+                    acc[i][j][4 * q + 0] = a0; acc[i][j][4 * q + 1] = a1; acc[i][j][4 * q + 2] = a2; acc[i][j][4 * q + 3] = a3;
+                }
+            }
+    };
+    // ReLU -> bf16 -> U, in place (callers put a barrier in front: every wave must be done reading U)
+    auto store_layer = [&](f32x16 (&acc)[CV_RT][CV_CT]) {
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bool live;
+                    uint2 *cell = cell_ptr(i, j, q, live);
+                    uint2 pk;
+                    pk.x = pack_bf16x2(fmaxf(acc[i][j][4 * q + 0], 0.f), fmaxf(acc[i][j][4 * q + 1], 0.f));
+                    pk.y = pack_bf16x2(fmaxf(acc[i][j][4 * q + 2], 0.f), fmaxf(acc[i][j][4 * q + 3], 0.f));
+                    if (live) *cell = pk;
+                }
+    };
+
+    if (planes != nullptr) {   // first layer: conv3x3(14 -> 128) + BN + ReLU, one k-step per tap
+        bf16x8 wf[9][CV_CT];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + khalf) * 128 + wc * 64 + j * 32 + l31) << 3));
+        f32x16 acc[CV_RT][CV_CT];
+        init_acc(acc, b0, false);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
+            bf16x8 af[CV_RT];
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) {
+                const int a = ((tapmask[i] >> t) & 1) ? T8_PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : T8_ZERO_OFF;
+                af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CV_CT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][j], af[i], acc[i][j], 0, 0, 0);
+        }
+        store_layer(acc);    // U is not read by the first conv: no barrier needed in front
+        __syncthreads();
+    }
+
+#define T8_SLAB(ASMSTR, NAB, NKEY)                                                                               \
+        asm volatile(ASMSTR                                                                                      \
+            : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),          \
+              [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),                                                        \
+              [f0a0] "+v"(f0.a[0]), [f0a1] "+v"(f0.a[1]), [f0a2] "+v"(f0.a[2]), [f0b0] "+v"(f0.b[0]), [f0b1] "+v"(f0.b[1]), \
+              [f1a0] "=&v"(f1.a[0]), [f1a1] "=&v"(f1.a[1]), [f1a2] "=&v"(f1.a[2]), [f1b0] "=&v"(f1.b[0]), [f1b1] "=&v"(f1.b[1]), \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [keep] "=&s"(keep)                                     \
+            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),          \
+              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
+              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
+              [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst)                                                \
+            : "memory")
+#define T8_SLAB_ARGS()                                                                                          \
+        const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);         \
+        const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                     \
+        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * TW_SLAB_BYTES;  \
+        const int ldst = T8_W_OFF + ((((unsigned)g + 3u) & 3u) << 14) + (wave_u << 10);
+
+    int g = 0;
+#pragma unroll 1
+    for (int layer = 0; layer < nlayers; ++layer) {
+        f32x16 acc[CV_RT][CV_CT];
+        if (!(layer & 1)) {   // first conv of a block: remember x, start from the bias
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { bool live; xreg[i][j][q] = *cell_ptr(i, j, q, live); }
+            init_acc(acc, bias + layer * 128, false);
+        } else {
+            init_acc(acc, bias + layer * 128, true);
+        }
+        int ab[CV_RT], key[CV_RT], nab[CV_RT], nkey[CV_RT], t0, t1, t2;
+        TwFrag f0, f1;
+        tap_addr(0, ab, key);
+        {
+            const int vb = vb0 + (((unsigned)g & 3u) << 14);
+            TW_LOADSET(0, 0, 512, f0, ab, key, vb);   // waited for by the first k-step itself
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            {
+                T8_SLAB_ARGS()
+                T8_SLAB(TW8_SLAB_ASM_H0, ab, key);
+                ++g;
+            }
+            {
+                tap_addr(tap + 1, nab, nkey);
+                T8_SLAB_ARGS()
+                T8_SLAB(TW8_SLAB_ASM_H1, nab, nkey);
+#pragma unroll
+                for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+                ++g;
+            }
+        }
+        // the last k-step prefetched garbage for a non-existent next slab; drain it, let the MFMAs retire, and make
+        // sure every wave is done reading U before anyone overwrites it in place
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        __syncthreads();
+        store_layer(acc);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (out) {
+        uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < nrows * 16; idx += T8_THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(r * CV_ROWB, c));
+        }
+    }
+    if (head_out) {
+        __syncthreads();
+        float *hw = reinterpret_cast<float *>(smem + T8_W_OFF);
+        for (int i = tid; i < 3 * 128; i += T8_THREADS) hw[i] = head_w[i];
+        __syncthreads();
+        for (int idx = tid; idx < nrows * 3; idx += T8_THREADS) {
+            const int r = idx / 3, c3 = idx - r * 3;
+            const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
+            const float *w = hw + c3 * 128;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int p = (it + tid) & 15;
+                const int c = p ^ key;
+                const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
+                const float *wc8 = w + c * 8;
+                acc += __uint_as_float(v.x << 16) * wc8[0] + __uint_as_float(v.x & 0xFFFF0000u) * wc8[1]
+                     + __uint_as_float(v.y << 16) * wc8[2] + __uint_as_float(v.y & 0xFFFF0000u) * wc8[3]
+                     + __uint_as_float(v.z << 16) * wc8[4] + __uint_as_float(v.z & 0xFFFF0000u) * wc8[5]
+                     + __uint_as_float(v.w << 16) * wc8[6] + __uint_as_float(v.w & 0xFFFF0000u) * wc8[7];
+            }
+            head_out[((size_t)pos0 * 90 + r) * 3 + c3] = fmaxf(acc + head_b[c3], 0.f);
+        }
+    }
+}
+#undef T8_SLAB
+#undef T8_SLAB_ARGS
+
 #undef TW_SLAB
 #undef TW_SLAB_ARGS
 #undef TW_LOADSET

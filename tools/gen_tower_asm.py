@@ -60,6 +60,46 @@ def slab(H):
     return L
 
 
+def kstep2(Y, X, CA, OB0, OB1, AB, KEY, VB, extras=None):
+    """8-wave variant: two fragment sets, each k-step first waits for its own set (the partner wave on the SIMD
+    covers the wait), then interleaves its 6 MFMAs with the 5 reads of the next k-step."""
+    ex = extras or [[], [], [], [], [], []]
+    L = ["s_waitcnt lgkmcnt(0)"]
+    L.append("v_xor_b32 %%[t0], %d, %%[%s0]" % (CA, KEY))
+    L.append(mfma(0, 0, Y)); L += ex[0]
+    L.append("v_xor_b32 %%[t1], %d, %%[%s1]" % (CA, KEY))
+    L.append("v_xor_b32 %%[t2], %d, %%[%s2]" % (CA, KEY))
+    L.append("v_lshl_add_u32 %%[t0], %%[t0], 4, %%[%s0]" % AB)
+    L.append("v_lshl_add_u32 %%[t1], %%[t1], 4, %%[%s1]" % AB)
+    L.append("v_lshl_add_u32 %%[t2], %%[t2], 4, %%[%s2]" % AB)
+    L.append(mfma(0, 1, Y)); L += ex[1]
+    L.append("ds_read_b128 %%[%sa0], %%[t0]" % X)
+    L.append("ds_read_b128 %%[%sa1], %%[t1]" % X)
+    L.append(mfma(1, 0, Y)); L += ex[2]
+    L.append("ds_read_b128 %%[%sa2], %%[t2]" % X)
+    L.append("ds_read_b128 %%[%sb0], %%[%s] offset:%d" % (X, VB, OB0))
+    L.append(mfma(1, 1, Y)); L += ex[3]
+    L.append("ds_read_b128 %%[%sb1], %%[%s] offset:%d" % (X, VB, OB1))
+    L.append(mfma(2, 0, Y)); L += ex[4]
+    L.append(mfma(2, 1, Y)); L += ex[5]
+    return L
+
+
+def slab8(H):
+    """k0: f0 -> loads f1 (k1) ; k1: f1 -> f0 (k2) ; mid ; k2: f0 -> f1 (k3) + 2 DMA pieces ; k3: f1 -> f0 (next slab k0)."""
+    nab, nkey = ("ab", "key") if H == 0 else ("nab", "nkey")
+    L = ["s_mov_b32 %[keep], m0"]
+    L += kstep2("f0", "f1", H * 8 + 2, 4096, 4608, "ab", "key", "vb")
+    L += kstep2("f1", "f0", H * 8 + 4, 8192, 8704, "ab", "key", "vb")
+    L += ["s_waitcnt vmcnt(2)", "s_barrier"]
+    dma = [["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"], [],
+           ["s_add_u32 m0, %[ldst], 0x2000", "s_nop 0", "global_load_lds_dwordx4 %[voff1], %[sbase]"], [], [], []]
+    L += kstep2("f0", "f1", H * 8 + 6, 12288, 12800, "ab", "key", "vb", dma)
+    L += kstep2("f1", "f0", (H ^ 1) * 8 + 0, 0, 512, nab, nkey, "vbn")
+    L += ["s_mov_b32 m0, %[keep]"]
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -73,6 +113,8 @@ def main():
     dst = os.path.join(os.path.dirname(here), "cchess_zero_amd", "csrc", "cz_tower_slab_asm.inc")
     txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
     txt += emit("TW_SLAB_ASM_H0", slab(0)) + "\n" + emit("TW_SLAB_ASM_H1", slab(1))
+    txt += "\n// 8-wave / 4-position variant (two fragment sets, 2 DMA pieces per wave)\n"
+    txt += emit("TW8_SLAB_ASM_H0", slab8(0)) + "\n" + emit("TW8_SLAB_ASM_H1", slab8(1))
     open(dst, "w").write(txt)
     print("wrote", dst, len(slab(0)), "instructions per slab")
 

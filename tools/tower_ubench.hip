@@ -10,6 +10,7 @@ int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8192;
     const int nblocks = argc > 2 ? atoi(argv[2]) : 7;
     const int iters = argc > 3 ? atoi(argv[3]) : 10;
+    const int variant = argc > 4 ? atoi(argv[4]) : 8;   // 4 = 2 positions / 4 waves, 8 = 4 positions / 8 waves
     const size_t n = (size_t)B * 90 * 128, nw = (size_t)2 * nblocks * 9 * 128 * 128;
     uint16_t *in, *out, *w; float *bias;
     CK(hipMalloc(&in, n * 2)); CK(hipMalloc(&out, n * 2)); CK(hipMalloc(&w, nw * 2)); CK(hipMalloc(&bias, 2 * nblocks * 128 * 4));
@@ -22,15 +23,18 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(w, h.data(), nw * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, 2 * nblocks * 128 * 4));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
-    const int grid = (B + TW_P - 1) / TW_P;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
+    const int grid = variant == 4 ? (B + TW_P - 1) / TW_P : (B + T8_P - 1) / T8_P;
+#define LAUNCH() do { if (variant == 4) hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); \
+                      else hipLaunchKernelGGL(k_tower8_c128, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); } while (0)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks);
+    for (int i = 0; i < 2; ++i) LAUNCH();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks);
+    for (int i = 0; i < iters; ++i) LAUNCH();
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * nblocks * 2.0 * B * 90 * 1152 * 128 / (us * 1e-6) / 1e12;
-    printf("tower P=%d threads=%d lds=%d B=%d blocks=%d : %9.1f us/launch (%7.1f us/layer) %7.1f TF/s\n", TW_P, TW_THREADS, TW_LDS_BYTES, B, nblocks, us, us / (2 * nblocks), tf);
+    printf("tower variant=%dw B=%d blocks=%d : %9.1f us/launch (%7.1f us/layer) %7.1f TF/s\n", variant, B, nblocks, us, us / (2 * nblocks), tf);
     return 0;
 }
