@@ -229,12 +229,14 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed
     # rocprofv3 --pmc measurement of the same launch shape is attached when the configuration matches.
+    tower_kernel = "k_tower_c128" if os.environ.get("CCHESS_TOWER_VARIANT", "") == "4w" else "k_tower8_c128"
     traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if tj["config"] == {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype} and args.backend in ("auto", "hip"):
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if (tj["config"] == {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype} and args.backend in ("auto", "hip")
+                and tj["kernel"] == tower_kernel):
             traffic = tj["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; algorithmic bytes %d)" % tj["algorithmic_bytes_per_launch"]
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; algorithmic bytes %d)" % tj["algorithmic_bytes_per_launch"]
     except Exception:
         pass
     st, nodes, sims, depth = eng.status()
@@ -250,7 +252,7 @@ def main():
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
         nl = 2 * args.blocks if net.backend == "hip" else 1   # fused tower: one launch = all 2*blocks conv layers
         conv_flops = 2.0 * G * 90 * 1152 * 128 * nl
-        kname = ("k_tower_c128 (first conv + whole residual tower + head 1x1 convs in one launch: %d conv3x3+BN(+residual)+ReLU layers counted, LDS-resident activations, bf16 MFMA, fp32 acc)" % nl
+        kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv3x3+BN(+residual)+ReLU layers counted, LDS-resident activations, bf16 MFMA, fp32 acc)" % nl
                  if net.backend == "hip" else "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)")
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/<tag>/) into the committed
+artefacts under profiles/: <round>_kernel_stats.csv, <round>_summary.md, <round>_bench_under_rocprof.json
+and pmc_traffic.json (the file bench.py attaches as roofline.traffic when its configuration matches).
+
+usage: tools/summarize_profile.py gpurun_out/prof r01b [kernel-substring]
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(d, pat):
+    hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    if not hits:
+        raise SystemExit("no %s under %s" % (pat, d))
+    return hits[0]
+
+
+def pmc_mean(path, counter, kernel_sub):
+    vals = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def main():
+    src, rnd = sys.argv[1], sys.argv[2]
+    ksub = sys.argv[3] if len(sys.argv) > 3 else "k_tower8_c128"
+    prof = os.path.join(ROOT, "profiles")
+    stats = find(os.path.join(src, "stats"), "*kernel_stats.csv")
+    shutil.copy(stats, os.path.join(prof, rnd + "_kernel_stats.csv"))
+    bline = None
+    for ln in open(os.path.join(src, "bench_under_rocprof.json")):
+        if ln.startswith("{"):
+            bline = json.loads(ln)
+    json.dump(bline, open(os.path.join(prof, rnd + "_bench_under_rocprof.json"), "w"), indent=1)
+    rows = list(csv.DictReader(open(stats)))
+    dom = [r for r in rows if ksub in r["Name"]][0]
+    md = ["# %s — rocprofv3 --kernel-trace --stats of the default bench" % rnd, "",
+          "Command on the MI355X box (tools/profile_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- "
+          "python bench.py --no-cpu-baseline --steps 100 --warmup 8`", "",
+          "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
+    for r in rows[:12]:
+        md.append("| `%s` | %s | %.1f | %s |" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    md += ["", "Dominant kernel `%s`: rocprof average %.1f us vs bench.py's live HIP-event average in the same run %.1f us "
+           "(roofline.achieved %.1f TFLOP/s, frac %.3f; whole-job %.0f sims/s under the profiler)."
+           % (ksub, float(dom["AverageNs"]) / 1e3, bline["roofline"]["us_per_launch"], bline["roofline"]["achieved"],
+              bline["roofline"]["frac"], bline["value"])]
+    fetch, nf = pmc_mean(find(os.path.join(src, "pmc_f"), "*counter_collection.csv"), "FETCH_SIZE", ksub)
+    write, nw = pmc_mean(find(os.path.join(src, "pmc_w"), "*counter_collection.csv"), "WRITE_SIZE", ksub)
+    cfg = bline["config"]
+    G, blocks = cfg["games_per_gpu"], cfg["res_block_nums"]
+    # algorithmic bytes of one launch: planes in (bf16 [G][90][16]) + all folded weights once
+    # (first conv 9*16*128, 2*blocks layers of 9*128*128, bf16) + biases (f32) + head conv output (f32 [G][90][3])
+    alg = G * 90 * 16 * 2 + (9 * 16 * 128 + 2 * blocks * 9 * 128 * 128) * 2 + (2 * blocks + 1) * 128 * 4 + G * 90 * 3 * 4
+    tj = {"kernel": ksub, "config": {"B": G, "res_block_nums": blocks, "dtype": bline["dtype"]},
+          "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
+                    "--steps 40 --warmup 4 --no-cpu-baseline` (tools/profile_round.sh); mean over %d/%d launches; counters are in KiB" % (nf, nw),
+          "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
+          "fetch_bytes_corrected_x2": fetch * 1024 * 2, "write_bytes": write * 1024,
+          "traffic_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+          "algorithmic_bytes_per_launch": alg,
+          "note": "gfx950 correction from MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads; uncalibrated for the "
+                  "LDS-DMA pattern, so the truth lies between x1 and x2). WRITE_SIZE equals the head conv outputs only: the trunk never "
+                  "leaves the CU. The read side is far above the algorithmic input because every workgroup streams the whole folded weight "
+                  "set (L2 / Infinity Cache hits for all but the first sweep)."}
+    json.dump(tj, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+    md += ["", "HBM PMC (separate passes): FETCH_SIZE %.0f KiB raw, WRITE_SIZE %.0f KiB per launch -> traffic %.3e B "
+           "(algorithmic %.3e B); see pmc_traffic.json." % (fetch, write, tj["traffic_bytes_per_launch"], alg)]
+    open(os.path.join(prof, rnd + "_summary.md"), "w").write("\n".join(md) + "\n")
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main()
