@@ -186,6 +186,22 @@ class PolicyValueNet:
         self.v1_b = m.value_fc1.bias.float()
         self.v2_w = m.value_fc2.weight.float().t().contiguous()
         self.v2_b = m.value_fc2.bias.float()
+        if self.backend.startswith("hip"):
+            # policy FC weight [2086,180] split into bf16 hi + lo and packed in MFMA B-fragment order
+            # [label/32][k/16][lane = (k%16)/8*32 + label%32][k%8] (cz_fc_heads_f32)
+            wpad = torch.zeros((66 * 32, 192), dtype=torch.float32, device=self.device)
+            wpad[:PROB_SIZE, :180] = m.policy_fc.weight.float()
+            hi = wpad.to(torch.bfloat16)
+            lo = (wpad - hi.float()).to(torch.bfloat16)
+
+            def frag(w):
+                return w.view(66, 32, 12, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+            self.hip_pfc_hi, self.hip_pfc_lo = frag(hi), frag(lo)
+            self.hip_pfc_b = m.policy_fc.bias.float().contiguous()
+            self.hip_v1_wt = m.value_fc1.weight.float().t().contiguous()      # [90,256]
+            self.hip_v1_b = m.value_fc1.bias.float().contiguous()
+            self.hip_v2_w = m.value_fc2.weight.float().reshape(-1).contiguous()  # [256]
+            self.hip_v2_b = m.value_fc2.bias.float().contiguous()
 
     def _hip_ctx(self):
         if self._ctx is None:
@@ -346,11 +362,26 @@ class PolicyValueNet:
         v = torch.tanh(torch.addmm(self.v2_b, v, self.v2_w))
         return logits, v
 
+    def _hip_fc_heads(self, z):
+        """z [B,90,3] f32 -> (logits [B,2086] f32, value [B,1] f32): policy FC on MFMA (split-bf16, fp32
+        accumulate) + value FCs on the fp32 VALU, cz_fc_heads_f32."""
+        import ctypes as C
+        from ._lib import check, lib
+        B = z.shape[0]
+        logits = torch.empty((B, PROB_SIZE), dtype=torch.float32, device=self.device)
+        value = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+        self._hip_ctx().bind_stream()
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        check(lib().cz_fc_heads_f32(self._hip_ctx().h, vp(z), vp(self.hip_pfc_hi), vp(self.hip_pfc_lo), vp(self.hip_pfc_b),
+                                    vp(self.hip_v1_wt), vp(self.hip_v1_b), vp(self.hip_v2_w), vp(self.hip_v2_b),
+                                    vp(logits), vp(value), B), "cz_fc_heads_f32")
+        return logits, value
+
     @torch.no_grad()
     def forward_device(self, planes):
         """Device planes [B,9,10,C] -> (logits [B,2086] f32, value [B,1] f32), all on the device."""
         if self.backend == "hip" and self.res_block_nums >= 1:
-            return self.fc_heads(self._hip_net_forward(planes))
+            return self._hip_fc_heads(self._hip_net_forward(planes))
         return self.heads(self.tower(planes))
 
     @torch.no_grad()

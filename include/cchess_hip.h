@@ -180,6 +180,18 @@ int cz_net_trunk_bf16(cz_ctx *, const void *planes16, const void *w0, const floa
                       const float *bias, void *trunk_out, const float *head_w, const float *head_b,
                       float *head_out, int B, int nblocks);
 
+/* The three fully connected layers behind the head convolutions (policy_value_network.py:56-74): policy FC
+ * 180 -> 2086 (raw logits) and value FC 90 -> 256, ReLU, FC 256 -> 1, tanh, from the head conv outputs
+ * z [B][90][3] f32 as cz_net_trunk_bf16 / cz_tower_heads_c128_bf16 leave them (flatten order (h,w,c)).
+ *   pfc_w_hi, pfc_w_lo : policy FC weight split into bf16 hi + lo parts (w ~= hi + lo), each packed in MFMA
+ *                        fragment order [66 = label/32][12 = k/16][64 lanes][8] bf16 with
+ *                        element = W[label = tile*32 + (lane & 31)][k = kblock*16 + (lane >> 5)*8 + j], zero padded
+ *   pfc_b [2086] f32;  v1_wt [90][256] f32 (value FC1 weight, input-major);  v1_b [256];  v2_w [256];  v2_b [1]
+ *   logits [B][2086] f32, value [B] f32 (either may be NULL to skip that head). */
+int cz_fc_heads_f32(cz_ctx *, const float *z, const void *pfc_w_hi, const void *pfc_w_lo, const float *pfc_b,
+                    const float *v1_wt, const float *v1_b, const float *v2_w, const float *v2_b,
+                    float *logits, float *value, int B);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,3 +185,36 @@ def test_fused_net_kernel_paths_agree(n):
     l3, v3 = net.heads(net.tower(x))                     # unfused route
     assert float((l1 - l3).abs().max()) < 2e-2 * float(l3.abs().max()) + 1e-3
     assert float((torch.softmax(l1, 1) - torch.softmax(l3, 1)).abs().max()) < 1e-3 and float((v1 - v3).abs().max()) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 31, 128, 129, 700])
+def test_hip_fc_heads_vs_fp64(B):
+    """cz_fc_heads_f32 (policy FC on split-bf16 MFMA, value FCs on the fp32 VALU) vs the same three layers in
+    float64 on identical inputs (policy_value_network.py:56-74).  Tolerance: policy logits 2e-4 relative to the
+    largest logit (hi*hi + hi*lo + lo*hi keeps ~16 mantissa bits per operand), value 1e-5 absolute."""
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(1, "cuda:0", torch.bfloat16, seed=11, backend="hip")
+    gen = torch.Generator().manual_seed(B)
+    with torch.no_grad():   # non-zero biases so every term of the layers is exercised
+        net.module.policy_fc.bias.copy_((torch.randn(2086, generator=gen) * 0.3).cuda())
+        net.module.value_fc1.bias.copy_((torch.randn(256, generator=gen) * 0.3).cuda())
+        net.module.value_fc2.bias.copy_((torch.randn(1, generator=gen) * 0.1).cuda())
+    net.refresh()
+    z = torch.relu(torch.randn((B, 90, 3), generator=gen) * 1.5).cuda()
+    logits, value = net._hip_fc_heads(z)
+    torch.cuda.synchronize()
+    m, zd = net.module, z.double()
+    ref_l = zd[:, :, :2].reshape(B, 180) @ m.policy_fc.weight.double().t() + m.policy_fc.bias.double()
+    h = torch.relu(zd[:, :, 2] @ m.value_fc1.weight.double().t() + m.value_fc1.bias.double())
+    ref_v = torch.tanh(h @ m.value_fc2.weight.double().t() + m.value_fc2.bias.double())
+    assert logits.shape == (B, 2086) and value.shape == (B, 1)
+    ref_l, ref_v = ref_l.detach(), ref_v.detach()
+    dl = float((logits.double() - ref_l).abs().max())
+    dv = float((value.double() - ref_v).abs().max())
+    print("fc heads B=%d: max|dlogit| %.3g (max|logit| %.3g), max|dv| %.3g" % (B, dl, float(ref_l.abs().max()), dv))
+    assert dl < 2e-4 * float(ref_l.abs().max())
+    assert dv < 1e-5
+    # and against the torch fp32 route the other backends use
+    l32, v32 = net.fc_heads(z)
+    assert float((logits - l32).abs().max()) < 5e-4 * float(l32.abs().max()) and float((value - v32).abs().max()) < 1e-5
