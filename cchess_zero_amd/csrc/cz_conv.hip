@@ -19,6 +19,8 @@ extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, 
     return CZ_OK;
 }
 
+static constexpr int kDefaultVariant = 1;
+
 static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
                         const float *head_b, float *head_out, int B, int nblocks, const void *planes = nullptr,
                         const void *w0 = nullptr, const float *b0 = nullptr) {
@@ -27,18 +29,31 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
     if (!c->tower_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerp_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
         c->tower_attr_set = true;
     }
-    // CCHESS_TOWER_VARIANT=4w selects the 2-position / 4-wave kernel, anything else the 4-position / 8-wave one
-    static const bool use4w = [] { const char *e = getenv("CCHESS_TOWER_VARIANT"); return e && e[0] == '4'; }();
-    if (use4w) {
+    // CCHESS_TOWER_VARIANT: "4w" = 2 positions / 4 waves (k_tower_c128), "8w" = 4 positions / 8 waves
+    // (k_tower8_c128), "pw" = 4 positions, one per wave (k_towerp_c128); default: see kDefaultVariant
+    static const int variant = [] {
+        const char *e = getenv("CCHESS_TOWER_VARIANT");
+        if (e && e[0] == '4') return 0;
+        if (e && e[0] == '8') return 1;
+        if (e && e[0] == 'p') return 2;
+        return kDefaultVariant;
+    }();
+    if (variant == 0) {
         const int grid = (B + TW_P - 1) / TW_P;
         hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
-    } else {
+    } else if (variant == 1) {
         const int grid = (B + T8_P - 1) / T8_P;
         hipLaunchKernelGGL(k_tower8_c128, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
+                           (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
+                           (const uint16_t *)w0, b0, B, 2 * nblocks);
+    } else {
+        const int grid = (B + TP_P - 1) / TP_P;
+        hipLaunchKernelGGL(k_towerp_c128, dim3(grid), dim3(TP_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
     }

@@ -259,6 +259,7 @@ constexpr int TW_SLAB_U4 = TW_SLAB_BYTES / 16;     // 1024 uint4 per slab, 4 per
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (RNE)
     f32x2 v; v[0] = lo; v[1] = hi;
     bf16x2 b = __builtin_convertvector(v, bf16x2);
@@ -700,10 +701,15 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
                 for (int q = 0; q < 4; ++q) {
                     bool live;
                     uint2 *cell = cell_ptr(i, j, q, live);
-                    uint2 pk;
-                    pk.x = pack_bf16x2(fmaxf(acc[i][j][4 * q + 0], 0.f), fmaxf(acc[i][j][4 * q + 1], 0.f));
-                    pk.y = pack_bf16x2(fmaxf(acc[i][j][4 * q + 2], 0.f), fmaxf(acc[i][j][4 * q + 3], 0.f));
-                    if (live) *cell = pk;
+                    // ReLU after the rounding, as a packed signed-16-bit max with 0: a bf16 is negative exactly when
+                    // its bit pattern is a negative int16 and RNE never changes the sign, so the result is the same
+                    // as relu-then-round at a quarter of the VALU work (no v_max_f32 + canonicalize per element)
+                    const s16x2 z = {0, 0};
+                    const s16x2 rl = __builtin_elementwise_max(
+                        __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]}, bf16x2)), z);
+                    const s16x2 rh = __builtin_elementwise_max(
+                        __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}, bf16x2)), z);
+                    if (live) *cell = make_uint2(__builtin_bit_cast(uint32_t, rl), __builtin_bit_cast(uint32_t, rh));
                 }
     };
 
@@ -833,6 +839,315 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
 }
 #undef T8_SLAB
 #undef T8_SLAB_ARGS
+
+// =================================================================================================
+// k_towerp_c128: the one-launch net trunk with ONE POSITION PER WAVE (four waves, four positions per workgroup).
+//
+// k_tower8_c128 is co-limited by LDS bandwidth: with 3 cell tiles x 2 channel tiles per wave every 6 MFMAs need
+// 5 ds_read_b128, 40 KB per k-step and CU against 256 B/clk, which is as long as the MFMAs take.  Here a wave
+// owns ALL 128 output channels of one position (3 cell tiles of 32, 90 live cells): 12 MFMAs per 7 fragment
+// reads, 28 KB per k-step and CU.  The 12 accumulators (192 registers) live in AGPRs, the block input x (96
+// packed registers) and two fragment sets in VGPRs; one wave per SIMD, latency hidden by software pipelining
+// (the next k-step's fragments are requested one per MFMA gap of the current one, see tools/gen_tower_asm.py).
+// A wave only ever reads and writes the LDS rows of its own position, so a layer is written back in place with
+// no workgroup barrier at all; the only barrier left is the one per slab that publishes the weight ring.
+// =================================================================================================
+constexpr int TP_P = 4;
+constexpr int TP_THREADS = 256;
+constexpr int TP_CT = 4;                            // channel tiles per wave: all of them
+
+#define TP_LOADSET(CA, OB, XA, XB, AB, KEY, VB)                                                      \
+    asm volatile(                                                                                    \
+        "v_xor_b32 %[t0], " #CA ", %[k0]\n\t"                                                        \
+        "v_xor_b32 %[t1], " #CA ", %[k1]\n\t"                                                        \
+        "v_xor_b32 %[t2], " #CA ", %[k2]\n\t"                                                        \
+        "v_lshl_add_u32 %[t0], %[t0], 4, %[b0]\n\t"                                                  \
+        "v_lshl_add_u32 %[t1], %[t1], 4, %[b1]\n\t"                                                  \
+        "v_lshl_add_u32 %[t2], %[t2], 4, %[b2]\n\t"                                                  \
+        "ds_read_b128 %[xa0], %[t0]\n\t"                                                             \
+        "ds_read_b128 %[xa1], %[t1]\n\t"                                                             \
+        "ds_read_b128 %[xa2], %[t2]\n\t"                                                             \
+        "ds_read_b128 %[xb0], %[vb] offset:" #OB "\n\t"                                              \
+        "ds_read_b128 %[xb1], %[vb] offset:" #OB "+512\n\t"                                          \
+        "ds_read_b128 %[xb2], %[vb] offset:" #OB "+1024\n\t"                                         \
+        "ds_read_b128 %[xb3], %[vb] offset:" #OB "+1536\n\t"                                         \
+        : [xa0] "=&v"(XA[0]), [xa1] "=&v"(XA[1]), [xa2] "=&v"(XA[2]), [xb0] "=&v"(XB[0]),               \
+          [xb1] "=&v"(XB[1]), [xb2] "=&v"(XB[2]), [xb3] "=&v"(XB[3]), [t0] "=&v"(t0), [t1] "=&v"(t1),   \
+          [t2] "=&v"(t2)                                                                              \
+        : [k0] "v"(KEY[0]), [k1] "v"(KEY[1]), [k2] "v"(KEY[2]), [b0] "v"(AB[0]), [b1] "v"(AB[1]),      \
+          [b2] "v"(AB[2]), [vb] "v"(VB)                                                               \
+        : "memory")
+
+__global__ __launch_bounds__(TP_THREADS, 1) void k_towerp_c128(const uint16_t *__restrict__ in,
+                                                               const uint16_t *__restrict__ wpk,
+                                                               const float *__restrict__ bias,
+                                                               uint16_t *__restrict__ out,
+                                                               const float *__restrict__ head_w,
+                                                               const float *__restrict__ head_b,
+                                                               float *__restrict__ head_out,
+                                                               const uint16_t *__restrict__ planes,
+                                                               const uint16_t *__restrict__ w0,
+                                                               const float *__restrict__ b0,
+                                                               int B, int nlayers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int pos0 = blockIdx.x * TP_P;
+    const int npos = (B - pos0) < TP_P ? (B - pos0) : TP_P;
+    const int nrows = npos * 90;
+    const int nslabs = nlayers * 18;
+    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
+    const unsigned voff0 = (unsigned)tid << 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool wave_live = wave_u < npos;   // a dead wave (batch tail) reads the zero row and stores nothing
+
+    auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * TW_SLAB_BYTES;
+        unsigned char *dst = smem + T8_W_OFF + ((unsigned)slab & 3u) * TW_SLAB_BYTES + (wave_u << 10);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + q * 4096 + voff0),
+                                             (__attribute__((address_space(3))) void *)(dst + q * 4096), 16, 0, 0);
+    };
+    for (int q = 0; q < 3; ++q) dma_slab(q < nslabs ? q : nslabs - 1);
+    if (planes == nullptr) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < T8_ROWS * 16; idx += TP_THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < nrows) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
+        }
+    } else {
+        const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
+        for (int idx = tid; idx < T8_ROWS * 2; idx += TP_THREADS) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < nrows * 2) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + T8_PLANES_OFF + (idx << 4)) = v;
+        }
+    }
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + T8_ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // this lane's three cells (tile i: cell 32*i + l31 of position `wave`; cells >= 90 are padding)
+    int rowb[CV_RT], tapmask[CV_RT];
+#pragma unroll
+    for (int i = 0; i < CV_RT; ++i) {
+        const int pix = 32 * i + l31, h = pix / 10, w = pix - h * 10;
+        rowb[i] = (wave * 90 + (pix < 90 ? pix : 0)) * CV_ROWB;
+        int m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
+            if (wave_live && pix < 90 && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+        }
+        tapmask[i] = m;
+    }
+    auto tap_addr = [&](int tap, int (&ab)[CV_RT], int (&key)[CV_RT]) {
+        const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : T8_ZERO_OFF;
+            ab[i] = a;
+            key[i] = ((a >> 8) & 15) ^ khalf;
+        }
+    };
+    const int vb0 = T8_W_OFF + khalf * 2048 + (l31 << 4);
+    int keep;
+
+    // 48 swizzled addresses per lane: recomputed from an opaque copy of the row offset wherever they are needed
+    // (hoisted out of the layer loop they would only be spilled)
+    int rb[CV_RT];
+    auto refresh_rb = [&]() {
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) { rb[i] = rowb[i]; asm volatile("" : "+v"(rb[i])); }
+    };
+    auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
+        live = wave_live && (32 * i + l31) < 90;
+        const int n0 = j * 32 + 8 * q + 4 * khalf;
+        return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
+    };
+    uint2 xreg[CV_RT][TP_CT][4];   // block input x at this lane's accumulator positions (packed bf16)
+    // Layer epilogue, one accumulator tile at a time out of the AGPRs: + bias (+ x) in packed fp32, -> bf16
+    // (v_cvt_pk_bf16_f32, RNE), ReLU as a packed signed-16-bit max with 0 (a bf16 is negative exactly when its bit
+    // pattern is a negative int16; rounding never changes the sign, so relu(round(v)) == round(relu(v))), then
+    // 8 bytes per lane into this wave's own rows of U, in place.
+    auto finish_layer = [&](f32x16 (&acc)[CV_RT][TP_CT], const float *bl, bool add_x) {
+#pragma unroll
+        for (int j = 0; j < TP_CT; ++j) {
+            f32x2 bq[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(bl + j * 32 + 8 * q + 4 * khalf);
+                bq[q][0] = f32x2{b4.x, b4.y};
+                bq[q][1] = f32x2{b4.z, b4.w};
+            }
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // explicit, ordered AGPR reads: left to the scheduler all 192 are hoisted to the top of the
+                    // epilogue and the block input x gets spilled to make room
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a[e]) : "a"(acc[i][j][4 * q + e]));
+                    f32x2 lo = f32x2{a[0], a[1]} + bq[q][0];
+                    f32x2 hi = f32x2{a[2], a[3]} + bq[q][1];
+                    if (add_x) {
+                        const uint2 x = xreg[i][j][q];
+                        lo += f32x2{__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xFFFF0000u)};
+                        hi += f32x2{__uint_as_float(x.y << 16), __uint_as_float(x.y & 0xFFFF0000u)};
+                    }
+                    const s16x2 z = {0, 0};
+                    const s16x2 rl = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(lo, bf16x2)), z);
+                    const s16x2 rh = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(hi, bf16x2)), z);
+                    bool live;
+                    uint2 *cell = cell_ptr(i, j, q, live);
+                    if (live) *cell = make_uint2(__builtin_bit_cast(uint32_t, rl), __builtin_bit_cast(uint32_t, rh));
+                }
+            }
+        }
+    };
+
+    if (planes != nullptr) {   // first layer: conv3x3(14 -> 128) + BN + ReLU, one k-step per tap
+        f32x16 acc[CV_RT][TP_CT];
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+            for (int j = 0; j < TP_CT; ++j) acc[i][j] = f32x16{};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
+            bf16x8 wf[TP_CT], af[CV_RT];
+#pragma unroll
+            for (int j = 0; j < TP_CT; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + khalf) * 128 + j * 32 + l31) << 3));
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) {
+                const int a = ((tapmask[i] >> t) & 1) ? T8_PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : T8_ZERO_OFF;
+                af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < TP_CT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        refresh_rb();
+        finish_layer(acc, b0, false);
+        __syncthreads();       // ring buffer 3 (the planes) is about to be overwritten by the DMA of slab 3
+    }
+
+#define TP_SLAB(ASMSTR, NAB, NKEY, AC)                                                                           \
+        asm volatile(ASMSTR                                                                                      \
+            : [p00] AC(acc[0][0]), [p01] AC(acc[0][1]), [p02] AC(acc[0][2]), [p03] AC(acc[0][3]),                  \
+              [p10] AC(acc[1][0]), [p11] AC(acc[1][1]), [p12] AC(acc[1][2]), [p13] AC(acc[1][3]),                  \
+              [p20] AC(acc[2][0]), [p21] AC(acc[2][1]), [p22] AC(acc[2][2]), [p23] AC(acc[2][3]),                  \
+              [f0a0] "+v"(fa0[0]), [f0a1] "+v"(fa0[1]), [f0a2] "+v"(fa0[2]), [f0b0] "+v"(fb0[0]),                  \
+              [f0b1] "+v"(fb0[1]), [f0b2] "+v"(fb0[2]), [f0b3] "+v"(fb0[3]),                                       \
+              [f1a0] "=&v"(fa1[0]), [f1a1] "=&v"(fa1[1]), [f1a2] "=&v"(fa1[2]), [f1b0] "=&v"(fb1[0]),              \
+              [f1b1] "=&v"(fb1[1]), [f1b2] "=&v"(fb1[2]), [f1b3] "=&v"(fb1[3]),                                    \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [keep] "=&s"(keep)                                   \
+            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),        \
+              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]), \
+              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),        \
+              [sbase] "s"(sbase), [sbase1] "s"(sbase + 4096), [sbase2] "s"(sbase + 8192),                          \
+              [sbase3] "s"(sbase + 12288), [ldst] "s"(ldst)                                                        \
+            : "memory", "scc")
+#define TP_ACC_RW "+a"
+#define TP_ACC_W "=&a"   /* first slab of a layer: the accumulators start from the MFMA's inline 0 */
+#define TP_SLAB_ARGS()                                                                                          \
+        const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);         \
+        const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                     \
+        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * TW_SLAB_BYTES;  \
+        const int ldst = T8_W_OFF + ((((unsigned)g + 3u) & 3u) << 14) + (wave_u << 10);
+
+    int g = 0;
+#pragma unroll 1
+    for (int layer = 0; layer < nlayers; ++layer) {
+        f32x16 acc[CV_RT][TP_CT];
+        if (!(layer & 1)) {   // first conv of a block: remember x for the residual add of the second
+            refresh_rb();
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < TP_CT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { bool live; xreg[i][j][q] = *cell_ptr(i, j, q, live); }
+        }
+        int ab[CV_RT], key[CV_RT], nab[CV_RT], nkey[CV_RT], t0, t1, t2;
+        bf16x8 fa0[CV_RT], fb0[TP_CT], fa1[CV_RT], fb1[TP_CT];   // two fragment sets (cells a, weights b)
+        tap_addr(0, ab, key);
+        {
+            const int vb = vb0 + (((unsigned)g & 3u) << 14);
+            TP_LOADSET(0, 0, fa0, fb0, ab, key, vb);   // waited for by the first k-step itself
+        }
+        {
+            TP_SLAB_ARGS()
+            TP_SLAB(TWP_SLAB_ASM_FIRST, ab, key, TP_ACC_W);
+            ++g;
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            {
+                tap_addr(tap + 1, nab, nkey);
+                TP_SLAB_ARGS()
+                TP_SLAB(TWP_SLAB_ASM_H1, nab, nkey, TP_ACC_RW);
+#pragma unroll
+                for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+                ++g;
+            }
+            if (tap < 8) {
+                TP_SLAB_ARGS()
+                TP_SLAB(TWP_SLAB_ASM_H0, ab, key, TP_ACC_RW);
+                ++g;
+            }
+        }
+        // drain the garbage prefetch of the non-existent next slab and let the last MFMAs retire; the rows this
+        // wave overwrites are read by no other wave, so no barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        refresh_rb();
+        finish_layer(acc, bias + layer * 128, (layer & 1) != 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (out) {
+        uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < nrows * 16; idx += TP_THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(r * CV_ROWB, c));
+        }
+    }
+    if (head_out) {
+        float *hw = reinterpret_cast<float *>(smem + T8_W_OFF);
+        for (int i = tid; i < 3 * 128; i += TP_THREADS) hw[i] = head_w[i];
+        __syncthreads();
+        for (int idx = tid; idx < nrows * 3; idx += TP_THREADS) {
+            const int r = idx / 3, c3 = idx - r * 3;
+            const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
+            const float *w = hw + c3 * 128;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int p = (it + tid) & 15;
+                const int c = p ^ key;
+                const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
+                const float *wc8 = w + c * 8;
+                acc += __uint_as_float(v.x << 16) * wc8[0] + __uint_as_float(v.x & 0xFFFF0000u) * wc8[1]
+                     + __uint_as_float(v.y << 16) * wc8[2] + __uint_as_float(v.y & 0xFFFF0000u) * wc8[3]
+                     + __uint_as_float(v.z << 16) * wc8[4] + __uint_as_float(v.z & 0xFFFF0000u) * wc8[5]
+                     + __uint_as_float(v.w << 16) * wc8[6] + __uint_as_float(v.w & 0xFFFF0000u) * wc8[7];
+            }
+            head_out[((size_t)pos0 * 90 + r) * 3 + c3] = fmaxf(acc + head_b[c3], 0.f);
+        }
+    }
+}
+#undef TP_SLAB
+#undef TP_SLAB_ARGS
+#undef TP_LOADSET
+#undef TP_ACC_RW
+#undef TP_ACC_W
 
 #undef TW_SLAB
 #undef TW_SLAB_ARGS

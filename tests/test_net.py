@@ -1,6 +1,8 @@
 """Net parity.  CPU: the torch module graph == the NumPy restatement of the TF graph (fp32).
 GPU: the inference engine (BN folded, channels_last, MFMA convs) within 1e-3 of the fp32
 restatement in fp32 mode; bf16 mode checked on softmax probabilities and value."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -218,3 +220,23 @@ def test_hip_fc_heads_vs_fp64(B):
     # and against the torch fp32 route the other backends use
     l32, v32 = net.fc_heads(z)
     assert float((logits - l32).abs().max()) < 5e-4 * float(l32.abs().max()) and float((value - v32).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_tower_variants_agree(tmp_path):
+    """The three fused-tower kernels (CCHESS_TOWER_VARIANT = 4w | 8w | pw) on identical inputs: 4w and 8w
+    accumulate in the same order and must agree bit for bit; pw adds the bias after the MFMA chain instead of
+    starting from it, so it is held to bf16 noise (2e-2 of the largest activation after 14 layers)."""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variant_helper.py")
+    outs = {}
+    for v in ("4w", "8w", "pw"):
+        f = str(tmp_path / ("z_%s.pt" % v))
+        env = dict(os.environ, CCHESS_TOWER_VARIANT=v)
+        subprocess.run([sys.executable, helper, f], check=True, env=env, timeout=300, stdin=subprocess.DEVNULL)
+        outs[v] = torch.load(f)
+    for k in outs["8w"]:
+        assert torch.equal(outs["4w"][k], outs["8w"][k]), k
+        d = float((outs["pw"][k] - outs["8w"][k]).abs().max())
+        assert d <= 2e-2 * float(outs["8w"][k].abs().max()) + 1e-6, (k, d)

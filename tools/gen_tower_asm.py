@@ -100,6 +100,62 @@ def slab8(H):
     return L
 
 
+ACCP = [["p%d%d" % (i, j) for j in range(4)] for i in range(3)]
+
+
+def mfmaP(i, j, Y):
+    return "v_mfma_f32_32x32x16_bf16 %%[%s], %%[%sb%d], %%[%sa%d], %%[%s]" % (ACCP[i][j], Y, j, Y, i, ACCP[i][j])
+
+
+def kstepP(Y, X, CA, OB, AB, KEY, VB, extras=None, exp=0, zero_c=False):
+    """Position-per-wave variant (one wave per SIMD, 3 cell tiles x 4 channel tiles = 12 MFMAs per k-step against
+    7 fragment reads).  Two complete fragment sets: the k-step waits for its own set (requested during the previous
+    k-step), then requests the other set for the next k-step, one ds_read_b128 per MFMA gap (a gap hides about five
+    single-issue instructions; clustering the reads, or single-buffering the weight fragments behind counted
+    waits, measured 4-7 % slower).  extras (LDS-DMA pieces, vmcnt-counted) go behind MFMAs 8..11."""
+    ex = extras or []
+    order = [(i, j) for j in range(4) for i in range(3)]
+    L = [] if exp & 4 else ["s_waitcnt lgkmcnt(0)"]
+    reads = ["ds_read_b128 %%[%sa%d], %%[t%d]" % (X, n, n) for n in range(3)]
+    reads += ["ds_read_b128 %%[%sb%d], %%[%s] offset:%d" % (X, j, VB, OB + 512 * j) for j in range(4)]
+    if exp & 8:
+        reads = []
+    for n in range(12):
+        L.append(mfmaP(*order[n], Y))
+        if n == 0 and not exp & 16:
+            for m in range(3):
+                L.append("v_xor_b32 %%[t%d], %d, %%[%s%d]" % (m, CA, KEY, m))
+            for m in range(3):
+                L.append("v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (m, m, AB, m))
+        if 1 <= n <= len(reads):
+            L.append(reads[n - 1])
+        if 8 <= n < 8 + len(ex):
+            L += ex[n - 8]
+    if zero_c:   # first k-step of a layer: the accumulators start from an inline 0 instead of their old contents
+        L = [l[:l.rindex(",")] + ", 0" if l.startswith("v_mfma") else l for l in L]
+    return L
+
+
+def slabP(H, exp=0, first=False):
+    """k0: f0 -> loads f1 (k1) ; k1: f1 -> f0 (k2) ; vmcnt(4) + barrier ; k2: f0 -> f1 (k3) + 4 DMA pieces ;
+    k3: f1 -> f0 (k0 of the next slab).  The DMA pieces share one lane-offset register; the 4 KB steps are four
+    scalar bases (the 13-bit instruction offset cannot hold them)."""
+    nab, nkey = ("ab", "key") if H == 0 else ("nab", "nkey")
+    L = ["s_mov_b32 %[keep], m0"]
+    L += kstepP("f0", "f1", H * 8 + 2, 4096, "ab", "key", "vb", exp=exp, zero_c=first)
+    L += kstepP("f1", "f0", H * 8 + 4, 8192, "ab", "key", "vb", exp=exp)
+    if not exp & 1:
+        L += ["s_waitcnt vmcnt(4)", "s_barrier"]
+    dma = [["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]]
+    for q in (1, 2, 3):
+        dma.append(["s_add_u32 m0, %%[ldst], 0x%x" % (q * 0x1000), "s_nop 0",
+                    "global_load_lds_dwordx4 %%[voff0], %%[sbase%d]" % q])
+    L += kstepP("f0", "f1", H * 8 + 6, 12288, "ab", "key", "vb", None if exp & 2 else dma, exp=exp)
+    L += kstepP("f1", "f0", (H ^ 1) * 8 + 0, 0, nab, nkey, "vbn", exp=exp)
+    L += ["s_mov_b32 m0, %[keep]"]
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -115,6 +171,14 @@ def main():
     txt += emit("TW_SLAB_ASM_H0", slab(0)) + "\n" + emit("TW_SLAB_ASM_H1", slab(1))
     txt += "\n// 8-wave / 4-position variant (two fragment sets, 2 DMA pieces per wave)\n"
     txt += emit("TW8_SLAB_ASM_H0", slab8(0)) + "\n" + emit("TW8_SLAB_ASM_H1", slab8(1))
+    txt += "\n// position-per-wave variant (4 waves, 3 cell tiles x 4 channel tiles each, two fragment sets)\n"
+    txt += emit("TWP_SLAB_ASM_H0", slabP(0)) + "\n" + emit("TWP_SLAB_ASM_H1", slabP(1))
+    txt += "\n" + emit("TWP_SLAB_ASM_FIRST", slabP(0, first=True))
+    if os.environ.get("CZ_TP_EXP"):   # timing experiments only (wrong results): 1 = no barrier, 2 = no DMA, 4 = no LDS waits, 8 = no fragment reads, 16 = no address math
+        e = int(os.environ["CZ_TP_EXP"])
+        txt = txt.replace("#define TWP_SLAB_ASM_H", "#define TWP_REAL_SLAB_ASM_H")
+        txt += emit("TWP_SLAB_ASM_H0", slabP(0, e)) + "\n" + emit("TWP_SLAB_ASM_H1", slabP(1, e))
+        txt += "\n" + emit("TWP_SLAB_ASM_FIRST", slabP(0, e, first=True))
     open(dst, "w").write(txt)
     print("wrote", dst, len(slab(0)), "instructions per slab")
 
