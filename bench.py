@@ -156,8 +156,8 @@ def main():
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
     # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
-    fused = (args.backend in ("auto", "hip")) and args.dtype == "bf16"
-    eng = SearchEngine(G, cap, local_rank, plane_dtype=torch.bfloat16 if fused else torch.float32, channels=16 if fused else 14, ctx=ctx)
+    fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16")
+    eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx)
     net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
     eng.reset(boards, side, rr)
@@ -252,7 +252,7 @@ def main():
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
         nl = 2 * args.blocks if net.backend == "hip" else 1   # fused tower: one launch = all 2*blocks conv layers
         conv_flops = 2.0 * G * 90 * 1152 * 128 * nl
-        kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv3x3+BN(+residual)+ReLU layers counted, LDS-resident activations, bf16 MFMA, fp32 acc)" % nl
+        kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv3x3+BN(+residual)+ReLU layers counted, LDS-resident activations, %s MFMA, fp32 acc)" % (nl, args.dtype)
                  if net.backend == "hip" else "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)")
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -264,12 +264,20 @@ def main():
         roof = {"bound": "mfma", "kernel": "net forward via torch/MIOpen (conv tower + heads), all launches of one step",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                 "ms_per_launch_group": net_ms, "flops_per_step": flops}
+    if (G, playout, args.blocks) == (8192, 1600, 7):
+        cfg_name = "BASELINE.json configs[2]" + ("; per-GPU share of configs[3]" if world > 1 else "")
+    elif (G, playout, args.blocks, args.dtype) == (8192, 1600, 19, "fp16"):
+        cfg_name = "per-GPU share of BASELINE.json configs[4]"
+    elif (G, playout, args.blocks) == (4096, 400, 7):
+        cfg_name = "BASELINE.json configs[1]"
+    else:
+        cfg_name = "custom configuration"
     out = {
         "metric": "MCTS simulations/sec (whole node), playout=%d, %d-block net" % (playout, args.blocks),
         "value": total_sims / dt, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (BASELINE.json configs[2])" % (G, playout, args.blocks, args.dtype),
+        "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)" % (G, playout, args.blocks, args.dtype, cfg_name),
                    "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "res_block_nums": args.blocks, "search_threads": 1,
                    "positions": "seeded random playouts from the start position, ply~U[0,80]",
                    "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),

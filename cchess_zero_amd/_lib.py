@@ -14,7 +14,7 @@ NLABELS = 2086
 MAXMOVES = 128
 NSQ = 90
 MASK_WORDS = 66
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 _u8p, _u16p, _i32p, _f32p, _vp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
 
@@ -49,6 +49,7 @@ _SIGS = {
     "cz_conv3x3_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_tower_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_net_trunk_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
+    "cz_net_trunk_f16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_fc_heads_f32": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "cz_tower_heads_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
 }

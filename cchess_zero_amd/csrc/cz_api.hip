@@ -198,7 +198,7 @@ int cz_encode_planes(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int 
     CZ_REQUIRE(c && G >= 0, "cz_encode_planes: null ctx / negative G");
     if (G == 0) return CZ_OK;
     CZ_REQUIRE(boards && side && planes, "cz_encode_planes: null argument");
-    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_encode_planes: dtype must be CZ_F32 or CZ_BF16");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16 || dtype == CZ_F16, "cz_encode_planes: dtype must be CZ_F32, CZ_BF16 or CZ_F16");
     CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_encode_planes: 14 <= channels <= 64");
     return czk_encode_planes(c, boards, side, G, planes, dtype, channels, quirk);
 }
@@ -226,7 +226,7 @@ int cz_search_set_width(cz_ctx *c, int width) {
 int cz_search_select_k(cz_ctx *c, int mode, int k, const uint8_t *active, void *planes, int dtype, int channels, uint8_t *needs_eval) {
     CZ_REQUIRE(c && c->G > 0, "cz_search_select_k: call cz_search_reset first");
     CZ_REQUIRE(mode == 0 || mode == 1, "cz_search_select_k: mode must be 0 or 1");
-    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_search_select_k: dtype must be CZ_F32 or CZ_BF16");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16 || dtype == CZ_F16, "cz_search_select_k: dtype must be CZ_F32, CZ_BF16 or CZ_F16");
     CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_search_select_k: 14 <= channels <= 64");
     if (k < 1 || k > c->width) { cz_set_error("cz_search_select_k: k=%d outside 1..width=%d (cz_search_set_width)", k, c->width); return CZ_EINVAL; }
     return czk_search_select_k(c, mode, k, active, planes, dtype, channels, needs_eval);
@@ -247,7 +247,7 @@ int cz_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const
 int cz_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int channels, uint8_t *needs_eval) {
     CZ_REQUIRE(c && c->G > 0, "cz_search_select: call cz_search_reset first");
     CZ_REQUIRE(mode == 0 || mode == 1, "cz_search_select: mode must be 0 or 1");
-    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_search_select: dtype must be CZ_F32 or CZ_BF16");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16 || dtype == CZ_F16, "cz_search_select: dtype must be CZ_F32, CZ_BF16 or CZ_F16");
     CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_search_select: 14 <= channels <= 64");
     return czk_search_select(c, mode, active, planes, dtype, channels, needs_eval);
 }

@@ -23,12 +23,13 @@ static constexpr int kDefaultVariant = 1;
 
 static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
                         const float *head_b, float *head_out, int B, int nblocks, const void *planes = nullptr,
-                        const void *w0 = nullptr, const float *b0 = nullptr) {
+                        const void *w0 = nullptr, const float *b0 = nullptr, bool f16 = false) {
     using namespace czconv;
     if (B == 0) return CZ_OK;
     if (!c->tower_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerp_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
         c->tower_attr_set = true;
     }
@@ -41,14 +42,19 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
         if (e && e[0] == 'p') return 2;
         return kDefaultVariant;
     }();
-    if (variant == 0) {
+    if (f16) {   // fp16 operands: the 8-wave kernel only
+        const int grid = (B + T8_P - 1) / T8_P;
+        hipLaunchKernelGGL(k_tower8_c128<true>, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
+                           (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
+                           (const uint16_t *)w0, b0, B, 2 * nblocks);
+    } else if (variant == 0) {
         const int grid = (B + TW_P - 1) / TW_P;
         hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
     } else if (variant == 1) {
         const int grid = (B + T8_P - 1) / T8_P;
-        hipLaunchKernelGGL(k_tower8_c128, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
+        hipLaunchKernelGGL(k_tower8_c128<false>, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
     } else {
@@ -80,4 +86,13 @@ extern "C" int cz_net_trunk_bf16(cz_ctx *c, const void *planes16, const void *w0
                "cz_net_trunk_bf16: null argument / nblocks < 1");
     CZ_REQUIRE(!head_out || (head_w && head_b), "cz_net_trunk_bf16: head_out needs head_w and head_b");
     return launch_tower(c, nullptr, wpk, bias, trunk_out, head_w, head_b, head_out, B, nblocks, planes16, w0, b0);
+}
+
+extern "C" int cz_net_trunk_f16(cz_ctx *c, const void *planes16, const void *w0, const float *b0, const void *wpk,
+                                const float *bias, void *trunk_out, const float *head_w, const float *head_b,
+                                float *head_out, int B, int nblocks) {
+    CZ_REQUIRE(c && planes16 && w0 && b0 && wpk && bias && B >= 0 && nblocks >= 1 && (trunk_out || head_out),
+               "cz_net_trunk_f16: null argument / nblocks < 1");
+    CZ_REQUIRE(!head_out || (head_w && head_b), "cz_net_trunk_f16: head_out needs head_w and head_b");
+    return launch_tower(c, nullptr, wpk, bias, trunk_out, head_w, head_b, head_out, B, nblocks, planes16, w0, b0, true);
 }

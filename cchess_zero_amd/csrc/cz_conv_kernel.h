@@ -586,6 +586,25 @@ constexpr int T8_W_OFF = T8_ZERO_OFF + CV_ROWB;     // 92,416
 constexpr int T8_LDS_BYTES = T8_W_OFF + TW_NBUF * TW_SLAB_BYTES;   // 157,952
 constexpr int T8_PLANES_OFF = T8_W_OFF + 3 * TW_SLAB_BYTES;        // input planes borrow ring buffer 3
 
+// Element type of activations and weights: bf16 (F16 = false) or IEEE fp16 (F16 = true, the reference's
+// "19-block fp16" configuration); accumulation is fp32 either way and only the MFMA opcode, the pack / unpack
+// conversions and the plane encoding's 1.0 differ.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16> __device__ __forceinline__ f32x2 unpack_pair(uint32_t u) {
+    if constexpr (F16) return __builtin_convertvector(__builtin_bit_cast(f16x2, u), f32x2);
+    else return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+}
+template <bool F16> __device__ __forceinline__ uint32_t pack_pair(f32x2 v) {   // round to nearest even
+    if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool F16>
 __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *__restrict__ in,
                                                                const uint16_t *__restrict__ wpk,
                                                                const float *__restrict__ bias,
@@ -684,8 +703,8 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
                     float a0 = bq.x, a1 = bq.y, a2 = bq.z, a3 = bq.w;
                     if (add_x) {
                         const uint2 x = xreg[i][j][q];
-                        a0 += __uint_as_float(x.x << 16); a1 += __uint_as_float(x.x & 0xFFFF0000u);
-                        a2 += __uint_as_float(x.y << 16); a3 += __uint_as_float(x.y & 0xFFFF0000u);
+                        const f32x2 xl = unpack_pair<F16>(x.x), xh = unpack_pair<F16>(x.y);
+                        a0 += xl[0]; a1 += xl[1]; a2 += xh[0]; a3 += xh[1];
                     }
                     acc[i][j][4 * q + 0] = a0; acc[i][j][4 * q + 1] = a1; acc[i][j][4 * q + 2] = a2; acc[i][j][4 * q + 3] = a3;
                 }
@@ -701,14 +720,14 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
                 for (int q = 0; q < 4; ++q) {
                     bool live;
                     uint2 *cell = cell_ptr(i, j, q, live);
-                    // ReLU after the rounding, as a packed signed-16-bit max with 0: a bf16 is negative exactly when
+                    // ReLU after the rounding, as a packed signed-16-bit max with 0: a bf16 / fp16 is negative exactly when
                     // its bit pattern is a negative int16 and RNE never changes the sign, so the result is the same
                     // as relu-then-round at a quarter of the VALU work (no v_max_f32 + canonicalize per element)
                     const s16x2 z = {0, 0};
                     const s16x2 rl = __builtin_elementwise_max(
-                        __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]}, bf16x2)), z);
+                        __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]})), z);
                     const s16x2 rh = __builtin_elementwise_max(
-                        __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}, bf16x2)), z);
+                        __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]})), z);
                     if (live) *cell = make_uint2(__builtin_bit_cast(uint32_t, rl), __builtin_bit_cast(uint32_t, rh));
                 }
     };
@@ -735,7 +754,7 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
             for (int i = 0; i < CV_RT; ++i)
 #pragma unroll
                 for (int j = 0; j < CV_CT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16<F16>(wf[t][j], af[i], acc[i][j]);
         }
         store_layer(acc);    // U is not read by the first conv: no barrier needed in front
         __syncthreads();
@@ -785,13 +804,13 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
         for (int tap = 0; tap < 9; ++tap) {
             {
                 T8_SLAB_ARGS()
-                T8_SLAB(TW8_SLAB_ASM_H0, ab, key);
+                if constexpr (F16) { T8_SLAB(TW8F_SLAB_ASM_H0, ab, key); } else { T8_SLAB(TW8_SLAB_ASM_H0, ab, key); }
                 ++g;
             }
             {
                 tap_addr(tap + 1, nab, nkey);
                 T8_SLAB_ARGS()
-                T8_SLAB(TW8_SLAB_ASM_H1, nab, nkey);
+                if constexpr (F16) { T8_SLAB(TW8F_SLAB_ASM_H1, nab, nkey); } else { T8_SLAB(TW8_SLAB_ASM_H1, nab, nkey); }
 #pragma unroll
                 for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
                 ++g;
@@ -828,10 +847,9 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
                 const int c = p ^ key;
                 const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
                 const float *wc8 = w + c * 8;
-                acc += __uint_as_float(v.x << 16) * wc8[0] + __uint_as_float(v.x & 0xFFFF0000u) * wc8[1]
-                     + __uint_as_float(v.y << 16) * wc8[2] + __uint_as_float(v.y & 0xFFFF0000u) * wc8[3]
-                     + __uint_as_float(v.z << 16) * wc8[4] + __uint_as_float(v.z & 0xFFFF0000u) * wc8[5]
-                     + __uint_as_float(v.w << 16) * wc8[6] + __uint_as_float(v.w & 0xFFFF0000u) * wc8[7];
+                const f32x2 e0 = unpack_pair<F16>(v.x), e1 = unpack_pair<F16>(v.y), e2 = unpack_pair<F16>(v.z), e3 = unpack_pair<F16>(v.w);
+                acc += e0[0] * wc8[0] + e0[1] * wc8[1] + e1[0] * wc8[2] + e1[1] * wc8[3]
+                     + e2[0] * wc8[4] + e2[1] * wc8[5] + e3[0] * wc8[6] + e3[1] * wc8[7];
             }
             head_out[((size_t)pos0 * 90 + r) * 3 + c3] = fmaxf(acc + head_b[c3], 0.f);
         }

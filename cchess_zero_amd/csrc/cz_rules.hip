@@ -131,7 +131,7 @@ int czk_encode_planes(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int
     if (dtype == CZ_F32)
         hipLaunchKernelGGL(k_encode_planes<float>, dim3(grid_for(G)), dim3(64), 0, c->stream, boards, side, G, (float *)planes, C, quirk, 1.0f);
     else
-        hipLaunchKernelGGL(k_encode_planes<uint16_t>, dim3(grid_for(G)), dim3(64), 0, c->stream, boards, side, G, (uint16_t *)planes, C, quirk, (uint16_t)0x3F80);
+        hipLaunchKernelGGL(k_encode_planes<uint16_t>, dim3(grid_for(G)), dim3(64), 0, c->stream, boards, side, G, (uint16_t *)planes, C, quirk, (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80));
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

@@ -596,7 +596,7 @@ int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, 
     if (dtype == CZ_F32)
         hipLaunchKernelGGL(k_select<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (float *)planes, C, 1.0f, needs_eval);
     else
-        hipLaunchKernelGGL(k_select<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (uint16_t *)planes, C, (uint16_t)0x3F80, needs_eval);
+        hipLaunchKernelGGL(k_select<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (uint16_t *)planes, C, (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80), needs_eval);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
@@ -634,7 +634,7 @@ int czk_search_select_k(cz_ctx *c, int mode, int K, const uint8_t *active, void 
     if (dtype == CZ_F32)
         hipLaunchKernelGGL(k_select_k<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, active, (float *)planes, C, 1.0f, needs_eval);
     else
-        hipLaunchKernelGGL(k_select_k<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, active, (uint16_t *)planes, C, (uint16_t)0x3F80, needs_eval);
+        hipLaunchKernelGGL(k_select_k<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, active, (uint16_t *)planes, C, (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80), needs_eval);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

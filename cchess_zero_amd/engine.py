@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, MAXMOVES, NLABELS, NSQ, check, lib
+from ._lib import BF16, F16, F32, MAXMOVES, NLABELS, NSQ, check, lib
 
 
 def _ptr(t):
@@ -63,7 +63,7 @@ class SearchEngine:
         self.G = 0
         self.channels = int(channels)
         self.plane_dtype = plane_dtype
-        self._pd = BF16 if plane_dtype == torch.bfloat16 else F32
+        self._pd = {torch.bfloat16: BF16, torch.float16: F16}.get(plane_dtype, F32)
         self.planes = None
         self.need = None
 

@@ -129,7 +129,8 @@ class PolicyValueNet:
     loop uses; forward() has the reference signature (policy_value_network.forward)."""
 
     def __init__(self, res_block_nums=7, device="cuda:0", dtype=torch.bfloat16, seed=0, module=None, backend="auto", ctx=None):
-        """backend: "hip"       = the whole residual tower in ONE fused MFMA launch, cz_tower_c128_bf16 (bf16 only),
+        """backend: "hip"       = first conv + residual tower + head convs in ONE fused MFMA launch (cz_net_trunk_bf16 /
+                                  cz_net_trunk_f16), FC heads in cz_fc_heads_f32; dtype bf16 or fp16,
                     "hip-layer" = one fused conv launch per layer, cz_conv3x3_c128_bf16 (bf16 only),
                     "torch"     = tower convs by torch/MIOpen (any dtype; the fp32 parity path),
                     "auto"      = hip for bf16 on a GPU, else torch."""
@@ -138,9 +139,11 @@ class PolicyValueNet:
         self.module = (module or PolicyValueModule(res_block_nums, seed)).to(self.device)
         self.res_block_nums = self.module.res_block_nums
         if backend == "auto":
-            backend = "hip" if (dtype == torch.bfloat16 and self.device.type == "cuda") else "torch"
-        if backend.startswith("hip") and dtype != torch.bfloat16:
-            raise ValueError("the hip conv backend computes in bf16 (fp32 accumulate); use backend='torch' for %s" % dtype)
+            backend = "hip" if (dtype in (torch.bfloat16, torch.float16) and self.device.type == "cuda") else "torch"
+        if backend == "hip" and dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("the fused hip backend computes in bf16 or fp16 (fp32 accumulate); use backend='torch' for %s" % dtype)
+        if backend == "hip-layer" and dtype != torch.bfloat16:
+            raise ValueError("the per-layer hip backend computes in bf16; use backend='hip' or 'torch' for %s" % dtype)
         self.backend = backend
         self._ctx = ctx
         self._bufs = None
@@ -159,20 +162,22 @@ class PolicyValueNet:
         self.w_in = conv_pack(m.conv_in)
         self.w_blocks = [(conv_pack(a), conv_pack(b)) for a, b in m.blocks]
         if self.backend.startswith("hip"):
+            hdt = torch.float16 if dt == torch.float16 else torch.bfloat16
+
             def hip_pack(cb):
                 w, b = cb.folded()  # [O,I,3,3] fp32 with the BN scale folded in
                 # -> [tap = dy*3+dx][ci/8][co][ci%8] bf16: the LDS image of the B operand, slab by slab
-                wp = w.permute(2, 3, 1, 0).reshape(9, 16, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+                wp = w.permute(2, 3, 1, 0).reshape(9, 16, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(hdt)
                 return wp, b.float().contiguous()
             self.hip_blocks = [(hip_pack(a), hip_pack(b)) for a, b in m.blocks]
             # first layer 14 -> 128: input channels padded to 16, [tap][ci/8][co][ci%8] bf16
             w0, b0 = m.conv_in.folded()
             w0p = torch.zeros((3, 3, 16, FILTERS), dtype=torch.float32, device=w0.device)
             w0p[:, :, :14, :] = w0.permute(2, 3, 1, 0)
-            self.hip_w0 = w0p.reshape(9, 2, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+            self.hip_w0 = w0p.reshape(9, 2, 8, FILTERS).permute(0, 1, 3, 2).contiguous().to(hdt)
             self.hip_b0 = b0.float().contiguous()
             layers = [x for blk in self.hip_blocks for x in blk]
-            self.hip_tower_w = torch.stack([w for w, _ in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.bfloat16, device=self.device)
+            self.hip_tower_w = torch.stack([w for w, _ in layers]).contiguous() if layers else torch.zeros((0,), dtype=hdt, device=self.device)
             self.hip_tower_b = torch.stack([b for _, b in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.float32, device=self.device)
         # heads: 1x1 convs as fp32 matmuls over [B*90,128]
         wp, bp = m.policy_conv.folded()
@@ -226,28 +231,31 @@ class PolicyValueNet:
             self.conv_events.append(ev)
         return out
 
-    def _hip_net_forward(self, planes):
-        """planes [B,9,10,C] (C = 16 bf16: zero-copy; anything else is repacked) -> z [B,90,3] f32.
-        First conv + residual tower + head 1x1 convs in ONE launch (cz_net_trunk_bf16)."""
+    def _hip_net_forward(self, planes, trunk=False):
+        """planes [B,9,10,C] (C = 16 in the net's 16-bit dtype: zero-copy; anything else is repacked) -> z [B,90,3] f32
+        (post-ReLU head conv outputs), or with trunk=True the trunk activations [B,90,128] in the net's dtype.
+        First conv + residual tower + head 1x1 convs in ONE launch (cz_net_trunk_bf16 / cz_net_trunk_f16)."""
         import ctypes as C
         from ._lib import check, lib
         B = planes.shape[0]
-        if planes.dtype == torch.bfloat16 and planes.shape[-1] == 16 and planes.is_contiguous():
+        hdt = torch.float16 if self.dtype == torch.float16 else torch.bfloat16
+        fn = lib().cz_net_trunk_f16 if hdt == torch.float16 else lib().cz_net_trunk_bf16
+        if planes.dtype == hdt and planes.shape[-1] == 16 and planes.is_contiguous():
             p16 = planes
         else:
-            p16 = torch.zeros((B, 9, 10, 16), dtype=torch.bfloat16, device=self.device)
-            p16[..., :14] = planes[..., :14].to(torch.bfloat16)
-        z = torch.empty((B, 90, 3), dtype=torch.float32, device=self.device)
+            p16 = torch.zeros((B, 9, 10, 16), dtype=hdt, device=self.device)
+            p16[..., :14] = planes[..., :14].to(hdt)
+        z = torch.empty((B, 90, FILTERS), dtype=hdt, device=self.device) if trunk else torch.empty((B, 90, 3), dtype=torch.float32, device=self.device)
         self._hip_ctx().bind_stream()
         ev = None
         if self.conv_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        check(lib().cz_net_trunk_bf16(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_w0.data_ptr()),
-                                      C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_tower_w.data_ptr()),
-                                      C.c_void_p(self.hip_tower_b.data_ptr()), None, C.c_void_p(self.head_w_rows.data_ptr()),
-                                      C.c_void_p(self.head_b.data_ptr()), C.c_void_p(z.data_ptr()), B, self.res_block_nums),
-              "cz_net_trunk_bf16")
+        check(fn(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_w0.data_ptr()),
+                 C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_tower_w.data_ptr()),
+                 C.c_void_p(self.hip_tower_b.data_ptr()), C.c_void_p(z.data_ptr()) if trunk else None,
+                 C.c_void_p(self.head_w_rows.data_ptr()), C.c_void_p(self.head_b.data_ptr()),
+                 None if trunk else C.c_void_p(z.data_ptr()), B, self.res_block_nums), "cz_net_trunk")
         if ev is not None:
             ev[1].record()
             self.conv_events.append(ev)
@@ -329,6 +337,9 @@ class PolicyValueNet:
     @torch.no_grad()
     def tower(self, planes):
         """planes [B,9,10,C>=14] (NHWC, any float dtype) -> trunk activations [B,128,9,10] channels_last."""
+        if self.backend == "hip" and self.dtype == torch.float16 and self.res_block_nums >= 1:
+            t = self._hip_net_forward(planes, trunk=True)   # fp16: the fused kernel is the only hip route
+            return t.reshape(t.shape[0], 9, 10, FILTERS).permute(0, 3, 1, 2)
         h = self.first_conv(planes)
         if self.backend == "hip":
             return self._hip_tower_forward(h)

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import BF16, F32, MASK_WORDS, MAXMOVES, NLABELS, NSQ, check, lib
+from ._lib import BF16, F16, F32, MASK_WORDS, MAXMOVES, NLABELS, NSQ, check, lib
 from .engine import Context, _ptr
 
 
@@ -51,6 +51,6 @@ class Rules:
         side = self._dev(side, torch.uint8)
         G = boards.shape[0]
         out = torch.empty((G, 9, 10, channels), dtype=dtype, device=self.dev)
-        check(lib().cz_encode_planes(self.ctx.h, _ptr(boards), _ptr(side), G, _ptr(out), BF16 if dtype == torch.bfloat16 else F32,
+        check(lib().cz_encode_planes(self.ctx.h, _ptr(boards), _ptr(side), G, _ptr(out), {torch.bfloat16: BF16, torch.float16: F16}.get(dtype, F32),
                                      channels, 1 if quirk_q1 else 0), "cz_encode_planes")
         return out

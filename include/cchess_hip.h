@@ -49,6 +49,7 @@ extern "C" {
 
 #define CZ_F32 0
 #define CZ_BF16 1
+#define CZ_F16 2 /* IEEE half: accepted where planes are written (cz_encode_planes, cz_search_select[_k]) */
 
 /* status bits reported by cz_search_status */
 #define CZ_ST_POOL_EXHAUSTED 1 /* node pool of the tree is full: expansion skipped */
@@ -179,6 +180,12 @@ int cz_tower_heads_c128_bf16(cz_ctx *, const void *in, const void *wpk, const fl
 int cz_net_trunk_bf16(cz_ctx *, const void *planes16, const void *w0, const float *b0, const void *wpk,
                       const float *bias, void *trunk_out, const float *head_w, const float *head_b,
                       float *head_out, int B, int nblocks);
+
+/* cz_net_trunk_bf16 with IEEE fp16 activations and weights (fp32 accumulate): the reference's "19-block net fp16"
+ * configuration (BASELINE.json configs[4]).  Same argument layout; planes16, w0, wpk and trunk_out hold fp16. */
+int cz_net_trunk_f16(cz_ctx *, const void *planes16, const void *w0, const float *b0, const void *wpk,
+                     const float *bias, void *trunk_out, const float *head_w, const float *head_b,
+                     float *head_out, int B, int nblocks);
 
 /* The three fully connected layers behind the head convolutions (policy_value_network.py:56-74): policy FC
  * 180 -> 2086 (raw logits) and value FC 90 -> 256, ReLU, FC 256 -> 1, tanh, from the head conv outputs

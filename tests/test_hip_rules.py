@@ -62,6 +62,8 @@ def test_planes_golden(rules, rules_golden):
     assert p16.shape == (len(p32), 9, 10, 16)
     assert torch.equal(p16[..., :14].float().cpu(), torch.from_numpy(p32))
     assert float(p16[..., 14:].abs().sum()) == 0.0
+    ph = rules.encode_planes(g["boards"], g["side"], torch.float16, 16)   # CZ_F16: 1.0 = 0x3C00
+    assert torch.equal(ph[..., :14].float().cpu(), torch.from_numpy(p32)) and float(ph[..., 14:].abs().sum()) == 0.0
 
 
 def test_rules_vs_oracle_large_corpus(rules):

@@ -171,6 +171,9 @@ def main():
     txt += emit("TW_SLAB_ASM_H0", slab(0)) + "\n" + emit("TW_SLAB_ASM_H1", slab(1))
     txt += "\n// 8-wave / 4-position variant (two fragment sets, 2 DMA pieces per wave)\n"
     txt += emit("TW8_SLAB_ASM_H0", slab8(0)) + "\n" + emit("TW8_SLAB_ASM_H1", slab8(1))
+    txt += "\n// the same with fp16 operands\n"
+    f16 = lambda L: [l.replace("v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16") for l in L]
+    txt += emit("TW8F_SLAB_ASM_H0", f16(slab8(0))) + "\n" + emit("TW8F_SLAB_ASM_H1", f16(slab8(1)))
     txt += "\n// position-per-wave variant (4 waves, 3 cell tiles x 4 channel tiles each, two fragment sets)\n"
     txt += emit("TWP_SLAB_ASM_H0", slabP(0)) + "\n" + emit("TWP_SLAB_ASM_H1", slabP(1))
     txt += "\n" + emit("TWP_SLAB_ASM_FIRST", slabP(0, first=True))
