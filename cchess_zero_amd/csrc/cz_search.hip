@@ -92,23 +92,36 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
         if (v.child_begin[root] < 0) {
             kind = 3; leaf = root;  // MCTS_tree.main root expansion, main.py:475-487
         } else if (mode != 0) {
+            // One dependent HBM round trip per tree level: every lane fetches, together with the statistics of the
+            // child it scores, that child's move label and expansion record (child_begin, child_count); the
+            // winner's are then taken from its lane, so the next level starts without touching memory again.
+            int cb = v.child_begin[node], cc = v.child_count[node], nN = v.N[node];
             for (;;) {
-                const int cb = v.child_begin[node];
                 if (cb < 0) { kind = 1; leaf = node; break; }  // not in `expanded`, main.py:357
-                const int cc = v.child_count[node];
                 if (cc == 0) { if (lane == 0) t.status[g] |= CZ_ST_NO_MOVES; break; }  // max() of empty, quirk Q7
                 // select_new / get_Q_plus_U_new, main.py:108-116,158-159.  Non-root nodes on the path
                 // carry their virtual loss (N += 3, main.py:403) while their children are scored.
-                const double sq = sqrt((double)(v.N[node] + (node != root ? 3 : 0)));
+                const double sq = sqrt((double)(nN + (node != root ? 3 : 0)));
                 Cand best; best.s = -INFINITY; best.i = 0x7FFFFFFF;
                 bool first_nan = false;
+                int cN[2] = {0, 0}, cBeg[2] = {-1, -1}, cCnt[2] = {0, 0}, cSd[2] = {0, 0};
+                float cP[2] = {0.f, 0.f}, cQ[2] = {0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int i = lane + 64 * r;
                     if (i < cc) {
-                        const float cp = 5.0f * v.P[cb + i];
-                        const double u = (double)cp * sq / (double)(1 + v.N[cb + i]);
-                        double s = (double)v.Q[cb + i] + u;
+                        cP[r] = v.P[cb + i]; cN[r] = v.N[cb + i]; cQ[r] = v.Q[cb + i];
+                        cBeg[r] = v.child_begin[cb + i]; cCnt[r] = v.child_count[cb + i];
+                        cSd[r] = tab.srcdst[v.move[cb + i]];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i = lane + 64 * r;
+                    if (i < cc) {
+                        const float cp = 5.0f * cP[r];
+                        const double u = (double)cp * sq / (double)(1 + cN[r]);
+                        double s = (double)cQ[r] + u;
                         if (s != s) { if (i == 0) first_nan = true; s = -INFINITY; }
                         Cand c; c.s = s; c.i = i;
                         best = better(best, c);
@@ -122,8 +135,12 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
                 int bi = best.i;
                 if (__shfl((int)first_nan, 0, 64)) bi = 0;  // a NaN first element is never displaced by `>`
                 const int c = cb + bi;
-                const int l = v.move[c];
-                const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+                const int wl = bi & 63, wr = bi >> 6;   // the winner sits in lane wl, round wr
+                const int sd = __shfl(wr ? cSd[1] : cSd[0], wl, 64);
+                const int nbeg = __shfl(wr ? cBeg[1] : cBeg[0], wl, 64);
+                const int ncnt = __shfl(wr ? cCnt[1] : cCnt[0], wl, 64);
+                const int nn = __shfl(wr ? cN[1] : cN[0], wl, 64);
+                const int src = sd & 0xFF, dst = sd >> 8;
                 const int cap = b[dst];
                 __syncthreads();
                 if (lane == 0) { b[dst] = b[src]; b[src] = 0; }  // sim_do_action, main.py:671-672
@@ -142,7 +159,7 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
                 } else if (rr >= 60) {      // main.py:415-416
                     kind = 2; leaf = c; pend = 0.f; break;
                 }
-                node = c;
+                node = c; cb = nbeg; cc = ncnt; nN = nn;
             }
         }
     }
