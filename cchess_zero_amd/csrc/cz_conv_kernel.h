@@ -683,12 +683,21 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
     int keep;
 
     // the cells / channel quads this lane owns in the accumulator layout
+    // 24 swizzled addresses per lane: recomputed from an opaque copy of the row offset wherever they are needed
+    // (hoisted out of the layer loop they are only spilled to scratch)
+    int rb[CV_RT];
+    auto refresh_rb = [&]() {
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int r = 32 * (wr * CV_RT + i) + l31;
+            rb[i] = (r < T8_ROWS ? r : 0) * CV_ROWB;
+            asm volatile("" : "+v"(rb[i]));
+        }
+    };
     auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
-        const int r = 32 * (wr * CV_RT + i) + l31;
-        live = r < T8_ROWS;
-        const int rc = live ? r : 0;
+        live = 32 * (wr * CV_RT + i) + l31 < T8_ROWS;
         const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
-        return reinterpret_cast<uint2 *>(smem + lds_addr(rc * CV_ROWB, n0 >> 3) + ((n0 & 4) << 1));
+        return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
     };
     // acc = bias (+ x): the residual is folded into the initialisation of a block's second conv
     uint2 xreg[CV_RT][CV_CT][4];   // block input x at this lane's accumulator positions (packed bf16)
@@ -756,6 +765,7 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
                 for (int j = 0; j < CV_CT; ++j)
                     acc[i][j] = mfma_32x32x16<F16>(wf[t][j], af[i], acc[i][j]);
         }
+        refresh_rb();
         store_layer(acc);    // U is not read by the first conv: no barrier needed in front
         __syncthreads();
     }
@@ -782,6 +792,7 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
         f32x16 acc[CV_RT][CV_CT];
+        refresh_rb();
         if (!(layer & 1)) {   // first conv of a block: remember x, start from the bias
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i)
@@ -820,6 +831,7 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
         // sure every wave is done reading U before anyone overwrites it in place
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
         __syncthreads();
+        refresh_rb();
         store_layer(acc);
         __syncthreads();
     }
