@@ -1,6 +1,6 @@
 // cz_heads.hip — the three fully connected layers behind the head convolutions, in two launches.
 //
-// Reference: policy_value_network.py:56-74 — policy head: flatten [9,10,2] in (h,w,c) order -> FC 180->2086
+// Reference: policy_value_network.py:62-63,72-74 — policy head: flatten [9,10,2] in (h,w,c) order -> FC 180->2086
 // (raw logits, no softmax before the search reads them, quirk Q3); value head: flatten [9,10,1] -> FC 90->256 +
 // ReLU -> FC 256->1 + tanh.  Input is the post-BN/ReLU output of the two 1x1 head convolutions as the tower
 // kernel leaves it: z [B][90][3] f32 (channels 0,1 = policy, 2 = value).

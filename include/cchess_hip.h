@@ -187,7 +187,7 @@ int cz_net_trunk_f16(cz_ctx *, const void *planes16, const void *w0, const float
                      const float *bias, void *trunk_out, const float *head_w, const float *head_b,
                      float *head_out, int B, int nblocks);
 
-/* The three fully connected layers behind the head convolutions (policy_value_network.py:56-74): policy FC
+/* The three fully connected layers behind the head convolutions (policy_value_network.py:62-63,72-74): policy FC
  * 180 -> 2086 (raw logits) and value FC 90 -> 256, ReLU, FC 256 -> 1, tanh, from the head conv outputs
  * z [B][90][3] f32 as cz_net_trunk_bf16 / cz_tower_heads_c128_bf16 leave them (flatten order (h,w,c)).
  *   pfc_w_hi, pfc_w_lo : policy FC weight split into bf16 hi + lo parts (w ~= hi + lo), each packed in MFMA
