@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
     ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 80: no tree can run out)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,7 +153,7 @@ def main():
 
     G, playout = args.games, args.playout
     tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-    cap = (playout + 2) * 80
+    cap = args.nodes_per_tree or (playout + 2) * 80
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
     # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)

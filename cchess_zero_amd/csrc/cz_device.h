@@ -35,85 +35,125 @@ __device__ __forceinline__ int czd_wave_excl_scan(int v, int lane, int *total) {
     return x - v;
 }
 
-// Per-lane generator for the piece on `sq` (if it belongs to `side`), in the exact emission
-// order of GameBoard.get_legal_moves (main.py:757-1095).  Writes labels to st[0..n).
-__device__ __forceinline__ int czd_gen_piece(const uint8_t *b, int sq, int side, const int16_t *lut,
-                                             uint16_t *st, bool &err) {
-    const int c = b[sq];
+// ---- 90-bit square sets ---------------------------------------------------------------------------
+// The rules are evaluated on wave-uniform bit sets built with __ballot (lane = square), not by walking the
+// board in LDS: a rook ray is a find-first-set on 9 or 10 bits instead of up to nine dependent LDS loads in a
+// divergent loop.  Two orders are kept: rank-major (bit y*9+x, the board's own order) for rank rays and
+// single-square tests, file-major (bit x*10+y) for file rays.
+struct CzdSet { unsigned long long lo, hi; };   // bits 0..63, 64..89
+__device__ __forceinline__ bool czd_tst(CzdSet m, int i) { return ((i < 64 ? m.lo >> i : m.hi >> (i - 64)) & 1ull) != 0; }
+__device__ __forceinline__ unsigned czd_bits(CzdSet m, int s) {   // the bits from position s (0 <= s <= 81) upward
+    unsigned long long v;
+    if (s == 0) v = m.lo;
+    else if (s < 64) v = (m.lo >> s) | (m.hi << (64 - s));
+    else v = m.hi >> (s - 64);
+    return (unsigned)v;
+}
+__device__ __forceinline__ CzdSet czd_andn(CzdSet a, CzdSet b) { CzdSet r; r.lo = a.lo & ~b.lo; r.hi = a.hi & ~b.hi; return r; }
+
+struct CzdBoardSets { CzdSet occ, enemy, occT, enemyT; };   // enemy = pieces of the side NOT to move
+
+// b: LDS board [96] (visible to all lanes).  All lanes must call this.
+__device__ __forceinline__ CzdBoardSets czd_board_sets(const uint8_t *b, int side, int lane) {
+    const int c0 = b[lane], c1 = (lane + 64 < CZD_NSQ) ? b[lane + 64] : 0;
+    const int t0 = lane, t1 = lane + 64;   // file-major index t = x*10 + y  ->  square y*9 + x
+    const int d0 = b[(t0 % 10) * 9 + t0 / 10], d1 = (t1 < CZD_NSQ) ? b[(t1 % 10) * 9 + t1 / 10] : 0;
+    CzdBoardSets s;
+    CzdSet blk, blkT;
+    s.occ.lo = __ballot(c0 != 0); s.occ.hi = __ballot(c1 != 0);
+    blk.lo = __ballot(c0 > 7);    blk.hi = __ballot(c1 > 7);
+    s.occT.lo = __ballot(d0 != 0); s.occT.hi = __ballot(d1 != 0);
+    blkT.lo = __ballot(d0 > 7);    blkT.hi = __ballot(d1 > 7);
+    s.enemy = side ? czd_andn(s.occ, blk) : blk;       // black to move: the enemy is red (occupied, not black)
+    s.enemyT = side ? czd_andn(s.occT, blkT) : blkT;
+    return s;
+}
+
+// Per-lane generator for the piece on `sq` (if it belongs to `side`), in the exact emission order of
+// GameBoard.get_legal_moves (main.py:757-1095).  Writes src | dst << 8 to st[0..n) (the label lookup happens
+// after compaction, coalesced).  c = piece code on sq.
+__device__ __forceinline__ int czd_gen_piece(int c, int sq, int side, const CzdBoardSets &S, uint16_t *st) {
     const int black = c > 7;
     if (c == 0 || black != side) return 0;
     const int t = black ? c - 7 : c;
     const int y = sq / 9, x = sq - y * 9;
     int n = 0;
-    auto emit = [&](int ty, int tx) {
-        int l = lut[sq * CZD_NSQ + ty * 9 + tx];
-        if (l < 0) err = true; else st[n++] = (uint16_t)l;
+    auto emit = [&](int ty, int tx) { st[n++] = (uint16_t)(sq | ((ty * 9 + tx) << 8)); };
+    auto occ = [&](int ty, int tx) { return czd_tst(S.occ, ty * 9 + tx); };
+    auto notown = [&](int ty, int tx) {   // validate_move, main.py:727: empty or enemy
+        const int q = ty * 9 + tx;
+        return !czd_tst(S.occ, q) || czd_tst(S.enemy, q);
     };
-    auto enemy = [&](int d) { return d != 0 && ((d > 7) != side); };
-    auto notown = [&](int d) { return d == 0 || ((d > 7) != side); };  // validate_move, main.py:727
     auto inb = [&](int ty, int tx) { return ty >= 0 && tx >= 0 && ty < 10 && tx < 9; };  // check_bounds :717
     switch (t) {
-    case 3: {  // R/r  main.py:757-833: -x, +x, -y, +y
-        for (int tx = x - 1; tx >= 0; --tx) { int d = b[y * 9 + tx]; if (d) { if (enemy(d)) emit(y, tx); break; } emit(y, tx); }
-        for (int tx = x + 1; tx < 9; ++tx) { int d = b[y * 9 + tx]; if (d) { if (enemy(d)) emit(y, tx); break; } emit(y, tx); }
-        for (int ty = y - 1; ty >= 0; --ty) { int d = b[ty * 9 + x]; if (d) { if (enemy(d)) emit(ty, x); break; } emit(ty, x); }
-        for (int ty = y + 1; ty < 10; ++ty) { int d = b[ty * 9 + x]; if (d) { if (enemy(d)) emit(ty, x); break; } emit(ty, x); }
+    case 3:    // R/r  main.py:757-833: -x, +x, -y, +y: slide over empties, capture the first enemy
+    case 7: {  // C/c  main.py:947-1062: slide over empties; behind exactly one screen capture the first enemy
+        const bool cannon = t == 7;
+        const unsigned row = czd_bits(S.occ, y * 9) & 0x1FFu, rowE = czd_bits(S.enemy, y * 9) & 0x1FFu;
+        const unsigned col = czd_bits(S.occT, x * 10) & 0x3FFu, colE = czd_bits(S.enemyT, x * 10) & 0x3FFu;
+        // one direction on a line of `len` squares: own index p, occupancy o, enemies e, step -1 / +1
+        auto ray = [&](unsigned o, unsigned e, int p, int len, int dir, bool along_x) {
+            int hit;   // index of the first occupied square in direction dir, or -1 / len
+            if (dir < 0) { const unsigned m = o & ((1u << p) - 1u); hit = m ? 31 - __clz(m) : -1; }
+            else { const unsigned m = o >> (p + 1); hit = m ? p + 1 + (__ffs(m) - 1) : len; }
+            for (int q = p + dir; q != hit; q += dir) { if (along_x) emit(y, q); else emit(q, x); }
+            if (hit < 0 || hit >= len) return;
+            if (!cannon) { if ((e >> hit) & 1u) { if (along_x) emit(y, hit); else emit(hit, x); } return; }
+            int hit2;  // the cannon's target: the next occupied square behind the screen
+            if (dir < 0) { const unsigned m = o & ((1u << hit) - 1u); hit2 = m ? 31 - __clz(m) : -1; }
+            else { const unsigned m = o >> (hit + 1); hit2 = m ? hit + 1 + (__ffs(m) - 1) : len; }
+            if (hit2 >= 0 && hit2 < len && ((e >> hit2) & 1u)) { if (along_x) emit(y, hit2); else emit(hit2, x); }
+        };
+        ray(row, rowE, x, 9, -1, true);
+        ray(row, rowE, x, 9, +1, true);
+        ray(col, colE, y, 10, -1, false);
+        ray(col, colE, y, 10, +1, false);
     } break;
     case 5: {  // N/n  main.py:835-856: (2i,j) with leg (i,0), then (i,2j) with leg (0,j)
         for (int i = -1; i <= 1; i += 2)
             for (int j = -1; j <= 1; j += 2) {
                 int ty = y + 2 * i, tx = x + j;
-                if (inb(ty, tx) && notown(b[ty * 9 + tx]) && b[(y + i) * 9 + x] == 0) emit(ty, tx);
+                if (inb(ty, tx) && notown(ty, tx) && !occ(y + i, x)) emit(ty, tx);
                 ty = y + i; tx = x + 2 * j;
-                if (inb(ty, tx) && notown(b[ty * 9 + tx]) && b[y * 9 + x + j] == 0) emit(ty, tx);
+                if (inb(ty, tx) && notown(ty, tx) && !occ(y, x + j)) emit(ty, tx);
             }
     } break;
     case 4: {  // B/b  main.py:857-888: two-step diagonals, eye empty, own half
         for (int i = -2; i <= 2; i += 4) {
             const int h = i / 2;
             int ty = y + i, tx = x + i;
-            if (inb(ty, tx) && notown(b[ty * 9 + tx]) && (side ? ty >= 5 : ty <= 4) && b[(y + h) * 9 + x + h] == 0) emit(ty, tx);
+            if (inb(ty, tx) && notown(ty, tx) && (side ? ty >= 5 : ty <= 4) && !occ(y + h, x + h)) emit(ty, tx);
             tx = x - i;
-            if (inb(ty, tx) && notown(b[ty * 9 + tx]) && (side ? ty >= 5 : ty <= 4) && b[(y + h) * 9 + x - h] == 0) emit(ty, tx);
+            if (inb(ty, tx) && notown(ty, tx) && (side ? ty >= 5 : ty <= 4) && !occ(y + h, x - h)) emit(ty, tx);
         }
     } break;
     case 2: {  // A/a  main.py:889-918: palace diagonals
         for (int i = -1; i <= 1; i += 2) {
             int ty = y + i, tx = x + i;
-            if (inb(ty, tx) && notown(b[ty * 9 + tx]) && (side ? ty >= 7 : ty <= 2) && tx >= 3 && tx <= 5) emit(ty, tx);
+            if (inb(ty, tx) && notown(ty, tx) && (side ? ty >= 7 : ty <= 2) && tx >= 3 && tx <= 5) emit(ty, tx);
             tx = x - i;
-            if (inb(ty, tx) && notown(b[ty * 9 + tx]) && (side ? ty >= 7 : ty <= 2) && tx >= 3 && tx <= 5) emit(ty, tx);
+            if (inb(ty, tx) && notown(ty, tx) && (side ? ty >= 7 : ty <= 2) && tx >= 3 && tx <= 5) emit(ty, tx);
         }
     } break;
     case 1: {  // K/k  main.py:919-946: (0,-1) (0,+1) (-1,0) (+1,0) inside the palace
         for (int i = 0; i < 2; ++i)
             for (int s = -1; s <= 1; s += 2) {
                 int ty = y + i * s, tx = x + (1 - i) * s;
-                if (inb(ty, tx) && notown(b[ty * 9 + tx]) && (side ? ty >= 7 : ty <= 2) && tx >= 3 && tx <= 5) emit(ty, tx);
+                if (inb(ty, tx) && notown(ty, tx) && (side ? ty >= 7 : ty <= 2) && tx >= 3 && tx <= 5) emit(ty, tx);
             }
-    } break;
-    case 7: {  // C/c  main.py:947-1062: slide over empties; after one screen capture the first enemy
-        bool hit = false;
-        for (int tx = x - 1; tx >= 0; --tx) { int d = b[y * 9 + tx]; if (!hit) { if (d) hit = true; else emit(y, tx); } else if (d) { if (enemy(d)) emit(y, tx); break; } }
-        hit = false;
-        for (int tx = x + 1; tx < 9; ++tx) { int d = b[y * 9 + tx]; if (!hit) { if (d) hit = true; else emit(y, tx); } else if (d) { if (enemy(d)) emit(y, tx); break; } }
-        hit = false;
-        for (int ty = y - 1; ty >= 0; --ty) { int d = b[ty * 9 + x]; if (!hit) { if (d) hit = true; else emit(ty, x); } else if (d) { if (enemy(d)) emit(ty, x); break; } }
-        hit = false;
-        for (int ty = y + 1; ty < 10; ++ty) { int d = b[ty * 9 + x]; if (!hit) { if (d) hit = true; else emit(ty, x); } else if (d) { if (enemy(d)) emit(ty, x); break; } }
     } break;
     case 6: {  // P/p  main.py:1063-1095: black advances to y-1, red to y+1; sideways past the river
         if (side) {
-            if (inb(y - 1, x) && notown(b[(y - 1) * 9 + x])) emit(y - 1, x);
+            if (inb(y - 1, x) && notown(y - 1, x)) emit(y - 1, x);
             if (y < 5) {
-                if (inb(y, x + 1) && notown(b[y * 9 + x + 1])) emit(y, x + 1);
-                if (inb(y, x - 1) && notown(b[y * 9 + x - 1])) emit(y, x - 1);
+                if (inb(y, x + 1) && notown(y, x + 1)) emit(y, x + 1);
+                if (inb(y, x - 1) && notown(y, x - 1)) emit(y, x - 1);
             }
         } else {
-            if (inb(y + 1, x) && notown(b[(y + 1) * 9 + x])) emit(y + 1, x);
+            if (inb(y + 1, x) && notown(y + 1, x)) emit(y + 1, x);
             if (y > 4) {
-                if (inb(y, x + 1) && notown(b[y * 9 + x + 1])) emit(y, x + 1);
-                if (inb(y, x - 1) && notown(b[y * 9 + x - 1])) emit(y, x - 1);
+                if (inb(y, x + 1) && notown(y, x + 1)) emit(y, x + 1);
+                if (inb(y, x - 1) && notown(y, x - 1)) emit(y, x - 1);
             }
         }
     } break;
@@ -126,17 +166,20 @@ __device__ __forceinline__ int czd_gen_piece(const uint8_t *b, int sq, int side,
 //   b     LDS board [96]; stage LDS [64*18] u16; out LDS [128] u16.
 // Returns the move count (wave-uniform), or -1 on overflow / unlabeled move.
 // Scan order = ascending sq (y outer, x inner, main.py:754-755): lanes take squares 0..63 then
-// 64..89; a wave prefix sum of the per-piece counts places every piece's run.
+// 64..89; a wave prefix sum of the per-piece counts places every piece's run of (src, dst) pairs; the pairs are
+// turned into labels afterwards, two coalesced LUT loads per lane instead of one load per emitted move inside
+// the divergent generator.
 __device__ __forceinline__ int czd_wave_movegen(const uint8_t *b, int side, const int16_t *lut,
                                                 uint16_t *stage, uint16_t *out, int lane) {
     bool err = false;
     int base = 0;
     uint16_t *st = stage + lane * CZD_STAGE_STRIDE;
+    const CzdBoardSets S = czd_board_sets(b, side, lane);
 #pragma unroll 1
     for (int r = 0; r < 2; ++r) {
         const int sq = lane + 64 * r;
         int n = 0;
-        if (sq < CZD_NSQ) n = czd_gen_piece(b, sq, side, lut, st, err);
+        if (sq < CZD_NSQ) n = czd_gen_piece(b[sq], sq, side, S, st);
         int total;
         const int off = base + czd_wave_excl_scan(n, lane, &total);
         if (off + n > CZD_MAXMOVES) { err = true; n = 0; }
@@ -151,14 +194,34 @@ __device__ __forceinline__ int czd_wave_movegen(const uint8_t *b, int side, cons
     const int Ksq = K0 ? __ffsll((long long)K0) - 1 : (K1 ? 64 + __ffsll((long long)K1) - 1 : -1);
     const int ksq = k0 ? __ffsll((long long)k0) - 1 : (k1 ? 64 + __ffsll((long long)k1) - 1 : -1);
     if (Ksq >= 0 && ksq >= 0 && (Ksq % 9) == (ksq % 9)) {
-        bool face = true;
-        for (int s = Ksq + 9; s < ksq; s += 9) face = face && (b[s] == 0);
-        if (face) {
+        // the reference walks from the red king towards higher ranks (main.py:1100-1104)
+        const int fx = Ksq % 9, y0 = Ksq / 9, y1 = ksq / 9;
+        const unsigned col = czd_bits(S.occT, fx * 10) & 0x3FFu;
+        const unsigned between = (y1 > y0 + 1) ? (((1u << y1) - 1u) & ~((1u << (y0 + 1)) - 1u)) : 0u;
+        if ((col & between) == 0u) {
             const int src = side ? ksq : Ksq, dst = side ? Ksq : ksq;
-            const int l = lut[src * CZD_NSQ + dst];
-            if (l < 0 || base >= CZD_MAXMOVES) err = true;
-            else { if (lane == 0) out[base] = (uint16_t)l; base += 1; }
+            if (base >= CZD_MAXMOVES) err = true;
+            else { if (lane == 0) out[base] = (uint16_t)(src | (dst << 8)); base += 1; }
         }
+    }
+    __syncthreads();
+    // (src, dst) -> label (label2i, main.py:217)
+    uint16_t lab[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        lab[r] = 0;
+        if (i < base) {
+            const int sd = out[i];
+            const int l = lut[(sd & 0xFF) * CZD_NSQ + (sd >> 8)];
+            if (l < 0) err = true; else lab[r] = (uint16_t)l;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        if (i < base) out[i] = lab[r];
     }
     const bool any_err = __ballot(err) != 0ull;
     __syncthreads();
@@ -171,6 +234,39 @@ __device__ __forceinline__ int czd_wave_movegen(const uint8_t *b, int side, cons
 template <typename T>
 __device__ __forceinline__ void czd_wave_encode_planes(const uint8_t *b, int side, int quirk_q1, T *out,
                                                        int C, T one, int lane) {
+    if (C == 16 && sizeof(T) == 2) {
+        // the fused net kernel's input format: 16 two-byte channels = 32 bytes per cell, one lane per cell, the one-hot
+        // built in registers and written as two 16-byte stores (the generic loop below spends ~25 operations per element)
+        uint4 *o4 = reinterpret_cast<uint4 *>(out);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int cell = lane + 64 * r;
+            if (cell < 90) {
+                int src;
+                if (quirk_q1) { const int h = cell / 10, w = cell - h * 10; src = h * 9 + w; }
+                else { const int xx = cell / 10, yy = cell - xx * 10; src = yy * 9 + xx; }
+                int code = 0;
+                if (src < CZD_NSQ) {
+                    if (side) {
+                        const int y = src / 9, x = src - y * 9;
+                        const int p = b[(9 - y) * 9 + x];
+                        code = p == 0 ? 0 : (p > 7 ? p - 7 : p + 7);
+                    } else code = b[src];
+                }
+                const int idx = code - 1;   // channel of the 1, or -1
+                const unsigned v = (unsigned)(unsigned short)one << ((idx & 1) * 16);
+                uint4 lo4 = make_uint4(0, 0, 0, 0), hi4 = make_uint4(0, 0, 0, 0);
+                const int wd = idx >> 1;    // 32-bit word 0..6 of the cell's 8
+                if (idx >= 0) {
+                    lo4.x = wd == 0 ? v : 0u; lo4.y = wd == 1 ? v : 0u; lo4.z = wd == 2 ? v : 0u; lo4.w = wd == 3 ? v : 0u;
+                    hi4.x = wd == 4 ? v : 0u; hi4.y = wd == 5 ? v : 0u; hi4.z = wd == 6 ? v : 0u;
+                }
+                o4[cell * 2] = lo4;
+                o4[cell * 2 + 1] = hi4;
+            }
+        }
+        return;
+    }
     const int total = 90 * C;
     for (int e = lane; e < total; e += 64) {
         const int cell = e / C, c = e - cell * C;
