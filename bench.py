@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
     ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--full-policy-fc", action="store_true", help="compute all 2086 logits per leaf (k_policy_fc) instead of folding the policy FC into the expansion")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 80: no tree can run out)")
     args = ap.parse_args()
 
@@ -160,6 +161,7 @@ def main():
     fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16")
     eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx)
     net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
+    fused_fc = net.fused_search and not args.full_policy_fc
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
     eng.reset(boards, side, rr)
 
@@ -176,11 +178,17 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        logits, value = net.forward_device(planes)
+        if fused_fc:   # trunk + value head; the policy FC runs inside the expansion kernel for the legal moves only
+            z, value = net.search_eval(planes)
+        else:
+            logits, value = net.forward_device(planes)
         if timed:
             e1.record()
             ev_net.append((e0, e1))
-        eng.expand_backup(logits, value)
+        if fused_fc:
+            eng.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32)
+        else:
+            eng.expand_backup(logits, value)
 
     def advance_ply():
         st = eng.root_stats()
@@ -279,7 +287,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)" % (G, playout, args.blocks, args.dtype, cfg_name),
-                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "res_block_nums": args.blocks, "search_threads": 1,
+                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits", "res_block_nums": args.blocks, "search_threads": 1,
                    "positions": "seeded random playouts from the start position, ply~U[0,80]",
                    "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),
                    "trees_with_error_status": bad, "status_bits": st_bits},

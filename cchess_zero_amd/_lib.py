@@ -38,6 +38,7 @@ _SIGS = {
     "cz_search_reset": (C.c_int, [C.c_void_p, _u8p, _u8p, _i32p, C.c_int]),
     "cz_search_select": (C.c_int, [C.c_void_p, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup": (C.c_int, [C.c_void_p, _vp, _vp, C.c_int]),
+    "cz_search_expand_backup_fc": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp]),
     "cz_search_set_width": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_select_k": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup_k": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int]),

@@ -251,6 +251,10 @@ int cz_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, i
     CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_search_select: 14 <= channels <= 64");
     return czk_search_select(c, mode, active, planes, dtype, channels, needs_eval);
 }
+int cz_search_expand_backup_fc(cz_ctx *c, const float *z, const float *value, const float *pfc_w, const float *pfc_b) {
+    CZ_REQUIRE(c && c->G > 0 && z && value && pfc_w && pfc_b, "cz_search_expand_backup_fc: null argument / no search");
+    return czk_search_expand_backup_fc(c, z, value, pfc_w, pfc_b);
+}
 int cz_search_expand_backup(cz_ctx *c, const void *logits, const void *value, int dtype) {
     CZ_REQUIRE(c && c->G > 0 && logits && value, "cz_search_expand_backup: null argument / no search");
     CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16, "cz_search_expand_backup: dtype must be CZ_F32 or CZ_BF16");

@@ -80,6 +80,7 @@ int czk_encode_planes(cz_ctx *, const uint8_t *, const uint8_t *, int, void *, i
 int czk_search_reset(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *, int);
 int czk_search_select(cz_ctx *, int, const uint8_t *, void *, int, int, uint8_t *);
 int czk_search_expand_backup(cz_ctx *, const void *, const void *, int);
+int czk_search_expand_backup_fc(cz_ctx *, const float *, const float *, const float *, const float *);
 int czk_search_root_stats(cz_ctx *, uint16_t *, int32_t *, float *, float *, float *, uint16_t *);
 int czk_search_advance(cz_ctx *, const uint16_t *);
 int czk_search_select_k(cz_ctx *, int, int, const uint8_t *, void *, int, int, uint8_t *);

@@ -187,11 +187,23 @@ template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f32<uint16_t>(uint16_t x) { return czd_bf16_bits_to_f32(x); }
 
-template <typename T>
+// FC = false: the raw prior of a move is read from a full logits row [2086] of type T.
+// FC = true : `logits` is instead the head-conv output z [G][90][3] f32 and the policy FC (policy_value_network.py:62-63,
+//             180 -> 2086, weight fcw [2086][180] f32, bias fcb) is evaluated in place for the <= 128 labels the
+//             expansion needs — the search never looks at the other ~2046 logits of a position, so computing and
+//             storing them (68 MB per step at 8192 trees) is wasted work.  Arithmetic, so that the CPU oracle can
+//             restate it bit for bit (float32, multiply and add rounded separately, -ffp-contract=off):
+//               x[k] = z[k / 2][k % 2] for k < 180 (the (h,w,c) flatten), p[k] = w[k] * x[k], p[180..191] = 0;
+//               s[l] = ((p[12l] + p[12l+1]) + ...) + p[12l+11] for l = 0..15 (s[15] = 0);
+//               s[l] += s[15-l]; s[l] += s[(l & 8) | (7 - (l & 7))]; s[l] += s[(l & 12) | (3 - (l & 3))]; s[l] += s[l ^ 1]
+//               (each step on all 16 values at once); logit = s[0] + bias.
+template <typename T, bool FC>
 __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, int G, const T *__restrict__ logits,
-                                                      const T *__restrict__ value) {
+                                                      const T *__restrict__ value, const float *__restrict__ fcw,
+                                                      const float *__restrict__ fcb) {
     __shared__ float pr[CZD_MAXMOVES];
     __shared__ float tot_s;
+    __shared__ __attribute__((aligned(16))) float xin[FC ? 180 : 4];
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     const int kind = t.pend_kind[g];
@@ -206,15 +218,71 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
         const int begin = t.n_nodes[g];
         const bool fits = begin + n <= t.cap;
         if (fits) {
-            const T *lg = logits + (size_t)g * CZ_NLABELS;
             uint16_t lab[2];
+            if constexpr (FC) {
+                const float *zg = reinterpret_cast<const float *>(logits) + (size_t)g * 270;
+                for (int i = lane; i < 270; i += 64) {
+                    const float zv = zg[i];
+                    const int cell = i / 3, ch = i - cell * 3;
+                    if (ch < 2) xin[cell * 2 + ch] = zv;
+                }
+                if (lane < 12) xin[180 + lane] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int i = lane + 64 * r;
-                lab[r] = 0;
-                if (i < n) {
-                    lab[r] = t.pend_moves[(size_t)g * CZD_MAXMOVES + i];
-                    pr[i] = to_f32<T>(lg[sd ? tab.unflip[lab[r]] : lab[r]]);
+                for (int r = 0; r < 2; ++r) {
+                    const int i = lane + 64 * r;
+                    lab[r] = i < n ? t.pend_moves[(size_t)g * CZD_MAXMOVES + i] : (uint16_t)0;
+                }
+                __syncthreads();
+                // four moves per pass, 16 lanes per move: lane l of a group owns inputs k = 12 l .. 12 l + 11 (three
+                // coalesced float4 of the weight row), sums its 12 products in order, then the 16 partial sums are
+                // folded with four symmetric DPP steps (i <-> 15-i, i <-> 7-i within halves, i <-> 3-i within quads,
+                // i <-> i^1); every lane of the group ends up with the same total.  One lane per move gathering its
+                // whole row (45 strided loads) made the texture addresser the bottleneck.
+                const int l16 = lane & 15, grp = lane >> 4;
+                float xr[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) xr[k] = xin[l16 * 12 + k];
+#pragma unroll 1
+                for (int base = 0; base < n; base += 4) {
+                    const int i = base + grp;
+                    int idx = 0;
+                    float sum = 0.f;
+                    if (i < n) {
+                        const int l = t.pend_moves[(size_t)g * CZD_MAXMOVES + i];
+                        idx = sd ? tab.unflip[l] : l;
+                        if (l16 < 15) {
+                            const float4 *w4 = reinterpret_cast<const float4 *>(fcw + (size_t)idx * 180 + l16 * 12);
+                            const float4 a = w4[0], bq = w4[1], cq = w4[2];
+                            sum = a.x * xr[0];
+                            sum = sum + a.y * xr[1];
+                            sum = sum + a.z * xr[2];
+                            sum = sum + a.w * xr[3];
+                            sum = sum + bq.x * xr[4];
+                            sum = sum + bq.y * xr[5];
+                            sum = sum + bq.z * xr[6];
+                            sum = sum + bq.w * xr[7];
+                            sum = sum + cq.x * xr[8];
+                            sum = sum + cq.y * xr[9];
+                            sum = sum + cq.z * xr[10];
+                            sum = sum + cq.w * xr[11];
+                        }
+                    }
+                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x140, 0xF, 0xF, false));  // row_mirror
+                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xF, 0xF, false));  // row_half_mirror
+                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x1B, 0xF, 0xF, false));   // quad_perm [3,2,1,0]
+                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                    if (i < n && l16 == 0) pr[i] = sum + fcb[idx];
+                }
+            } else {
+                const T *lg = logits + (size_t)g * CZ_NLABELS;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i = lane + 64 * r;
+                    lab[r] = 0;
+                    if (i < n) {
+                        lab[r] = t.pend_moves[(size_t)g * CZD_MAXMOVES + i];
+                        pr[i] = to_f32<T>(lg[sd ? tab.unflip[lab[r]] : lab[r]]);
+                    }
                 }
             }
             __syncthreads();
@@ -620,9 +688,17 @@ int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, 
 
 int czk_search_expand_backup(cz_ctx *c, const void *logits, const void *value, int dtype) {
     if (dtype == CZ_F32)
-        hipLaunchKernelGGL(k_expand_backup<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const float *)logits, (const float *)value);
+        hipLaunchKernelGGL((k_expand_backup<float, false>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const float *)logits,
+                           (const float *)value, (const float *)nullptr, (const float *)nullptr);
     else
-        hipLaunchKernelGGL(k_expand_backup<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const uint16_t *)logits, (const uint16_t *)value);
+        hipLaunchKernelGGL((k_expand_backup<uint16_t, false>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const uint16_t *)logits,
+                           (const uint16_t *)value, (const float *)nullptr, (const float *)nullptr);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_expand_backup_fc(cz_ctx *c, const float *z, const float *value, const float *fcw, const float *fcb) {
+    hipLaunchKernelGGL((k_expand_backup<float, true>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, z, value, fcw, fcb);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

@@ -117,6 +117,15 @@ class SearchEngine:
         else:
             check(lib().cz_search_expand_backup(self.ctx.h, _ptr(logits), _ptr(value), dt), "cz_search_expand_backup")
 
+    def expand_backup_fc(self, z, value, pfc_w, pfc_b):
+        """expand_backup with the policy FC folded in (cz_search_expand_backup_fc): z [G,90,3] f32 head-conv outputs,
+        value [G] or [G,1] f32, pfc_w [2086,180] f32 (torch layout), pfc_b [2086] f32.  Width 1 only."""
+        assert self.width == 1, "expand_backup_fc pairs with the one-simulation-per-tree select"
+        assert z.dtype == torch.float32 and z.is_contiguous() and z.shape == (self.G, 90, 3)
+        value = value.float().contiguous()
+        assert value.numel() == self.G and pfc_w.is_contiguous() and pfc_w.shape == (NLABELS, 180) and pfc_b.numel() == NLABELS
+        check(lib().cz_search_expand_backup_fc(self.ctx.h, _ptr(z), _ptr(value), _ptr(pfc_w), _ptr(pfc_b)), "cz_search_expand_backup_fc")
+
     def root_stats(self):
         G, dev = self.G, self.dev
         out = dict(label=torch.empty((G, MAXMOVES), dtype=torch.int16, device=dev),
@@ -166,8 +175,15 @@ class SearchEngine:
     # -- the hot loop ------------------------------------------------------------------------------
     def step(self, forward, mode=1, active=None):
         """One lock-step simulation for every tree: select -> forward(planes) -> expand_backup.
-        `forward` maps the device planes tensor to (logits [G,2086], value [G,1]) device tensors."""
+        `forward` maps the device planes tensor to (logits [G,2086], value [G,1]) device tensors; if it is a
+        PolicyValueNet with the fused hip backend (has `search_eval`) and width is 1, the policy FC is evaluated
+        inside the expansion for the legal moves only (expand_backup_fc) and no logits tensor exists at all."""
         planes, _ = self.select(mode, active)
+        net = getattr(forward, "__self__", forward)
+        if self.width == 1 and getattr(net, "search_eval", None) is not None and net.fused_search:
+            z, value = net.search_eval(planes)
+            self.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32)
+            return
         logits, value = forward(planes)
         self.expand_backup(logits, value)
 

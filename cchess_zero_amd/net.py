@@ -148,6 +148,7 @@ class PolicyValueNet:
         self._ctx = ctx
         self._bufs = None
         self.conv_events = None  # set to a list to collect (start, end) HIP events around each conv launch
+        self.fuse_policy_fc = True  # search loop: policy FC for the legal moves only, inside the expansion kernel
         self.refresh()
 
     @torch.no_grad()
@@ -203,6 +204,8 @@ class PolicyValueNet:
                 return w.view(66, 32, 12, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
             self.hip_pfc_hi, self.hip_pfc_lo = frag(hi), frag(lo)
             self.hip_pfc_b = m.policy_fc.bias.float().contiguous()
+            self.pfc_w_rows = m.policy_fc.weight.float().contiguous()   # [2086,180]: rows the expansion kernel gathers
+            self.pfc_b_f32 = self.hip_pfc_b
             self.hip_v1_wt = m.value_fc1.weight.float().t().contiguous()      # [90,256]
             self.hip_v1_b = m.value_fc1.bias.float().contiguous()
             self.hip_v2_w = m.value_fc2.weight.float().reshape(-1).contiguous()  # [256]
@@ -387,6 +390,25 @@ class PolicyValueNet:
                                     vp(self.hip_v1_wt), vp(self.hip_v1_b), vp(self.hip_v2_w), vp(self.hip_v2_b),
                                     vp(logits), vp(value), B), "cz_fc_heads_f32")
         return logits, value
+
+    @property
+    def fused_search(self):
+        """True when the search loop may skip the full policy FC (SearchEngine.step -> expand_backup_fc)."""
+        return self.backend == "hip" and self.res_block_nums >= 1 and self.fuse_policy_fc
+
+    @torch.no_grad()
+    def search_eval(self, planes):
+        """Device planes -> (z [B,90,3] f32 head-conv outputs, value [B,1] f32): what the search needs when the policy
+        FC is evaluated inside the expansion kernel (cz_search_expand_backup_fc)."""
+        import ctypes as C
+        from ._lib import check, lib
+        z = self._hip_net_forward(planes)
+        B = z.shape[0]
+        value = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        check(lib().cz_fc_heads_f32(self._hip_ctx().h, vp(z), None, None, None, vp(self.hip_v1_wt), vp(self.hip_v1_b),
+                                    vp(self.hip_v2_w), vp(self.hip_v2_b), None, vp(value), B), "cz_fc_heads_f32")
+        return z, value
 
     @torch.no_grad()
     def forward_device(self, planes):

@@ -118,6 +118,15 @@ int cz_search_select(cz_ctx *, int mode, const uint8_t *active, void *leaf_plane
  *   back_up_value (:189-194) along the unwind (:426-435), including the float32 effect of the
  *   virtual-loss add/remove (:403-404,426-427).  logits [G][2086], value [G] of `dtype`. */
 int cz_search_expand_backup(cz_ctx *, const void *logits, const void *value, int dtype);
+
+/* cz_search_expand_backup with the policy FC (policy_value_network.py:62-63) folded in: instead of a full logits row
+ * per tree it takes the head-conv outputs z [G][90][3] f32 (cz_net_trunk_*), the FC weight pfc_w [2086][180] f32
+ * (row = label, torch / "out,in" layout; the reference stores [in,out]) and bias pfc_b [2086], and evaluates the FC
+ * only for the <= 128 labels each expansion reads (leaf_node.expand gathers action_probs[label2i[move]], main.py:
+ * 179-183).  The float32 evaluation order of the 180-term dot product is fixed and documented at k_expand_backup
+ * (cz_search.hip) so that a CPU restatement reproduces the priors bit for bit (tests/test_hip_search.py).
+ * value [G] f32.  Pairs with cz_search_select (one simulation per tree). */
+int cz_search_expand_backup_fc(cz_ctx *, const float *z, const float *value, const float *pfc_w, const float *pfc_b);
 /* k simulations in flight per tree and step, with the reference's virtual loss (N += 3, W -= 3 while in flight):
  * replaces the `search_threads` coroutines of MCTS_tree (asyncio.Semaphore(search_threads), main.py:250,337-348,
  * virtual loss :231,403-404,426-427, now_expanding :354-360).  cz_search_set_width sizes the pending-leaf arrays

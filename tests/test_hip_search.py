@@ -109,3 +109,70 @@ def test_pool_exhaustion_is_reported():
         lg, v = fwd(p)
         hip.expand_backup(lg, v)
     assert np.all(hip.status() & 1)  # CZ_ST_POOL_EXHAUSTED, trees parked, no crash
+
+
+def _fc_logits_restated(z, w, b):
+    """The arithmetic k_expand_backup<FC> documents (cz_search.hip), restated in NumPy float32 for ALL labels:
+    products p[k] = w[k] * x[k] (x = the (h,w,c) flatten of the two policy channels, padded to 192 with zeros);
+    16 partial sums of 12 consecutive products each, added in order; four symmetric folding steps; + bias.
+    z [G,90,3], w [2086,180], b [2086] -> [G,2086] float32."""
+    G = z.shape[0]
+    x = np.zeros((G, 192), np.float32)
+    x[:, :180] = z[:, :, :2].reshape(G, 180)
+    wp = np.zeros((2086, 192), np.float32)
+    wp[:, :180] = w
+    p = (wp[None, :, :] * x[:, None, :]).astype(np.float32).reshape(G, 2086, 16, 12)
+    s = p[..., 0].copy()
+    for k in range(1, 12):
+        s = (s + p[..., k]).astype(np.float32)
+    l = np.arange(16)
+    for partner in (15 - l, (l & 8) | (7 - (l & 7)), (l & 12) | (3 - (l & 3)), l ^ 1):
+        s = (s + s[..., partner]).astype(np.float32)
+    return (s[..., 0] + b[None, :].astype(np.float32)).astype(np.float32)
+
+
+def test_expand_with_folded_policy_fc_vs_oracle(rules_golden):
+    """cz_search_expand_backup_fc (policy FC evaluated inside the expansion, legal moves only) against the oracle
+    fed with the full logits of the same FC restated in NumPy float32: whole trees bit-identical."""
+    from oracle import oracle as O
+    g = rules_golden
+    ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
+    idx = np.nonzero(ok)[0][::13][:192]
+    G = len(idx)
+    boards, side = g["boards"][idx], g["side"][idx]
+    rr = (np.arange(G) * 5 % 50).astype(np.int32)
+    hip = _HipEngine(G, 20000)
+    orc = O.Search(G, 20000)
+    hip.reset(boards, side, rr)
+    orc.reset(boards, side, rr)
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal((2086, 180)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(2086) * 0.2).astype(np.float32)
+    wd, bd = torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda()
+    for ply in range(2):
+        for step in range(41):
+            m = 0 if step == 0 else 1
+            hp, hn = hip.select(m)
+            op, on = orc.select(m)
+            assert np.array_equal(hn, on) and np.array_equal(hp, op), (ply, step)
+            # a "net": z and value are deterministic functions of the leaf planes
+            feat = op.reshape(G, -1).astype(np.float32)
+            z = np.maximum(0, (feat[:, :270] * 0.7 + feat[:, 270:540] * 0.31 + feat[:, 540:810] * 0.05 - 0.2)).astype(np.float32).reshape(G, 90, 3)
+            z = (z + (feat.sum(axis=1, keepdims=True) % 7).astype(np.float32)[:, :, None] * 0.01).astype(np.float32)
+            value = np.tanh(feat[:, ::9].sum(axis=1, keepdims=True) * 0.01 - 1.0).astype(np.float32)
+            hip.e.expand_backup_fc(torch.from_numpy(z).cuda(), torch.from_numpy(value).cuda(), wd, bd)
+            orc.expand_backup(_fc_logits_restated(z, w, b), value)
+        hs, os_ = hip.root_stats(), orc.root_stats()
+        for k in ("label", "N", "count"):
+            assert np.array_equal(hs[k], os_[k]), (ply, k)
+        for k in ("Q", "P", "W"):
+            assert np.array_equal(hs[k].view(np.uint32), os_[k].view(np.uint32)), (ply, k)
+        for t in range(0, G, 11):
+            assert np.array_equal(hip.tree_dump(t), orc.tree_dump(t)), (ply, t)
+        played = np.full(G, 0xFFFF, np.uint16)
+        for t in range(G):
+            n = int(os_["count"][t])
+            if n:
+                played[t] = os_["label"][t, int(np.argmax(os_["N"][t, :n]))]
+        hip.advance(played)
+        orc.advance(played)
