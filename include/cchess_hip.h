@@ -122,8 +122,8 @@ int cz_search_expand_backup(cz_ctx *, const void *logits, const void *value, int
 /* cz_search_expand_backup with the policy FC (policy_value_network.py:62-63) folded in: instead of a full logits row
  * per tree it takes the head-conv outputs z [G][90][3] f32 (cz_net_trunk_*), the FC weight pfc_w [2086][180] f32
  * (row = label, torch / "out,in" layout; the reference stores [in,out]) and bias pfc_b [2086], and evaluates the FC
- * only for the <= 128 labels each expansion reads (leaf_node.expand gathers action_probs[label2i[move]], main.py:
- * 179-183).  The float32 evaluation order of the 180-term dot product is fixed and documented at k_expand_backup
+ * only for the <= 128 labels each expansion reads (leaf_node.expand gathers action_probs[label2i[action]], main.py:
+ * 179-181).  The float32 evaluation order of the 180-term dot product is fixed and documented at k_expand_backup
  * (cz_search.hip) so that a CPU restatement reproduces the priors bit for bit (tests/test_hip_search.py).
  * value [G] f32.  Pairs with cz_search_select (one simulation per tree). */
 int cz_search_expand_backup_fc(cz_ctx *, const float *z, const float *value, const float *pfc_w, const float *pfc_b);
