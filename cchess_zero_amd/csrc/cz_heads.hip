@@ -24,7 +24,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int PFC_K = 180, PFC_KB = 12;      // 12 k-blocks of 16 (K padded to 192)
+constexpr int PFC_KB = 12;                   // K = 180 inputs padded to 12 k-blocks of 16
 constexpr int PFC_N = CZ_NLABELS;            // 2086
 constexpr int PFC_LT = (PFC_N + 31) / 32;    // 66 label tiles of 32
 constexpr int PFC_WAVES = 4;

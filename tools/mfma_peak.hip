@@ -1,6 +1,6 @@
 // tools/mfma_peak.hip — what the MFMA pipe sustains on this chip with nothing else going on:
 // back-to-back v_mfma_f32_32x32x16_bf16 on 12 independent accumulators, operands in registers.
-// args: waves_per_simd(1|2) iters zero_data(0|1)
+// args: waves_per_simd(1|2) iters data(0 = random bf16, 1 = zeros, 2 = random with half the elements zero)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&src, 1024 * 16)); CK(hipMalloc(&dst, 4096 * 512 * 4));
     unsigned short h[8192];
     srand(1);
-    for (int i = 0; i < 8192; ++i) h[i] = zero ? 0 : (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
+    for (int i = 0; i < 8192; ++i) h[i] = (zero == 1 || (zero == 2 && (rand() & 1))) ? 0 : (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
     CK(hipMemcpy(src, h, sizeof h, hipMemcpyHostToDevice));
     const int grid = 256 * 4, threads = 256 * wps;   // 4 rounds of one workgroup per CU
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
