@@ -100,6 +100,21 @@ def slab8(H):
     return L
 
 
+def slabQ(hs):
+    """Two-workgroups-per-CU variant (k_tower2x_c128): 8 KB slabs = 2 k-steps (32 input channels), 4 per tap.
+    k0: f0 -> loads f1 (k1) ; vmcnt(2) + barrier ; k1: f1 -> f0 (k0 of the next slab; the next tap's addresses after
+    the fourth slab) + 2 DMA pieces."""
+    nab, nkey = ("nab", "nkey") if hs == 3 else ("ab", "key")
+    L = ["s_mov_b32 %[keep], m0"]
+    L += kstep2("f0", "f1", hs * 4 + 2, 4096, 4608, "ab", "key", "vb")
+    L += ["s_waitcnt vmcnt(2)", "s_barrier"]
+    dma = [["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"], [],
+           ["s_add_u32 m0, %[ldst], 0x1000", "s_nop 0", "global_load_lds_dwordx4 %[voff1], %[sbase]"], [], [], []]
+    L += kstep2("f1", "f0", ((hs + 1) % 4) * 4, 0, 512, nab, nkey, "vbn", dma)
+    L += ["s_mov_b32 m0, %[keep]"]
+    return L
+
+
 ACCP = [["p%d%d" % (i, j) for j in range(4)] for i in range(3)]
 
 
@@ -174,6 +189,9 @@ def main():
     txt += "\n// the same with fp16 operands\n"
     f16 = lambda L: [l.replace("v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16") for l in L]
     txt += emit("TW8F_SLAB_ASM_H0", f16(slab8(0))) + "\n" + emit("TW8F_SLAB_ASM_H1", f16(slab8(1)))
+    txt += "\n// two-workgroups-per-CU variant (2 positions / 4 waves, 8 KB slabs), bf16 and fp16\n"
+    for hs in range(4):
+        txt += emit("TW2_SLAB_ASM_Q%d" % hs, slabQ(hs)) + "\n" + emit("TW2F_SLAB_ASM_Q%d" % hs, f16(slabQ(hs))) + "\n"
     txt += "\n// position-per-wave variant (4 waves, 3 cell tiles x 4 channel tiles each, two fragment sets)\n"
     txt += emit("TWP_SLAB_ASM_H0", slabP(0)) + "\n" + emit("TWP_SLAB_ASM_H1", slabP(1))
     txt += "\n" + emit("TWP_SLAB_ASM_FIRST", slabP(0, first=True))
