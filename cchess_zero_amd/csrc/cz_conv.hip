@@ -28,16 +28,16 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
     if (B == 0) return CZ_OK;
     if (!c->tower_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerp_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower2x_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower2x_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
         c->tower_attr_set = true;
     }
     // CCHESS_TOWER_VARIANT: "4w" = 2 positions / 4 waves (k_tower_c128), "8w" = 4 positions / 8 waves
     // (k_tower8_c128), "pw" = 4 positions, one per wave (k_towerp_c128), "2x" = two workgroups of 2 positions / 4 waves
-    // per CU (k_tower2x_c128); default: see kDefaultVariant
+    // per CU (k_tower8_c128<.., 2>); default: see kDefaultVariant
     static const int variant = [] {
         const char *e = getenv("CCHESS_TOWER_VARIANT");
         if (e && e[0] == '4') return 0;
@@ -49,16 +49,16 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
     if (variant == 3) {
         const int grid = (B + T2_P - 1) / T2_P;
         if (f16)
-            hipLaunchKernelGGL(k_tower2x_c128<true>, dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
+            hipLaunchKernelGGL((k_tower8_c128<true, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
                                (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                                (const uint16_t *)w0, b0, B, 2 * nblocks);
         else
-            hipLaunchKernelGGL(k_tower2x_c128<false>, dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
+            hipLaunchKernelGGL((k_tower8_c128<false, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
                                (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                                (const uint16_t *)w0, b0, B, 2 * nblocks);
     } else if (f16) {   // fp16 operands: the 8-wave kernel (or 2x above)
         const int grid = (B + T8_P - 1) / T8_P;
-        hipLaunchKernelGGL(k_tower8_c128<true>, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
+        hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
     } else if (variant == 0) {
@@ -68,7 +68,7 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
     } else if (variant == 1) {
         const int grid = (B + T8_P - 1) / T8_P;
-        hipLaunchKernelGGL(k_tower8_c128<false>, dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
+        hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
     } else {

@@ -577,14 +577,27 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
 //           the next k-step.
 //   weights same 4-deep ring of 16 KB slabs by LDS-DMA, 2 pieces per wave and slab, counted vmcnt(2).
 //   layer   main loop -> s_barrier (all reads of U done) -> epilogue writes U in place -> s_barrier.
+// P = 2 ("2x", k_tower8_c128<F16, 2>): the same per-wave structure with 2 positions / 4 waves / 77 KB of LDS per workgroup and
+// TWO workgroups per CU.  In the P = 4 kernel all eight waves of a CU run in lock step (they share one weight ring), so
+// the MFMA pipes idle during a layer's epilogue and barriers; two workgroups with private rings (four 8 KB slabs) drift
+// apart on their own and cover for each other.  The price is the weight stream per position, which doubles.
 // =================================================================================================
-constexpr int T8_P = 4;
-constexpr int T8_ROWS = T8_P * 90;                  // 360 cells = 11.25 row tiles -> 12 (24 rows padding)
-constexpr int T8_THREADS = 512;
-constexpr int T8_ZERO_OFF = T8_ROWS * CV_ROWB;      // 92,160
-constexpr int T8_W_OFF = T8_ZERO_OFF + CV_ROWB;     // 92,416
-constexpr int T8_LDS_BYTES = T8_W_OFF + TW_NBUF * TW_SLAB_BYTES;   // 157,952
-constexpr int T8_PLANES_OFF = T8_W_OFF + 3 * TW_SLAB_BYTES;        // input planes borrow ring buffer 3
+// Geometry of the kernel for P positions per workgroup (P = 4: eight waves, one workgroup per CU, 16 KB slabs;
+// P = 2: four waves, TWO workgroups per CU with private rings of 8 KB slabs, see the comment at the kernel).
+template <int P> struct T8Geo {
+    static constexpr int ROWS = P * 90;                        // 360 cells -> 12 row tiles of 32; 180 -> 6
+    static constexpr int THREADS = P * 128;                    // 2 waves per position: 3 x 2 accumulator tiles each
+    static constexpr int SLAB_BYTES = P == 4 ? 64 * 128 * 2 : 32 * 128 * 2;   // 64 / 32 input channels of one tap
+    static constexpr int SLAB_SHIFT = P == 4 ? 14 : 13;
+    static constexpr int SLABS_PER_LAYER = 9 * 128 * 128 * 2 / SLAB_BYTES;    // 18 / 36
+    static constexpr int ZERO_OFF = ROWS * CV_ROWB;            // 92,160 / 46,080
+    static constexpr int W_OFF = ZERO_OFF + CV_ROWB;
+    static constexpr int LDS_BYTES = W_OFF + TW_NBUF * SLAB_BYTES;            // 157,952 / 79,104
+    static constexpr int PLANES_OFF = W_OFF + 3 * SLAB_BYTES;  // the input planes (32 B per cell) borrow ring buffer 3
+};
+constexpr int T8_P = 4, T8_THREADS = T8Geo<4>::THREADS, T8_LDS_BYTES = T8Geo<4>::LDS_BYTES;
+constexpr int T8_ROWS = T8Geo<4>::ROWS, T8_ZERO_OFF = T8Geo<4>::ZERO_OFF, T8_W_OFF = T8Geo<4>::W_OFF, T8_PLANES_OFF = T8Geo<4>::PLANES_OFF;
+constexpr int T2_P = 2, T2_THREADS = T8Geo<2>::THREADS, T2_LDS_BYTES = T8Geo<2>::LDS_BYTES;
 
 // Element type of activations and weights: bf16 (F16 = false) or IEEE fp16 (F16 = true, the reference's
 // "19-block fp16" configuration); accumulation is fp32 either way and only the MFMA opcode, the pack / unpack
@@ -604,8 +617,8 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <bool F16>
-__global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *__restrict__ in,
+template <bool F16, int P>
+__global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__restrict__ in,
                                                                const uint16_t *__restrict__ wpk,
                                                                const float *__restrict__ bias,
                                                                uint16_t *__restrict__ out,
@@ -617,29 +630,30 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
                                                                const float *__restrict__ b0,
                                                                int B, int nlayers) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Geo = T8Geo<P>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int pos0 = blockIdx.x * T8_P;
-    const int npos = (B - pos0) < T8_P ? (B - pos0) : T8_P;
+    const int pos0 = blockIdx.x * P;
+    const int npos = (B - pos0) < P ? (B - pos0) : P;
     const int nrows = npos * 90;
-    const int nslabs = nlayers * 18;
+    const int nslabs = nlayers * Geo::SLABS_PER_LAYER;
     auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
-    const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + 8192u;
+    const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + (unsigned)Geo::THREADS * 16u;   // second DMA piece of a slab
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * TW_SLAB_BYTES;
-        unsigned char *dst = smem + T8_W_OFF + ((unsigned)slab & 3u) * TW_SLAB_BYTES + (wave_u << 10);
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * Geo::SLAB_BYTES;
+        unsigned char *dst = smem + Geo::W_OFF + ((unsigned)slab & 3u) * Geo::SLAB_BYTES + (wave_u << 10);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff0),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff1),
-                                         (__attribute__((address_space(3))) void *)(dst + 8192), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(dst + Geo::THREADS * 16), 16, 0, 0);
     };
     for (int q = 0; q < 3; ++q) dma_slab(q < nslabs ? q : nslabs - 1);
     if (planes == nullptr) {
         const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
-        for (int idx = tid; idx < T8_ROWS * 16; idx += T8_THREADS) {
+        for (int idx = tid; idx < Geo::ROWS * 16; idx += Geo::THREADS) {
             const int r = idx >> 4, c = idx & 15;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < nrows) v = g[idx];
@@ -647,13 +661,13 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
         }
     } else {
         const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
-        for (int idx = tid; idx < T8_ROWS * 2; idx += T8_THREADS) {
+        for (int idx = tid; idx < Geo::ROWS * 2; idx += Geo::THREADS) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (idx < nrows * 2) v = g[idx];
-            *reinterpret_cast<uint4 *>(smem + T8_PLANES_OFF + (idx << 4)) = v;
+            *reinterpret_cast<uint4 *>(smem + Geo::PLANES_OFF + (idx << 4)) = v;
         }
     }
-    if (tid < 16) *reinterpret_cast<uint4 *>(smem + T8_ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + Geo::ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -666,7 +680,7 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
         int m = 0;
         for (int t = 0; t < 9; ++t) {
             const int y = h + t / 3 - 1, x = w + t % 3 - 1;
-            if (r < T8_ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+            if (r < Geo::ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
         }
         tapmask[i] = m;
     }
@@ -674,12 +688,12 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
         const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
-            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : T8_ZERO_OFF;
+            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : Geo::ZERO_OFF;
             ab[i] = a;
             key[i] = ((a >> 8) & 15) ^ khalf;
         }
     };
-    const int vb0 = T8_W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);
+    const int vb0 = Geo::W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);
     int keep;
 
     // the cells / channel quads this lane owns in the accumulator layout
@@ -690,12 +704,12 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
             const int r = 32 * (wr * CV_RT + i) + l31;
-            rb[i] = (r < T8_ROWS ? r : 0) * CV_ROWB;
+            rb[i] = (r < Geo::ROWS ? r : 0) * CV_ROWB;
             asm volatile("" : "+v"(rb[i]));
         }
     };
     auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
-        live = 32 * (wr * CV_RT + i) + l31 < T8_ROWS;
+        live = 32 * (wr * CV_RT + i) + l31 < Geo::ROWS;
         const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
         return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
     };
@@ -756,7 +770,7 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
             bf16x8 af[CV_RT];
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) {
-                const int a = ((tapmask[i] >> t) & 1) ? T8_PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : T8_ZERO_OFF;
+                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : Geo::ZERO_OFF;
                 af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
             }
 #pragma unroll
@@ -783,300 +797,14 @@ __global__ __launch_bounds__(T8_THREADS, 2) void k_tower8_c128(const uint16_t *_
               [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst)                                                \
             : "memory")
 #define T8_SLAB_ARGS()                                                                                          \
-        const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);         \
+        const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << Geo::SLAB_SHIFT); \
         const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                     \
-        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * TW_SLAB_BYTES;  \
-        const int ldst = T8_W_OFF + ((((unsigned)g + 3u) & 3u) << 14) + (wave_u << 10);
-
-    int g = 0;
-#pragma unroll 1
-    for (int layer = 0; layer < nlayers; ++layer) {
-        f32x16 acc[CV_RT][CV_CT];
-        refresh_rb();
-        if (!(layer & 1)) {   // first conv of a block: remember x, start from the bias
-#pragma unroll
-            for (int i = 0; i < CV_RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { bool live; xreg[i][j][q] = *cell_ptr(i, j, q, live); }
-            init_acc(acc, bias + layer * 128, false);
-        } else {
-            init_acc(acc, bias + layer * 128, true);
-        }
-        int ab[CV_RT], key[CV_RT], nab[CV_RT], nkey[CV_RT], t0, t1, t2;
-        TwFrag f0, f1;
-        tap_addr(0, ab, key);
-        {
-            const int vb = vb0 + (((unsigned)g & 3u) << 14);
-            TW_LOADSET(0, 0, 512, f0, ab, key, vb);   // waited for by the first k-step itself
-        }
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            {
-                T8_SLAB_ARGS()
-                if constexpr (F16) { T8_SLAB(TW8F_SLAB_ASM_H0, ab, key); } else { T8_SLAB(TW8_SLAB_ASM_H0, ab, key); }
-                ++g;
-            }
-            {
-                tap_addr(tap + 1, nab, nkey);
-                T8_SLAB_ARGS()
-                if constexpr (F16) { T8_SLAB(TW8F_SLAB_ASM_H1, nab, nkey); } else { T8_SLAB(TW8_SLAB_ASM_H1, nab, nkey); }
-#pragma unroll
-                for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
-                ++g;
-            }
-        }
-        // the last k-step prefetched garbage for a non-existent next slab; drain it, let the MFMAs retire, and make
-        // sure every wave is done reading U before anyone overwrites it in place
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        __syncthreads();
-        refresh_rb();
-        store_layer(acc);
-        __syncthreads();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (out) {
-        uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
-        for (int idx = tid; idx < nrows * 16; idx += T8_THREADS) {
-            const int r = idx >> 4, c = idx & 15;
-            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(r * CV_ROWB, c));
-        }
-    }
-    if (head_out) {
-        __syncthreads();
-        float *hw = reinterpret_cast<float *>(smem + T8_W_OFF);
-        for (int i = tid; i < 3 * 128; i += T8_THREADS) hw[i] = head_w[i];
-        __syncthreads();
-        for (int idx = tid; idx < nrows * 3; idx += T8_THREADS) {
-            const int r = idx / 3, c3 = idx - r * 3;
-            const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
-            const float *w = hw + c3 * 128;
-            float acc = 0.f;
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int p = (it + tid) & 15;
-                const int c = p ^ key;
-                const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
-                const float *wc8 = w + c * 8;
-                const f32x2 e0 = unpack_pair<F16>(v.x), e1 = unpack_pair<F16>(v.y), e2 = unpack_pair<F16>(v.z), e3 = unpack_pair<F16>(v.w);
-                acc += e0[0] * wc8[0] + e0[1] * wc8[1] + e1[0] * wc8[2] + e1[1] * wc8[3]
-                     + e2[0] * wc8[4] + e2[1] * wc8[5] + e3[0] * wc8[6] + e3[1] * wc8[7];
-            }
-            head_out[((size_t)pos0 * 90 + r) * 3 + c3] = fmaxf(acc + head_b[c3], 0.f);
-        }
-    }
-}
-#undef T8_SLAB
-#undef T8_SLAB_ARGS
-
-// =================================================================================================
-// k_tower2x_c128: TWO independent workgroups per CU (2 positions / 4 waves each, 77 KB of LDS each).
-//
-// In k_tower8_c128 all eight waves of a CU run in lock step (they share one weight ring), so while a layer's
-// epilogue (accumulators -> 16 bit -> LDS, 10 % of the time) or a barrier is in progress the MFMA pipes idle.
-// Two smaller workgroups with private rings drift apart on their own: the SIMD's second wave belongs to the
-// other workgroup and keeps issuing MFMAs while this one is in its epilogue.  Same per-wave structure as the 8-wave
-// kernel (3 x 2 accumulator tiles, one activation buffer updated in place, block input x in registers); the price
-// is the weight stream per position, which doubles again (each workgroup streams every layer for 2 positions).
-// Ring: four 8 KB slabs (32 input channels of one tap = 2 k-steps), DMA two slabs ahead, one barrier per slab.
-// =================================================================================================
-constexpr int T2_P = 2;
-constexpr int T2_ROWS = T2_P * 90;                  // 180 cells = 5.6 row tiles -> 6 (12 rows padding)
-constexpr int T2_THREADS = 256;
-constexpr int T2_SLAB_BYTES = 32 * 128 * 2;        // 32 input channels of one tap: 8 KB
-constexpr int T2_ZERO_OFF = T2_ROWS * CV_ROWB;      // 46,080
-constexpr int T2_W_OFF = T2_ZERO_OFF + CV_ROWB;     // 46,336
-constexpr int T2_LDS_BYTES = T2_W_OFF + TW_NBUF * T2_SLAB_BYTES;   // 79,104: two workgroups per CU
-constexpr int T2_PLANES_OFF = T2_W_OFF + 3 * T2_SLAB_BYTES;        // input planes (5.8 KB) borrow ring buffer 3
-
-template <bool F16>
-__global__ __launch_bounds__(T2_THREADS, 2) void k_tower2x_c128(const uint16_t *__restrict__ in,
-                                                               const uint16_t *__restrict__ wpk,
-                                                               const float *__restrict__ bias,
-                                                               uint16_t *__restrict__ out,
-                                                               const float *__restrict__ head_w,
-                                                               const float *__restrict__ head_b,
-                                                               float *__restrict__ head_out,
-                                                               const uint16_t *__restrict__ planes,
-                                                               const uint16_t *__restrict__ w0,
-                                                               const float *__restrict__ b0,
-                                                               int B, int nlayers) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const int pos0 = blockIdx.x * T2_P;
-    const int npos = (B - pos0) < T2_P ? (B - pos0) : T2_P;
-    const int nrows = npos * 90;
-    const int nslabs = nlayers * 36;
-    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
-    const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + 4096u;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * T2_SLAB_BYTES;
-        unsigned char *dst = smem + T2_W_OFF + ((unsigned)slab & 3u) * T2_SLAB_BYTES + (wave_u << 10);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff0),
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff1),
-                                         (__attribute__((address_space(3))) void *)(dst + 4096), 16, 0, 0);
-    };
-    for (int q = 0; q < 3; ++q) dma_slab(q < nslabs ? q : nslabs - 1);
-    if (planes == nullptr) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
-        for (int idx = tid; idx < T2_ROWS * 16; idx += T2_THREADS) {
-            const int r = idx >> 4, c = idx & 15;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < nrows) v = g[idx];
-            *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
-        }
-    } else {
-        const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
-        for (int idx = tid; idx < T2_ROWS * 2; idx += T2_THREADS) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < nrows * 2) v = g[idx];
-            *reinterpret_cast<uint4 *>(smem + T2_PLANES_OFF + (idx << 4)) = v;
-        }
-    }
-    if (tid < 16) *reinterpret_cast<uint4 *>(smem + T2_ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int rowb[CV_RT], tapmask[CV_RT];
-#pragma unroll
-    for (int i = 0; i < CV_RT; ++i) {
-        const int r = 32 * (wr * CV_RT + i) + l31;
-        const int pix = r % 90, h = pix / 10, w = pix - h * 10;
-        rowb[i] = r * CV_ROWB;
-        int m = 0;
-        for (int t = 0; t < 9; ++t) {
-            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
-            if (r < T2_ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
-        }
-        tapmask[i] = m;
-    }
-    auto tap_addr = [&](int tap, int (&ab)[CV_RT], int (&key)[CV_RT]) {
-        const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
-#pragma unroll
-        for (int i = 0; i < CV_RT; ++i) {
-            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : T2_ZERO_OFF;
-            ab[i] = a;
-            key[i] = ((a >> 8) & 15) ^ khalf;
-        }
-    };
-    const int vb0 = T2_W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);
-    int keep;
-
-    // the cells / channel quads this lane owns in the accumulator layout
-    // 24 swizzled addresses per lane: recomputed from an opaque copy of the row offset wherever they are needed
-    // (hoisted out of the layer loop they are only spilled to scratch)
-    int rb[CV_RT];
-    auto refresh_rb = [&]() {
-#pragma unroll
-        for (int i = 0; i < CV_RT; ++i) {
-            const int r = 32 * (wr * CV_RT + i) + l31;
-            rb[i] = (r < T2_ROWS ? r : 0) * CV_ROWB;
-            asm volatile("" : "+v"(rb[i]));
-        }
-    };
-    auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
-        live = 32 * (wr * CV_RT + i) + l31 < T2_ROWS;
-        const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
-        return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
-    };
-    // acc = bias (+ x): the residual is folded into the initialisation of a block's second conv
-    uint2 xreg[CV_RT][CV_CT][4];   // block input x at this lane's accumulator positions (packed bf16)
-    auto init_acc = [&](f32x16 (&acc)[CV_RT][CV_CT], const float *bl, bool add_x) {
-#pragma unroll
-        for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bq = *reinterpret_cast<const float4 *>(bl + wc * 64 + j * 32 + 8 * q + 4 * khalf);
-#pragma unroll
-                for (int i = 0; i < CV_RT; ++i) {
-                    float a0 = bq.x, a1 = bq.y, a2 = bq.z, a3 = bq.w;
-                    if (add_x) {
-                        const uint2 x = xreg[i][j][q];
-                        const f32x2 xl = unpack_pair<F16>(x.x), xh = unpack_pair<F16>(x.y);
-                        a0 += xl[0]; a1 += xl[1]; a2 += xh[0]; a3 += xh[1];
-                    }
-                    acc[i][j][4 * q + 0] = a0; acc[i][j][4 * q + 1] = a1; acc[i][j][4 * q + 2] = a2; acc[i][j][4 * q + 3] = a3;
-                }
-            }
-    };
-    // ReLU -> bf16 -> U, in place (callers put a barrier in front: every wave must be done reading U)
-    auto store_layer = [&](f32x16 (&acc)[CV_RT][CV_CT]) {
-#pragma unroll
-        for (int i = 0; i < CV_RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bool live;
-                    uint2 *cell = cell_ptr(i, j, q, live);
-                    // ReLU after the rounding, as a packed signed-16-bit max with 0: a bf16 / fp16 is negative exactly when
-                    // its bit pattern is a negative int16 and RNE never changes the sign, so the result is the same
-                    // as relu-then-round at a quarter of the VALU work (no v_max_f32 + canonicalize per element)
-                    const s16x2 z = {0, 0};
-                    const s16x2 rl = __builtin_elementwise_max(
-                        __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]})), z);
-                    const s16x2 rh = __builtin_elementwise_max(
-                        __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]})), z);
-                    if (live) *cell = make_uint2(__builtin_bit_cast(uint32_t, rl), __builtin_bit_cast(uint32_t, rh));
-                }
-    };
-
-    if (planes != nullptr) {   // first layer: conv3x3(14 -> 128) + BN + ReLU, one k-step per tap
-        bf16x8 wf[9][CV_CT];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j)
-                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + khalf) * 128 + wc * 64 + j * 32 + l31) << 3));
-        f32x16 acc[CV_RT][CV_CT];
-        init_acc(acc, b0, false);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
-            bf16x8 af[CV_RT];
-#pragma unroll
-            for (int i = 0; i < CV_RT; ++i) {
-                const int a = ((tapmask[i] >> t) & 1) ? T2_PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : T2_ZERO_OFF;
-                af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < CV_RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CV_CT; ++j)
-                    acc[i][j] = mfma_32x32x16<F16>(wf[t][j], af[i], acc[i][j]);
-        }
-        refresh_rb();
-        store_layer(acc);    // U is not read by the first conv: no barrier needed in front
-        __syncthreads();
-    }
-
-#define T2_SLAB(ASMSTR, NAB, NKEY)                                                                               \
-        asm volatile(ASMSTR                                                                                      \
-            : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),          \
-              [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),                                                        \
-              [f0a0] "+v"(f0.a[0]), [f0a1] "+v"(f0.a[1]), [f0a2] "+v"(f0.a[2]), [f0b0] "+v"(f0.b[0]), [f0b1] "+v"(f0.b[1]), \
-              [f1a0] "=&v"(f1.a[0]), [f1a1] "=&v"(f1.a[1]), [f1a2] "=&v"(f1.a[2]), [f1b0] "=&v"(f1.b[0]), [f1b1] "=&v"(f1.b[1]), \
-              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [keep] "=&s"(keep)                                     \
-            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),          \
-              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
-              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
-              [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst)                                                \
-            : "memory")
-#define T2_SLAB_ARGS()                                                                                          \
-        const int vb = vb0 + (((unsigned)g & 3u) << 13), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 13);         \
-        const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                     \
-        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * T2_SLAB_BYTES;  \
-        const int ldst = T2_W_OFF + ((((unsigned)g + 3u) & 3u) << 13) + (wave_u << 10);
-#define T2_Q(N, NAB, NKEY)                                                                                      \
+        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * Geo::SLAB_BYTES; \
+        const int ldst = Geo::W_OFF + ((((unsigned)g + 3u) & 3u) << Geo::SLAB_SHIFT) + (wave_u << 10);
+#define T8_RUN(BF, HF, NAB, NKEY)                                                                               \
         {                                                                                                       \
-            T2_SLAB_ARGS()                                                                                      \
-            if constexpr (F16) { T2_SLAB(TW2F_SLAB_ASM_Q##N, NAB, NKEY); } else { T2_SLAB(TW2_SLAB_ASM_Q##N, NAB, NKEY); } \
+            T8_SLAB_ARGS()                                                                                      \
+            if constexpr (F16) { T8_SLAB(HF, NAB, NKEY); } else { T8_SLAB(BF, NAB, NKEY); }                     \
             ++g;                                                                                                \
         }
 
@@ -1100,16 +828,22 @@ __global__ __launch_bounds__(T2_THREADS, 2) void k_tower2x_c128(const uint16_t *
         TwFrag f0, f1;
         tap_addr(0, ab, key);
         {
-            const int vb = vb0 + (((unsigned)g & 3u) << 13);
+            const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT);
             TW_LOADSET(0, 0, 512, f0, ab, key, vb);   // waited for by the first k-step itself
         }
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            T2_Q(0, ab, key)
-            T2_Q(1, ab, key)
-            T2_Q(2, ab, key)
-            tap_addr(tap + 1, nab, nkey);
-            T2_Q(3, nab, nkey)
+            if constexpr (P == 4) {        // two 16 KB slabs per tap
+                T8_RUN(TW8_SLAB_ASM_H0, TW8F_SLAB_ASM_H0, ab, key)
+                tap_addr(tap + 1, nab, nkey);
+                T8_RUN(TW8_SLAB_ASM_H1, TW8F_SLAB_ASM_H1, nab, nkey)
+            } else {                       // four 8 KB slabs per tap
+                T8_RUN(TW2_SLAB_ASM_Q0, TW2F_SLAB_ASM_Q0, ab, key)
+                T8_RUN(TW2_SLAB_ASM_Q1, TW2F_SLAB_ASM_Q1, ab, key)
+                T8_RUN(TW2_SLAB_ASM_Q2, TW2F_SLAB_ASM_Q2, ab, key)
+                tap_addr(tap + 1, nab, nkey);
+                T8_RUN(TW2_SLAB_ASM_Q3, TW2F_SLAB_ASM_Q3, nab, nkey)
+            }
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
         }
@@ -1124,17 +858,17 @@ __global__ __launch_bounds__(T2_THREADS, 2) void k_tower2x_c128(const uint16_t *
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (out) {
         uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
-        for (int idx = tid; idx < nrows * 16; idx += T2_THREADS) {
+        for (int idx = tid; idx < nrows * 16; idx += Geo::THREADS) {
             const int r = idx >> 4, c = idx & 15;
             go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(r * CV_ROWB, c));
         }
     }
     if (head_out) {
         __syncthreads();
-        float *hw = reinterpret_cast<float *>(smem + T2_W_OFF);
-        for (int i = tid; i < 3 * 128; i += T2_THREADS) hw[i] = head_w[i];
+        float *hw = reinterpret_cast<float *>(smem + Geo::W_OFF);
+        for (int i = tid; i < 3 * 128; i += Geo::THREADS) hw[i] = head_w[i];
         __syncthreads();
-        for (int idx = tid; idx < nrows * 3; idx += T2_THREADS) {
+        for (int idx = tid; idx < nrows * 3; idx += Geo::THREADS) {
             const int r = idx / 3, c3 = idx - r * 3;
             const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
             const float *w = hw + c3 * 128;
@@ -1153,9 +887,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void k_tower2x_c128(const uint16_t *
         }
     }
 }
-#undef T2_SLAB
-#undef T2_SLAB_ARGS
-#undef T2_Q
+#undef T8_SLAB
+#undef T8_SLAB_ARGS
+#undef T8_RUN
 
 // =================================================================================================
 // k_towerp_c128: the one-launch net trunk with ONE POSITION PER WAVE (four waves, four positions per workgroup).
