@@ -11,6 +11,7 @@ int main(int argc, char **argv) {
     const int nblocks = argc > 2 ? atoi(argv[2]) : 7;
     const int iters = argc > 3 ? atoi(argv[3]) : 10;
     const int variant = argc > 4 ? atoi(argv[4]) : 8;   // 4 = 2 positions / 4 waves, 8 = 4 positions / 8 waves, 1 = 4 positions, one per wave, 2 = two workgroups of 2 positions per CU
+    const int zero = argc > 5 ? atoi(argv[5]) : 0;      // 1 = all-zero activations and weights (power experiment)
     const size_t n = (size_t)B * 90 * 128, nw = (size_t)2 * nblocks * 9 * 128 * 128;
     uint16_t *in, *out, *w; float *bias;
     CK(hipMalloc(&in, n * 2)); CK(hipMalloc(&out, n * 2)); CK(hipMalloc(&w, nw * 2)); CK(hipMalloc(&bias, 2 * nblocks * 128 * 4));
@@ -21,6 +22,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(in, h.data(), n * 2, hipMemcpyHostToDevice));
     for (size_t i = 0; i < nw; ++i) { s = s * 1664525u + 1013904223u; h[i] = (uint16_t)(0x3A00 + ((s >> 16) & 0x1FF) + ((s >> 31) << 15)); }
     CK(hipMemcpy(w, h.data(), nw * 2, hipMemcpyHostToDevice));
+    if (zero) { CK(hipMemset(in, 0, n * 2)); CK(hipMemset(w, 0, nw * 2)); }
     CK(hipMemset(bias, 0, 2 * nblocks * 128 * 4));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
