@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
     ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--search-threads", type=int, default=1, help="simulations in flight per tree and step (the reference's search_threads; virtual loss 3); batch = games * search_threads")
     ap.add_argument("--full-policy-fc", action="store_true", help="compute all 2086 logits per leaf (k_policy_fc) instead of folding the policy FC into the expansion")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 80: no tree can run out)")
     args = ap.parse_args()
@@ -159,9 +160,10 @@ def main():
     rules = Rules(ctx)
     # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
     fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16")
-    eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx)
+    K = max(1, args.search_threads)
+    eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx, width=K)
     net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
-    fused_fc = net.fused_search and not args.full_policy_fc
+    fused_fc = net.fused_search and not args.full_policy_fc and K == 1
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
     eng.reset(boards, side, rr)
 
@@ -190,7 +192,11 @@ def main():
         else:
             eng.expand_backup(logits, value)
 
+    banked = [0]   # simulations completed in plies that were closed inside the timed region (k > 1 accounting)
+
     def advance_ply():
+        if K > 1:
+            banked[0] += int(eng.status()[2].sum().item())
         st = eng.root_stats()
         n = st["N"].clone()
         cnt = (st["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
@@ -209,13 +215,16 @@ def main():
                 advance_ply()
                 sims_in_ply = 0
             one_step(1, timed)
-            sims_in_ply += 1
+            sims_in_ply += K
 
     one_step(0, False)          # MCTS_tree.main root expansion (not a simulation)
     run(args.warmup, False)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
+    torch.cuda.synchronize()
+    sims0 = int(eng.status()[2].sum().item()) if K > 1 else 0
+    banked[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps, True)
@@ -253,7 +262,13 @@ def main():
     st_bits = {name: int(((st & bit) != 0).sum().item()) for name, bit in
                (("pool_exhausted", 1), ("no_moves", 2), ("move_overflow", 4), ("bad_advance", 8))}
     net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net])) if ev_net else float("nan")
-    total_sims = float(G) * args.steps * world
+    if K == 1:
+        total_sims = float(G) * args.steps * world
+    else:   # descents that ran into a pending expansion are abandoned: count what was actually backed up
+        mine = torch.tensor([banked[0] + int(sims.sum().item()) - sims0], dtype=torch.float64, device=dev if (dist_on and args.dist_backend == "nccl") else "cpu")
+        if dist_on:
+            dist.all_reduce(mine)
+        total_sims = float(mine.item())
     flops = flops_per_position(args.blocks) * G
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     if conv_ev:
@@ -287,7 +302,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)" % (G, playout, args.blocks, args.dtype, cfg_name),
-                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits", "res_block_nums": args.blocks, "search_threads": 1,
+                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits", "res_block_nums": args.blocks, "search_threads": K,
                    "positions": "seeded random playouts from the start position, ply~U[0,80]",
                    "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),
                    "trees_with_error_status": bad, "status_bits": st_bits},
