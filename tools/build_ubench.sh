@@ -14,5 +14,7 @@ build nowstream -DCZ_ABL=16
 build mfmaonly -DCZ_ABL=27
 build_t() { tag=$1; shift; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" -o ubench/tower_$tag tower_ubench.hip & }
 build_t base
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o ubench/fc_base fc_ubench.hip &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o ubench/mfma_peak mfma_peak.hip &
 wait
 ls -la ubench
