@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--search-threads", type=int, default=1, help="simulations in flight per tree and step (the reference's search_threads; virtual loss 3); batch = games * search_threads")
+    ap.add_argument("--compact", action="store_true", help="compact evaluation batches: no net row for terminal / drawn leaves (no gain at 8192 trees: the trunk runs in rounds of 1024 rows)")
     ap.add_argument("--full-policy-fc", action="store_true", help="compute all 2086 logits per leaf (k_policy_fc) instead of folding the policy FC into the expansion")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 80: no tree can run out)")
     args = ap.parse_args()
@@ -164,6 +165,7 @@ def main():
     eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx, width=K)
     net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
     fused_fc = net.fused_search and not args.full_policy_fc and K == 1
+    compact = fused_fc and args.compact   # leaves that need no net evaluation are not in the net's batch
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
     eng.reset(boards, side, rr)
 
@@ -176,19 +178,23 @@ def main():
         # HIP events around every conv launch of every 8th timed step (same stream as the launches)
         net.conv_events = conv_ev if (timed and step_no[0] % 8 == 0) else None
         step_no[0] += 1
-        planes, _ = eng.select(mode)
+        n_rows = None
+        if compact:
+            planes, n_rows = eng.select_compact(mode)
+        else:
+            planes, _ = eng.select(mode)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if fused_fc:   # trunk + value head; the policy FC runs inside the expansion kernel for the legal moves only
-            z, value = net.search_eval(planes)
+            z, value = net.search_eval(planes, n_rows)
         else:
             logits, value = net.forward_device(planes)
         if timed:
             e1.record()
             ev_net.append((e0, e1))
         if fused_fc:
-            eng.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32)
+            eng.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32, compact=compact)
         else:
             eng.expand_backup(logits, value)
 
@@ -224,6 +230,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     sims0 = int(eng.status()[2].sum().item()) if K > 1 else 0
+    rows0, csteps0 = eng.eval_totals() if compact else (0, 0)
     banked[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -251,8 +258,9 @@ def main():
     traffic, traffic_src = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if (tj["config"] == {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype} and args.backend in ("auto", "hip")
-                and tj["kernel"] == tower_kernel):
+        want = {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype}
+        if ({k: tj["config"].get(k) for k in want} == want and bool(tj["config"].get("compact", False)) == bool(compact)
+                and args.backend in ("auto", "hip") and tj["kernel"] == tower_kernel):
             traffic = tj["traffic_bytes_per_launch"]
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; algorithmic bytes %d)" % tj["algorithmic_bytes_per_launch"]
     except Exception:
@@ -269,13 +277,18 @@ def main():
         if dist_on:
             dist.all_reduce(mine)
         total_sims = float(mine.item())
-    flops = flops_per_position(args.blocks) * G
+    # rows the net evaluated per launch: all G without compaction, else the measured mean over the timed region
+    rows_per_launch = float(G)
+    if compact:
+        rows1, csteps1 = eng.eval_totals()
+        rows_per_launch = (rows1 - rows0) / max(1, csteps1 - csteps0)
+    flops = flops_per_position(args.blocks) * rows_per_launch
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     if conv_ev:
         # dominant kernel: k_conv3x3_c128 (one launch = one fused tower layer over the whole batch)
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
         nl = 2 * args.blocks if net.backend == "hip" else 1   # fused tower: one launch = all 2*blocks conv layers
-        conv_flops = 2.0 * G * 90 * 1152 * 128 * nl
+        conv_flops = 2.0 * rows_per_launch * 90 * 1152 * 128 * nl
         kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv3x3+BN(+residual)+ReLU layers counted, LDS-resident activations, %s MFMA, fp32 acc)" % (nl, args.dtype)
                  if net.backend == "hip" else "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)")
         roof = {"bound": "mfma", "kernel": kname,
@@ -302,7 +315,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)" % (G, playout, args.blocks, args.dtype, cfg_name),
-                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits", "res_block_nums": args.blocks, "search_threads": K,
+                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits",
+                   "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "res_block_nums": args.blocks, "search_threads": K,
                    "positions": "seeded random playouts from the start position, ply~U[0,80]",
                    "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),
                    "trees_with_error_status": bad, "status_bits": st_bits},

@@ -38,7 +38,10 @@ _SIGS = {
     "cz_search_reset": (C.c_int, [C.c_void_p, _u8p, _u8p, _i32p, C.c_int]),
     "cz_search_select": (C.c_int, [C.c_void_p, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup": (C.c_int, [C.c_void_p, _vp, _vp, C.c_int]),
-    "cz_search_expand_backup_fc": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp]),
+    "cz_search_expand_backup_fc": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, C.c_int]),
+    "cz_search_select_compact": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "cz_set_batch_count": (C.c_int, [C.c_void_p, _vp]),
+    "cz_search_eval_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "cz_search_set_width": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_select_k": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup_k": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int]),

@@ -46,6 +46,9 @@ void carve_trees(Carver &c, CzTrees &t, size_t G) {
     t.pend_side = c.take<uint8_t>(G);
     t.pend_nmoves = c.take<uint16_t>(G);
     t.pend_moves = c.take<uint16_t>(G * CZD_MAXMOVES);
+    t.slot_of = c.take<int32_t>(G);
+    t.evcnt = c.take<int32_t>(2);
+    t.evtotal = c.take<unsigned long long>(2);
 }
 
 }  // namespace
@@ -251,9 +254,34 @@ int cz_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, i
     CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_search_select: 14 <= channels <= 64");
     return czk_search_select(c, mode, active, planes, dtype, channels, needs_eval);
 }
-int cz_search_expand_backup_fc(cz_ctx *c, const float *z, const float *value, const float *pfc_w, const float *pfc_b) {
+int cz_search_expand_backup_fc(cz_ctx *c, const float *z, const float *value, const float *pfc_w, const float *pfc_b, int compact) {
     CZ_REQUIRE(c && c->G > 0 && z && value && pfc_w && pfc_b, "cz_search_expand_backup_fc: null argument / no search");
-    return czk_search_expand_backup_fc(c, z, value, pfc_w, pfc_b);
+    return czk_search_expand_backup_fc(c, z, value, pfc_w, pfc_b, compact != 0);
+}
+int cz_search_select_compact(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int channels,
+                             const int32_t **slot_of, const int32_t **n_rows) {
+    CZ_REQUIRE(c && c->G > 0 && planes, "cz_search_select_compact: call cz_search_reset first / null planes");
+    CZ_REQUIRE(mode == 0 || mode == 1, "cz_search_select_compact: mode must be 0 or 1");
+    CZ_REQUIRE(dtype == CZ_F32 || dtype == CZ_BF16 || dtype == CZ_F16, "cz_search_select_compact: dtype must be CZ_F32, CZ_BF16 or CZ_F16");
+    CZ_REQUIRE(channels >= 14 && channels <= 64, "cz_search_select_compact: 14 <= channels <= 64");
+    c->step_parity ^= 1;
+    if (slot_of) *slot_of = c->t.slot_of;
+    if (n_rows) *n_rows = c->t.evcnt + c->step_parity;
+    return czk_search_select(c, mode, active, planes, dtype, channels, nullptr, true);
+}
+int cz_set_batch_count(cz_ctx *c, const int32_t *n_rows_dev) {
+    CZ_REQUIRE(c, "null ctx");
+    c->batch_count = n_rows_dev;
+    return CZ_OK;
+}
+int cz_search_eval_totals(cz_ctx *c, unsigned long long *rows, unsigned long long *steps) {
+    CZ_REQUIRE(c, "null ctx");
+    unsigned long long h[2] = {0, 0};
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    CZ_HIP(hipMemcpy(h, c->t.evtotal, sizeof(h), hipMemcpyDeviceToHost));
+    if (rows) *rows = h[0];
+    if (steps) *steps = h[1];
+    return CZ_OK;
 }
 int cz_search_expand_backup(cz_ctx *c, const void *logits, const void *value, int dtype) {
     CZ_REQUIRE(c && c->G > 0 && logits && value, "cz_search_expand_backup: null argument / no search");

@@ -51,16 +51,16 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
         if (f16)
             hipLaunchKernelGGL((k_tower8_c128<true, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
                                (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks);
+                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
         else
             hipLaunchKernelGGL((k_tower8_c128<false, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
                                (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks);
+                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
     } else if (f16) {   // fp16 operands: the 8-wave kernel (or 2x above)
         const int grid = (B + T8_P - 1) / T8_P;
         hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                           (const uint16_t *)w0, b0, B, 2 * nblocks);
+                           (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
     } else if (variant == 0) {
         const int grid = (B + TW_P - 1) / TW_P;
         hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
@@ -70,7 +70,7 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
         const int grid = (B + T8_P - 1) / T8_P;
         hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                           (const uint16_t *)w0, b0, B, 2 * nblocks);
+                           (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
     } else {
         const int grid = (B + TP_P - 1) / TP_P;
         hipLaunchKernelGGL(k_towerp_c128, dim3(grid), dim3(TP_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,

@@ -549,8 +549,8 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
             float acc = 0.f;
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
-                const int p = (it + tid) & 15;      // physical 16-byte slot, rotated per lane against bank conflicts
-                const int c = p ^ key;              // logical chunk = channels 8c .. 8c+7
+                const int c = it;                   // logical chunk = channels 8c .. 8c+7, always summed in this order:
+                const int p = c ^ key;              // a position's result must not depend on the row / thread it lands on
                 const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
                 const float *wc8 = w + c * 8;
                 acc += __uint_as_float(v.x << 16) * wc8[0] + __uint_as_float(v.x & 0xFFFF0000u) * wc8[1]
@@ -628,13 +628,19 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
                                                                const uint16_t *__restrict__ planes,
                                                                const uint16_t *__restrict__ w0,
                                                                const float *__restrict__ b0,
-                                                               int B, int nlayers) {
+                                                               int B, int nlayers,
+                                                               const int *__restrict__ bcount) {   // device row count or NULL
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Geo = T8Geo<P>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, khalf = lane >> 5;
     const int pos0 = blockIdx.x * P;
+    if (bcount) {   // compact batches: only the first *bcount rows are live this step (whole workgroups beyond them leave)
+        const int live = *bcount;
+        B = live < B ? live : B;
+    }
+    if (pos0 >= B) return;
     const int npos = (B - pos0) < P ? (B - pos0) : P;
     const int nrows = npos * 90;
     const int nslabs = nlayers * Geo::SLABS_PER_LAYER;
@@ -875,8 +881,8 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             float acc = 0.f;
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
-                const int p = (it + tid) & 15;
-                const int c = p ^ key;
+                const int c = it;                   // fixed summation order: the result of a position does not depend on its row
+                const int p = c ^ key;
                 const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
                 const float *wc8 = w + c * 8;
                 const f32x2 e0 = unpack_pair<F16>(v.x), e1 = unpack_pair<F16>(v.y), e2 = unpack_pair<F16>(v.z), e3 = unpack_pair<F16>(v.w);
@@ -1181,8 +1187,8 @@ __global__ __launch_bounds__(TP_THREADS, 1) void k_towerp_c128(const uint16_t *_
             float acc = 0.f;
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
-                const int p = (it + tid) & 15;
-                const int c = p ^ key;
+                const int c = it;                   // fixed summation order: the result of a position does not depend on its row
+                const int p = c ^ key;
                 const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
                 const float *wc8 = w + c * 8;
                 acc += __uint_as_float(v.x << 16) * wc8[0] + __uint_as_float(v.x & 0xFFFF0000u) * wc8[1]

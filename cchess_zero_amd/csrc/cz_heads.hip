@@ -50,7 +50,9 @@ __device__ __forceinline__ void split_bf16(float x, __bf16 &hi, __bf16 &lo) {
 //     streaming from L2 instead moved 405 MB per call; this moves 102 MB.
 __global__ __launch_bounds__(256, 1) void k_policy_fc(const float *__restrict__ z, const uint4 *__restrict__ w_hi,
                                                        const uint4 *__restrict__ w_lo, const float *__restrict__ bias,
-                                                       float *__restrict__ logits, int B) {
+                                                       float *__restrict__ logits, int B, const int *__restrict__ bcount) {
+    if (bcount) { const int live = *bcount; B = live < B ? live : B; }   // compact batches: first *bcount rows only
+    if ((int)(blockIdx.x / PFC_SPLIT) * PFC_POS >= B) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint16_t (*a_hi)[64][8] = reinterpret_cast<uint16_t (*)[64][8]>(smem + (size_t)(wave * 2 + 0) * PFC_FRAG_U4 * 16);
@@ -186,7 +188,10 @@ constexpr int VFC_POS = 8;    // positions per workgroup: 1024 workgroups at B =
 
 __global__ __launch_bounds__(256) void k_value_fc(const float *__restrict__ z, const float *__restrict__ w1t /*[90][256]*/,
                                                    const float *__restrict__ b1, const float *__restrict__ w2,
-                                                   const float *__restrict__ b2, float *__restrict__ value, int B) {
+                                                   const float *__restrict__ b2, float *__restrict__ value, int B,
+                                                   const int *__restrict__ bcount) {
+    if (bcount) { const int live = *bcount; B = live < B ? live : B; }
+    if ((int)blockIdx.x * VFC_POS >= B) return;
     __shared__ __attribute__((aligned(16))) float vin[VFC_POS][92];   // 90 inputs + 2 zeros: 23 float4 per position
     __shared__ float part[VFC_POS][256 + 8];   // per-position products of the 256 hidden units (padded rows)
     const int t = threadIdx.x;
@@ -248,12 +253,12 @@ extern "C" int cz_fc_heads_f32(cz_ctx *c, const float *z, const void *pfc_w_hi, 
         }
         const int chunks = (B + PFC_POS - 1) / PFC_POS;
         hipLaunchKernelGGL(k_policy_fc, dim3(chunks * PFC_SPLIT), dim3(256), PFC_LDS_BYTES, c->stream, z, (const uint4 *)pfc_w_hi,
-                           (const uint4 *)pfc_w_lo, pfc_b, logits, B);
+                           (const uint4 *)pfc_w_lo, pfc_b, logits, B, c->batch_count);
         CZ_HIP(hipGetLastError());
     }
     if (value) {
         hipLaunchKernelGGL(k_value_fc, dim3((B + VFC_POS - 1) / VFC_POS), dim3(256), 0, c->stream, z, v1_wt, v1_b, v2_w, v2_b,
-                           value, B);
+                           value, B, c->batch_count);
         CZ_HIP(hipGetLastError());
     }
     return CZ_OK;

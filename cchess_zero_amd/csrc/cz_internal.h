@@ -56,6 +56,10 @@ struct CzTrees {
     float *pend_value;
     uint8_t *pend_side;
     uint16_t *pend_nmoves, *pend_moves;  // [max_games][128]
+    // compact evaluation batches (cz_search_select_compact): row of the step's leaf in planes / z / value, or -1
+    int32_t *slot_of;                 // [max_games]
+    int32_t *evcnt;                   // [2] rows handed out this step / next step (ping-pong, zeroed one step ahead)
+    unsigned long long *evtotal;      // [2] rows evaluated, steps: running totals for the flop accounting
 };
 
 struct cz_ctx {
@@ -70,6 +74,8 @@ struct cz_ctx {
     bool conv_attr_set, tower_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1
+    int step_parity;   // which evcnt entry the current compact step uses
+    const int32_t *batch_count;  // cz_set_batch_count: device row count bounding the net launches, or NULL
 };
 
 // kernels' launch wrappers (cz_rules.hip / cz_search.hip)
@@ -78,9 +84,9 @@ int czk_apply_move(cz_ctx *, uint8_t *, uint8_t *, const uint16_t *, int, uint64
 int czk_hash(cz_ctx *, const uint8_t *, const uint8_t *, int, uint64_t *);
 int czk_encode_planes(cz_ctx *, const uint8_t *, const uint8_t *, int, void *, int, int, int);
 int czk_search_reset(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *, int);
-int czk_search_select(cz_ctx *, int, const uint8_t *, void *, int, int, uint8_t *);
+int czk_search_select(cz_ctx *, int, const uint8_t *, void *, int, int, uint8_t *, bool compact = false);
 int czk_search_expand_backup(cz_ctx *, const void *, const void *, int);
-int czk_search_expand_backup_fc(cz_ctx *, const float *, const float *, const float *, const float *);
+int czk_search_expand_backup_fc(cz_ctx *, const float *, const float *, const float *, const float *, bool compact);
 int czk_search_root_stats(cz_ctx *, uint16_t *, int32_t *, float *, float *, float *, uint16_t *);
 int czk_search_advance(cz_ctx *, const uint16_t *);
 int czk_search_select_k(cz_ctx *, int, int, const uint8_t *, void *, int, int, uint8_t *);

@@ -63,10 +63,14 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
     return a;
 }
 
-template <typename T>
+// COMPACT: the leaf planes of the trees that need a net evaluation are written to consecutive rows handed out by an
+// atomic counter (t.evcnt[parity]); t.slot_of[g] records the row (or -1), the other counter is zeroed for the next
+// step.  Terminal / drawn / parked trees then cost the net nothing (they are 9 % of the simulations on the bench
+// workload), and which row a tree gets does not matter: every row of the net is computed independently.
+template <typename T, bool COMPACT>
 __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, int mode,
                                                const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
-                                               T one, uint8_t *__restrict__ needs_eval) {
+                                               T one, uint8_t *__restrict__ needs_eval, int parity) {
     __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
     __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
     __shared__ uint16_t mv[CZD_MAXMOVES];
@@ -168,10 +172,22 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
         nmoves = czd_wave_movegen(b, side, tab.lut, stage, mv, lane);  // main.py:374 / :483
         if (nmoves < 0) { if (lane == 0) t.status[g] |= CZ_ST_MOVE_OVERFLOW; kind = 0; nmoves = 0; }
     }
+    if constexpr (COMPACT) {
+        int slot = -1;
+        if (kind == 1 || kind == 3) {
+            if (lane == 0) slot = atomicAdd(&t.evcnt[parity], 1);
+            slot = __shfl(slot, 0, 64);
+        }
+        pl = slot >= 0 ? planes + (size_t)slot * 90 * C : nullptr;
+        if (lane == 0) {
+            t.slot_of[g] = slot;
+            if (g == 0) t.evcnt[parity ^ 1] = 0;   // nobody touches the other counter until the next step's select
+        }
+    }
     if (kind == 1 || kind == 3) {
         for (int i = lane; i < nmoves; i += 64) t.pend_moves[(size_t)g * CZD_MAXMOVES + i] = mv[i];
         if (pl) czd_wave_encode_planes<T>(b, side, 1, pl, C, one, lane);  // generate_inputs, main.py:362 / :477
-    } else if (pl) {
+    } else if (pl && !COMPACT) {
         for (int e = lane; e < 90 * C; e += 64) pl[e] = (T)0;
     }
     if (lane == 0) {
@@ -200,12 +216,19 @@ template <> __device__ __forceinline__ float to_f32<uint16_t>(uint16_t x) { retu
 template <typename T, bool FC>
 __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, int G, const T *__restrict__ logits,
                                                       const T *__restrict__ value, const float *__restrict__ fcw,
-                                                      const float *__restrict__ fcb) {
+                                                      const float *__restrict__ fcb, int compact_parity) {
     __shared__ float pr[CZD_MAXMOVES];
     __shared__ float tot_s;
     __shared__ __attribute__((aligned(16))) float xin[FC ? 180 : 4];
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
+    // compact batches (compact_parity >= 0): tree g's leaf sits in row slot_of[g] of z / value; tree 0 also books the
+    // step's row count into the running totals (the flop accounting of bench.py)
+    int row = g;
+    if (FC && compact_parity >= 0) {
+        row = t.slot_of[g];
+        if (g == 0 && lane == 0) { t.evtotal[0] += (unsigned long long)t.evcnt[compact_parity]; t.evtotal[1] += 1ull; }
+    }
     const int kind = t.pend_kind[g];
     if (kind == 0) return;
     const TreeView v = view_of(t, g, t.cur[g]);
@@ -220,7 +243,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
         if (fits) {
             uint16_t lab[2];
             if constexpr (FC) {
-                const float *zg = reinterpret_cast<const float *>(logits) + (size_t)g * 270;
+                const float *zg = reinterpret_cast<const float *>(logits) + (size_t)row * 270;
                 for (int i = lane; i < 270; i += 64) {
                     const float zv = zg[i];
                     const int cell = i / 3, ch = i - cell * 3;
@@ -308,7 +331,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
             t.status[g] |= CZ_ST_POOL_EXHAUSTED;
         }
         if (kind == 3) { if (lane == 0) t.pend_kind[g] = 0; return; }
-        val = to_f32<T>(value[g]) * -1.0f;  // return value[0] * -1, main.py:384
+        val = to_f32<T>(value[FC ? row : g]) * -1.0f;  // return value[0] * -1, main.py:384
     } else {
         val = t.pend_value[g];
     }
@@ -677,11 +700,14 @@ int czk_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, cons
     return CZ_OK;
 }
 
-int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int C, uint8_t *needs_eval) {
-    if (dtype == CZ_F32)
-        hipLaunchKernelGGL(k_select<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (float *)planes, C, 1.0f, needs_eval);
-    else
-        hipLaunchKernelGGL(k_select<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (uint16_t *)planes, C, (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80), needs_eval);
+int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int C, uint8_t *needs_eval, bool compact) {
+    const uint16_t one16 = (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80);
+    const int par = c->step_parity;
+#define CZ_LAUNCH_SELECT(TT, CMP, ONE)                                                                                  \
+    hipLaunchKernelGGL((k_select<TT, CMP>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (TT *)planes, C, ONE, needs_eval, par)
+    if (dtype == CZ_F32) { if (compact) CZ_LAUNCH_SELECT(float, true, 1.0f); else CZ_LAUNCH_SELECT(float, false, 1.0f); }
+    else { if (compact) CZ_LAUNCH_SELECT(uint16_t, true, one16); else CZ_LAUNCH_SELECT(uint16_t, false, one16); }
+#undef CZ_LAUNCH_SELECT
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
@@ -689,16 +715,17 @@ int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, 
 int czk_search_expand_backup(cz_ctx *c, const void *logits, const void *value, int dtype) {
     if (dtype == CZ_F32)
         hipLaunchKernelGGL((k_expand_backup<float, false>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const float *)logits,
-                           (const float *)value, (const float *)nullptr, (const float *)nullptr);
+                           (const float *)value, (const float *)nullptr, (const float *)nullptr, -1);
     else
         hipLaunchKernelGGL((k_expand_backup<uint16_t, false>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, (const uint16_t *)logits,
-                           (const uint16_t *)value, (const float *)nullptr, (const float *)nullptr);
+                           (const uint16_t *)value, (const float *)nullptr, (const float *)nullptr, -1);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
 
-int czk_search_expand_backup_fc(cz_ctx *c, const float *z, const float *value, const float *fcw, const float *fcb) {
-    hipLaunchKernelGGL((k_expand_backup<float, true>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, z, value, fcw, fcb);
+int czk_search_expand_backup_fc(cz_ctx *c, const float *z, const float *value, const float *fcw, const float *fcb, bool compact) {
+    hipLaunchKernelGGL((k_expand_backup<float, true>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, z, value, fcw, fcb,
+                       compact ? c->step_parity : -1);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

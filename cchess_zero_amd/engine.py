@@ -64,6 +64,10 @@ class SearchEngine:
         self.channels = int(channels)
         self.plane_dtype = plane_dtype
         self._pd = {torch.bfloat16: BF16, torch.float16: F16}.get(plane_dtype, F32)
+        # step(): compact evaluation batches on the fused-net path.  Off by default: at 8192 trees the trunk needs
+        # ceil(rows / 1024) workgroup rounds, so dropping the ~9 % terminal leaves of the bench workload removes no round
+        # (and the row counter costs 60 us of atomics); self-play switches it on, where finished games park their trees.
+        self.compact = False
         self.planes = None
         self.need = None
 
@@ -117,14 +121,38 @@ class SearchEngine:
         else:
             check(lib().cz_search_expand_backup(self.ctx.h, _ptr(logits), _ptr(value), dt), "cz_search_expand_backup")
 
-    def expand_backup_fc(self, z, value, pfc_w, pfc_b):
+    def expand_backup_fc(self, z, value, pfc_w, pfc_b, compact=False):
         """expand_backup with the policy FC folded in (cz_search_expand_backup_fc): z [G,90,3] f32 head-conv outputs,
-        value [G] or [G,1] f32, pfc_w [2086,180] f32 (torch layout), pfc_b [2086] f32.  Width 1 only."""
+        value [G] or [G,1] f32, pfc_w [2086,180] f32 (torch layout), pfc_b [2086] f32.  Width 1 only.
+        compact=True: z / value rows are the ones select_compact handed out (tree g -> row slot_of[g])."""
         assert self.width == 1, "expand_backup_fc pairs with the one-simulation-per-tree select"
         assert z.dtype == torch.float32 and z.is_contiguous() and z.shape == (self.G, 90, 3)
         value = value.float().contiguous()
         assert value.numel() == self.G and pfc_w.is_contiguous() and pfc_w.shape == (NLABELS, 180) and pfc_b.numel() == NLABELS
-        check(lib().cz_search_expand_backup_fc(self.ctx.h, _ptr(z), _ptr(value), _ptr(pfc_w), _ptr(pfc_b)), "cz_search_expand_backup_fc")
+        check(lib().cz_search_expand_backup_fc(self.ctx.h, _ptr(z), _ptr(value), _ptr(pfc_w), _ptr(pfc_b), 1 if compact else 0),
+              "cz_search_expand_backup_fc")
+
+    def select_compact(self, mode=1, active=None):
+        """select() with compact evaluation batches: the leaf planes of the trees that need a net evaluation go to rows
+        0 .. n-1 of the planes buffer (cz_search_select_compact).  Returns (planes, n_rows_ptr): the full planes tensor and
+        the DEVICE address of n (an int), to be handed to the net through set_batch_count — no host synchronisation."""
+        import ctypes as C
+        assert self.width == 1
+        act = None
+        if active is not None:
+            act = torch.as_tensor(active).to(self.dev).to(torch.uint8).contiguous()
+        slot_p, n_p = C.c_void_p(), C.c_void_p()
+        check(lib().cz_search_select_compact(self.ctx.h, int(mode), _ptr(act), _ptr(self.planes), self._pd, self.channels,
+                                             C.byref(slot_p), C.byref(n_p)), "cz_search_select_compact")
+        self._act = act
+        return self.planes, n_p
+
+    def eval_totals(self):
+        """(rows evaluated, compact steps) since the context was created (synchronises)."""
+        import ctypes as C
+        r, n = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(lib().cz_search_eval_totals(self.ctx.h, C.byref(r), C.byref(n)), "cz_search_eval_totals")
+        return int(r.value), int(n.value)
 
     def root_stats(self):
         G, dev = self.G, self.dev
@@ -178,12 +206,18 @@ class SearchEngine:
         `forward` maps the device planes tensor to (logits [G,2086], value [G,1]) device tensors; if it is a
         PolicyValueNet with the fused hip backend (has `search_eval`) and width is 1, the policy FC is evaluated
         inside the expansion for the legal moves only (expand_backup_fc) and no logits tensor exists at all."""
-        planes, _ = self.select(mode, active)
         net = getattr(forward, "__self__", forward)
         if self.width == 1 and getattr(net, "search_eval", None) is not None and net.fused_search:
-            z, value = net.search_eval(planes)
-            self.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32)
+            if self.compact:   # terminal / drawn / parked trees cost the net nothing
+                planes, n_rows = self.select_compact(mode, active)
+                z, value = net.search_eval(planes, n_rows)
+                self.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32, compact=True)
+            else:
+                planes, _ = self.select(mode, active)
+                z, value = net.search_eval(planes)
+                self.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32)
             return
+        planes, _ = self.select(mode, active)
         logits, value = forward(planes)
         self.expand_backup(logits, value)
 

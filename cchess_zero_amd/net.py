@@ -397,17 +397,25 @@ class PolicyValueNet:
         return self.backend == "hip" and self.res_block_nums >= 1 and self.fuse_policy_fc
 
     @torch.no_grad()
-    def search_eval(self, planes):
+    def search_eval(self, planes, n_rows=None):
         """Device planes -> (z [B,90,3] f32 head-conv outputs, value [B,1] f32): what the search needs when the policy
-        FC is evaluated inside the expansion kernel (cz_search_expand_backup_fc)."""
+        FC is evaluated inside the expansion kernel (cz_search_expand_backup_fc).  n_rows: device address of an int
+        (SearchEngine.select_compact) — only the first *n_rows rows are computed, the rest of z / value is undefined."""
         import ctypes as C
         from ._lib import check, lib
-        z = self._hip_net_forward(planes)
-        B = z.shape[0]
-        value = torch.empty((B, 1), dtype=torch.float32, device=self.device)
-        vp = lambda t: C.c_void_p(t.data_ptr())
-        check(lib().cz_fc_heads_f32(self._hip_ctx().h, vp(z), None, None, None, vp(self.hip_v1_wt), vp(self.hip_v1_b),
-                                    vp(self.hip_v2_w), vp(self.hip_v2_b), None, vp(value), B), "cz_fc_heads_f32")
+        h = self._hip_ctx().h
+        if n_rows is not None:
+            check(lib().cz_set_batch_count(h, n_rows), "cz_set_batch_count")
+        try:
+            z = self._hip_net_forward(planes)
+            B = z.shape[0]
+            value = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+            vp = lambda t: C.c_void_p(t.data_ptr())
+            check(lib().cz_fc_heads_f32(h, vp(z), None, None, None, vp(self.hip_v1_wt), vp(self.hip_v1_b),
+                                        vp(self.hip_v2_w), vp(self.hip_v2_b), None, vp(value), B), "cz_fc_heads_f32")
+        finally:
+            if n_rows is not None:
+                check(lib().cz_set_batch_count(h, None), "cz_set_batch_count")
         return z, value
 
     @torch.no_grad()

@@ -94,6 +94,7 @@ class SelfPlay:
 
     def start(self, boards, side, rr=None):
         self.eng.reset(boards, side, rr)
+        self.eng.compact = True   # finished games park their trees: their rows drop out of the net's batch
         G = self.eng.G
         self.active = torch.ones(G, dtype=torch.bool, device=self.dev)
         self.hist = [[] for _ in range(G)]   # per game: list of (board u8[90], side, labels u16[k], probs f32[k])

@@ -126,7 +126,22 @@ int cz_search_expand_backup(cz_ctx *, const void *logits, const void *value, int
  * 179-181).  The float32 evaluation order of the 180-term dot product is fixed and documented at k_expand_backup
  * (cz_search.hip) so that a CPU restatement reproduces the priors bit for bit (tests/test_hip_search.py).
  * value [G] f32.  Pairs with cz_search_select (one simulation per tree). */
-int cz_search_expand_backup_fc(cz_ctx *, const float *z, const float *value, const float *pfc_w, const float *pfc_b);
+int cz_search_expand_backup_fc(cz_ctx *, const float *z, const float *value, const float *pfc_w, const float *pfc_b,
+                               int compact /* 1: z / value rows are the ones cz_search_select_compact handed out */);
+
+/* Compact evaluation batches.  Terminal and drawn leaves (main.py:409-416) and parked trees need no net evaluation — the
+ * reference never calls forward() for them — so cz_search_select_compact writes the leaf planes of the trees that DO
+ * need one to consecutive rows 0 .. n-1 of leaf_planes (rows are handed out by an atomic counter; which tree gets
+ * which row is irrelevant because every row of the net is computed independently).  *slot_of -> device int32 [G]: the
+ * row of tree g's leaf or -1; *n_rows -> device int32: n for this step (valid until the step after the next).  Pass
+ * n_rows to cz_set_batch_count so that the following cz_net_trunk_bf16 / cz_net_trunk_f16 / cz_fc_heads_f32 launches
+ * stop after n rows (whole workgroups beyond them return at once; no host synchronisation), then call
+ * cz_search_expand_backup_fc(..., compact = 1).  cz_search_eval_totals returns the running totals of rows evaluated
+ * and of compact steps (synchronises the stream): the flop accounting of a benchmark. */
+int cz_search_select_compact(cz_ctx *, int mode, const uint8_t *active, void *leaf_planes, int dtype, int channels,
+                             const int32_t **slot_of, const int32_t **n_rows);
+int cz_set_batch_count(cz_ctx *, const int32_t *n_rows_dev /* or NULL: every row of B */);
+int cz_search_eval_totals(cz_ctx *, unsigned long long *rows, unsigned long long *steps);
 /* k simulations in flight per tree and step, with the reference's virtual loss (N += 3, W -= 3 while in flight):
  * replaces the `search_threads` coroutines of MCTS_tree (asyncio.Semaphore(search_threads), main.py:250,337-348,
  * virtual loss :231,403-404,426-427, now_expanding :354-360).  cz_search_set_width sizes the pending-leaf arrays

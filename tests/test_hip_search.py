@@ -176,3 +176,38 @@ def test_expand_with_folded_policy_fc_vs_oracle(rules_golden):
                 played[t] = os_["label"][t, int(np.argmax(os_["N"][t, :n]))]
         hip.advance(played)
         orc.advance(played)
+
+
+def test_compact_batches_give_identical_trees(rules_golden):
+    """SearchEngine.step with compact evaluation batches (terminal / drawn / parked trees get no net row, rows handed out
+    by an atomic counter, net launches bounded by the device-side row count) against the same search with one row per
+    tree: identical trees, with the real fused net.  Roots near the 60-ply limit make many leaves terminal."""
+    from cchess_zero_amd.engine import SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet
+    g = rules_golden
+    ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
+    idx = np.nonzero(ok)[0][::9][:301]          # not a multiple of 4: the last workgroup of the trunk is ragged
+    G = len(idx)
+    boards, side = g["boards"][idx], g["side"][idx]
+    rr = (np.arange(G) * 3 % 62).astype(np.int32)  # some trees start at rr 58..61: every leaf a draw
+    net = PolicyValueNet(2, "cuda:0", torch.bfloat16, seed=4)
+    assert net.fused_search
+    engs = []
+    for compact in (False, True):
+        e = SearchEngine(G, 6000, plane_dtype=torch.bfloat16, channels=16)
+        e.compact = compact
+        e.reset(boards, side, rr)
+        active = np.ones(G, np.uint8)
+        active[5::17] = 0                          # parked trees
+        e.search(net.forward_device, 40, active=active)
+        engs.append(e)
+    a, b = engs[0].root_stats_host(), engs[1].root_stats_host()
+    for k in ("label", "N", "count"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("Q", "P", "W"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    for t in range(0, G, 7):
+        assert np.array_equal(engs[0].tree_dump(t), engs[1].tree_dump(t)), t
+    rows, steps = engs[1].eval_totals()
+    assert steps == 41 and 0 < rows < 41 * G      # fewer rows than trees x steps: some leaves needed no evaluation
+    print("compact batches: %d rows for %d tree-steps (%.1f %%)" % (rows, 41 * G, 100.0 * rows / (41 * G)))

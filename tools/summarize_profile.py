@@ -60,8 +60,10 @@ def main():
     G, blocks = cfg["games_per_gpu"], cfg["res_block_nums"]
     # algorithmic bytes of one launch: planes in (bf16 [G][90][16]) + all folded weights once
     # (first conv 9*16*128, 2*blocks layers of 9*128*128, bf16) + biases (f32) + head conv output (f32 [G][90][3])
-    alg = G * 90 * 16 * 2 + (9 * 16 * 128 + 2 * blocks * 9 * 128 * 128) * 2 + (2 * blocks + 1) * 128 * 4 + G * 90 * 3 * 4
-    tj = {"kernel": ksub, "config": {"B": G, "res_block_nums": blocks, "dtype": bline["dtype"]},
+    rows_ = cfg.get("net_rows_per_step", G)   # compact batches: fewer rows than trees
+    alg = int(rows_ * 90 * 16 * 2 + (9 * 16 * 128 + 2 * blocks * 9 * 128 * 128) * 2 + (2 * blocks + 1) * 128 * 4 + rows_ * 90 * 3 * 4)
+    tj = {"kernel": ksub, "config": {"B": G, "res_block_nums": blocks, "dtype": bline["dtype"], "compact": bool(cfg.get("compact_batches", False)),
+                                     "net_rows_per_step": rows_},
           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
                     "--steps 40 --warmup 4 --no-cpu-baseline` (tools/profile_round.sh); mean over %d/%d launches; counters are in KiB" % (nf, nw),
           "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
