@@ -52,3 +52,33 @@ def test_missing_gpu_fails_loudly():
     from cchess_zero_amd import _lib, engine
     with pytest.raises(_lib.CchessHipError):
         engine.Context(4, 16)
+
+
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """Regression guard: the kernels of the search step must not spill to scratch (private segment 0 bytes).  hipcc has
+    twice turned hoisted address arrays and prefetch buffers into scratch traffic that cost 5-10 % without any warning;
+    the device assembly is generated here (no GPU needed) and the code-object metadata is checked."""
+    import re
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from cchess_zero_amd import build
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cchess_zero_amd", "csrc")
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    hot = {"cz_conv.hip": ["k_tower8_c128"], "cz_search.hip": ["k_select", "k_expand_backup"],
+           "cz_heads.hip": ["k_policy_fc", "k_value_fc"], "cz_rules.hip": ["k_movegen", "k_encode_planes"]}
+
+    def asm(src):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.run([build.hipcc()] + flags + ["--offload-device-only", "-S", "-o", out, os.path.join(csrc, src)], check=True,
+                       stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        return src, open(out).read()
+    with ThreadPoolExecutor(4) as ex:
+        texts = dict(ex.map(asm, hot))
+    checked = 0
+    for src, names in hot.items():
+        # metadata entries look like:  .name: <mangled>  ...  .private_segment_fixed_size: N
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", texts[src]):
+            if any(n in m.group(1) for n in names) and "k_select_k" not in m.group(1):
+                assert int(m.group(2)) == 0, "%s uses %s bytes of scratch" % (m.group(1), m.group(2))
+                checked += 1
+    assert checked >= 4 + 2 + 2 + 2 + 2, checked   # 4 trunk instantiations, 2+2 select/expand, 2 heads, 2 rules
