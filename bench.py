@@ -156,7 +156,9 @@ def main():
 
     G, playout = args.games, args.playout
     tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-    cap = args.nodes_per_tree or (playout + 2) * 80
+    # node pool per tree: a ply adds ~40 children per simulation (<= 128) on top of the subtree kept from the previous
+    # ply; 160 per simulation has held over 20+ plies of the bench workload (8192 trees: 2 pools x 59 GB of 288 GB)
+    cap = args.nodes_per_tree or (playout + 2) * 160
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
     # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
@@ -202,8 +204,7 @@ def main():
     banked = [0]   # simulations completed in plies that were closed inside the timed region (k > 1 accounting)
 
     def advance_ply():
-        if K > 1:
-            banked[0] += int(eng.status()[2].sum().item())
+        banked[0] += int(eng.status()[2].sum().item())   # one sync per ply (every `playout` steps)
         st = eng.root_stats()
         n = st["N"].clone()
         cnt = (st["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
@@ -230,7 +231,7 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    sims0 = int(eng.status()[2].sum().item()) if K > 1 else 0
+    sims0 = int(eng.status()[2].sum().item())
     rows0, csteps0 = eng.eval_totals() if compact else (0, 0)
     banked[0] = 0
     torch.cuda.synchronize()
@@ -274,13 +275,12 @@ def main():
     st_bits = {name: int(((st & bit) != 0).sum().item()) for name, bit in
                (("pool_exhausted", 1), ("no_moves", 2), ("move_overflow", 4), ("bad_advance", 8))}
     net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net])) if ev_net else float("nan")
-    if K == 1:
-        total_sims = float(G) * args.steps * world
-    else:   # descents that ran into a pending expansion are abandoned: count what was actually backed up
-        mine = torch.tensor([banked[0] + int(sims.sum().item()) - sims0], dtype=torch.float64, device=dev if (dist_on and args.dist_backend == "nccl") else "cpu")
-        if dist_on:
-            dist.all_reduce(mine)
-        total_sims = float(mine.item())
+    # simulations are COUNTED (completed backups, per-tree device counters), not assumed: a parked tree (node pool
+    # exhausted) or an abandoned descent (k > 1) contributes nothing.  With k = 1 and no parked tree this is G * steps.
+    mine = torch.tensor([banked[0] + int(sims.sum().item()) - sims0], dtype=torch.float64, device=dev if (dist_on and args.dist_backend == "nccl") else "cpu")
+    if dist_on:
+        dist.all_reduce(mine)
+    total_sims = float(mine.item())
     # rows the net evaluated per launch: all G without compaction, else the measured mean over the timed region
     rows_per_launch = float(G)
     if compact:
@@ -322,6 +322,7 @@ def main():
                    "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits",
                    "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
                    "positions": "seeded random playouts from the start position, ply~U[0,80]",
+                   "simulations_counted": total_sims, "simulations_nominal": float(G) * args.steps * world * K,
                    "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),
                    "trees_with_error_status": bad, "status_bits": st_bits},
         "roofline": roof,
