@@ -481,7 +481,9 @@ class cchess_main(object):
         from cchess_zero_amd.engine import SearchEngine
         from cchess_zero_amd.selfplay import SelfPlay
         G = games or self.games
-        cap = max(4096, (self.playout_counts + 2) * 80)
+        # a ply adds ~40 nodes per simulation on top of the subtree kept from the previous ply (160 has held over many plies;
+        # a tree that does overflow is parked and its game adjudicated a draw at max_plies)
+        cap = max(4096, (self.playout_counts + 2) * 160)
         if getattr(self, "_batch_eng", None) is None or self._batch_eng.ctx.max_games < G:
             self._batch_eng = SearchEngine(G, cap, torch.cuda.current_device())
         sp = SelfPlay(self._batch_eng, self.policy_value_netowrk.net, self.playout_counts, self.exploration, self.temperature,
