@@ -156,8 +156,10 @@ def main():
 
     G, playout = args.games, args.playout
     tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-    # node pool per tree: a ply adds ~40 children per simulation (<= 128) on top of the subtree kept from the previous
-    # ply; 160 per simulation has held over 20+ plies of the bench workload (8192 trees: 2 pools x 59 GB of 288 GB)
+    # node pool per tree: a ply adds ~40 nodes per simulation on top of the subtree kept from the previous ply; 160 per
+    # simulation has held over 6+ plies of this workload (80 overflowed 3 000 of 8192 trees by the fourth ply).  Same-box
+    # A/B: the capacity does not change the step time (2.300 ms at 128 160 and at 256 320 nodes per tree).  Simulations
+    # are counted, so an overflowing (parked) tree could not inflate the result anyway.
     cap = args.nodes_per_tree or (playout + 2) * 160
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
