@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--search-threads", type=int, default=1, help="simulations in flight per tree and step (the reference's search_threads; virtual loss 3); batch = games * search_threads")
+    ap.add_argument("--graph", action="store_true", help="replay the four launches of a step as one captured HIP graph (measured: no gain, the host already runs ahead of the GPU)")
     ap.add_argument("--compact", action="store_true", help="compact evaluation batches: no net row for terminal / drawn leaves (no gain at 8192 trees: the trunk runs in rounds of 1024 rows)")
     ap.add_argument("--full-policy-fc", action="store_true", help="compute all 2086 logits per leaf (k_policy_fc) instead of folding the policy FC into the expansion")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 80: no tree can run out)")
@@ -218,18 +219,37 @@ def main():
 
     sims_in_ply = 0
 
+    graph = [None]   # the steady-state step (4 launches, static arguments) captured as one HIP graph
+
     def run(nsteps, timed):
         nonlocal sims_in_ply
         for _ in range(nsteps):
             if sims_in_ply >= playout:
                 advance_ply()
                 sims_in_ply = 0
-            one_step(1, timed)
+            # every 8th timed step runs eagerly so that HIP events can bracket the trunk launch on its stream
+            if graph[0] is not None and not (timed and step_no[0] % 8 == 0):
+                step_no[0] += 1
+                graph[0].replay()
+            else:
+                one_step(1, timed)
             sims_in_ply += K
 
     one_step(0, False)          # MCTS_tree.main root expansion (not a simulation)
     run(args.warmup, False)
     torch.cuda.synchronize()
+    if args.graph and fused_fc and not compact:
+        try:   # capture AFTER the warm-up (kernel attributes set, allocator warm); a failure falls back to eager launches
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                one_step(1, False)
+            step_no[0] -= 1                      # the capture itself executed nothing
+            torch.cuda.synchronize()
+            graph[0] = gr
+        except Exception as e:
+            print("bench: HIP graph capture failed (%r), running eagerly" % (e,), file=sys.stderr)
+            graph[0] = None
+            torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -322,7 +342,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)" % (G, playout, args.blocks, args.dtype, cfg_name),
                    "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits",
-                   "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
+                   "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "hip_graph": graph[0] is not None, "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
                    "positions": "seeded random playouts from the start position, ply~U[0,80]",
                    "simulations_counted": total_sims, "simulations_nominal": float(G) * args.steps * world * K,
                    "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),

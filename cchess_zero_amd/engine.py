@@ -73,6 +73,7 @@ class SearchEngine:
 
     # -- tree lifecycle ------------------------------------------------------------------------
     def reset(self, boards, side, rr=None):
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         boards = torch.as_tensor(np.ascontiguousarray(boards, np.uint8) if not torch.is_tensor(boards) else boards).to(self.dev).reshape(-1, NSQ).contiguous()
         side = torch.as_tensor(np.ascontiguousarray(side, np.uint8) if not torch.is_tensor(side) else side).to(self.dev).contiguous()
         G = boards.shape[0]
@@ -89,6 +90,7 @@ class SearchEngine:
     def select(self, mode=1, active=None, k=None):
         """-> (leaf planes [G*k,9,10,C] device tensor, needs_eval [G*k] u8 device tensor); k <= width descents per
         tree (default: the engine's width)."""
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         k = self.width if k is None else int(k)
         self._k = k
         act = None
@@ -107,6 +109,7 @@ class SearchEngine:
 
     def expand_backup(self, logits, value):
         """logits [G,2086], value [G,1] or [G]: float32 or bfloat16 device tensors."""
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         if logits.dtype != value.dtype:
             value = value.to(logits.dtype)
         dt = BF16 if logits.dtype == torch.bfloat16 else F32
@@ -125,6 +128,7 @@ class SearchEngine:
         """expand_backup with the policy FC folded in (cz_search_expand_backup_fc): z [G,90,3] f32 head-conv outputs,
         value [G] or [G,1] f32, pfc_w [2086,180] f32 (torch layout), pfc_b [2086] f32.  Width 1 only.
         compact=True: z / value rows are the ones select_compact handed out (tree g -> row slot_of[g])."""
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         assert self.width == 1, "expand_backup_fc pairs with the one-simulation-per-tree select"
         assert z.dtype == torch.float32 and z.is_contiguous() and z.shape == (self.G, 90, 3)
         value = value.float().contiguous()
@@ -136,6 +140,7 @@ class SearchEngine:
         """select() with compact evaluation batches: the leaf planes of the trees that need a net evaluation go to rows
         0 .. n-1 of the planes buffer (cz_search_select_compact).  Returns (planes, n_rows_ptr): the full planes tensor and
         the DEVICE address of n (an int), to be handed to the net through set_batch_count — no host synchronisation."""
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         import ctypes as C
         assert self.width == 1
         act = None
@@ -149,12 +154,14 @@ class SearchEngine:
 
     def eval_totals(self):
         """(rows evaluated, compact steps) since the context was created (synchronises)."""
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         import ctypes as C
         r, n = C.c_ulonglong(0), C.c_ulonglong(0)
         check(lib().cz_search_eval_totals(self.ctx.h, C.byref(r), C.byref(n)), "cz_search_eval_totals")
         return int(r.value), int(n.value)
 
     def root_stats(self):
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         G, dev = self.G, self.dev
         out = dict(label=torch.empty((G, MAXMOVES), dtype=torch.int16, device=dev),
                    N=torch.empty((G, MAXMOVES), dtype=torch.int32, device=dev),
@@ -172,18 +179,21 @@ class SearchEngine:
                     P=st["P"].cpu().numpy(), W=st["W"].cpu().numpy(), count=st["count"].cpu().numpy().view(np.uint16))
 
     def advance(self, played):
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         if not torch.is_tensor(played):
             played = torch.from_numpy(np.ascontiguousarray(played, np.uint16).view(np.int16))
         played = played.to(self.dev).contiguous()
         check(lib().cz_search_advance(self.ctx.h, _ptr(played)), "cz_search_advance")
 
     def status(self):
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         G, dev = self.G, self.dev
         st, nodes, sims, depth = (torch.empty(G, dtype=torch.int32, device=dev) for _ in range(4))
         check(lib().cz_search_status(self.ctx.h, _ptr(st), _ptr(nodes), _ptr(sims), _ptr(depth)), "cz_search_status")
         return st, nodes, sims, depth
 
     def root_state(self):
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         G, dev = self.G, self.dev
         b = torch.empty((G, NSQ), dtype=torch.uint8, device=dev)
         s = torch.empty(G, dtype=torch.uint8, device=dev)
@@ -192,6 +202,7 @@ class SearchEngine:
         return b, s, rr
 
     def tree_dump(self, g, max_records=1 << 20):
+        self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         out = np.zeros((max_records, 7), np.int32)
         n = lib().cz_search_tree_dump(self.ctx.h, int(g), out.ctypes.data_as(C.c_void_p), int(max_records))
         if n < 0:

@@ -20,6 +20,7 @@ class Rules:
 
     def movegen(self, boards, side, want_mask=True):
         """GameBoard.get_legal_moves for G positions -> (moves [G,128] i16(u16 bits), count [G], mask [G,66] i32)."""
+        self.ctx.bind_stream()   # torch's current stream
         boards = self._dev(boards, torch.uint8).reshape(-1, NSQ)
         side = self._dev(side, torch.uint8)
         G = boards.shape[0]
@@ -31,6 +32,7 @@ class Rules:
 
     def apply_move(self, boards, side, labels, hash_=None):
         """In-place GameBoard.sim_do_action for G games -> (captured [G] u8, terminal [G] i8)."""
+        self.ctx.bind_stream()   # torch's current stream
         G = boards.shape[0]
         assert boards.is_cuda and side.is_cuda and boards.dtype == torch.uint8 and boards.is_contiguous()
         labels = self._dev(labels, torch.int16) if not (torch.is_tensor(labels) and labels.dtype == torch.int16) else labels.to(self.dev).contiguous()
@@ -40,6 +42,7 @@ class Rules:
         return cap, term
 
     def hash(self, boards, side):
+        self.ctx.bind_stream()   # torch's current stream
         boards = self._dev(boards, torch.uint8).reshape(-1, NSQ)
         side = self._dev(side, torch.uint8)
         h = torch.empty(boards.shape[0], dtype=torch.int64, device=self.dev)
@@ -47,6 +50,7 @@ class Rules:
         return h
 
     def encode_planes(self, boards, side, dtype=torch.float32, channels=14, quirk_q1=True):
+        self.ctx.bind_stream()   # torch's current stream
         boards = self._dev(boards, torch.uint8).reshape(-1, NSQ)
         side = self._dev(side, torch.uint8)
         G = boards.shape[0]
