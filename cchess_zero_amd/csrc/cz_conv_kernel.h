@@ -372,7 +372,10 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
         for (int i = 0; i < CV_RT; ++i) {
             const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : TW_ZERO_OFF;
             ab[i] = a;
-            key[i] = ((a >> 8) & 15) ^ khalf;
+            // a masked lane reads the all-zero row, but in the 16-byte slot its REAL (off-board) neighbour row would have
+            // used: the 16 lanes of a ds_read_b128 group then still hit 16 distinct slots.  With the zero row's own swizzle
+            // key every group containing a border cell paid a 2-way bank conflict (24 % of the LDS cycles).
+            key[i] = (((rowb[i] + delta) >> 8) & 15) ^ khalf;
         }
     };
     const int vb0 = TW_W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);   // this lane's B column in slab buffer 0
@@ -696,7 +699,10 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         for (int i = 0; i < CV_RT; ++i) {
             const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : Geo::ZERO_OFF;
             ab[i] = a;
-            key[i] = ((a >> 8) & 15) ^ khalf;
+            // a masked lane reads the all-zero row, but in the 16-byte slot its REAL (off-board) neighbour row would have
+            // used: the 16 lanes of a ds_read_b128 group then still hit 16 distinct slots.  With the zero row's own swizzle
+            // key every group containing a border cell paid a 2-way bank conflict (24 % of the LDS cycles).
+            key[i] = (((rowb[i] + delta) >> 8) & 15) ^ khalf;
         }
     };
     const int vb0 = Geo::W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);
@@ -1006,7 +1012,10 @@ __global__ __launch_bounds__(TP_THREADS, 1) void k_towerp_c128(const uint16_t *_
         for (int i = 0; i < CV_RT; ++i) {
             const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : T8_ZERO_OFF;
             ab[i] = a;
-            key[i] = ((a >> 8) & 15) ^ khalf;
+            // a masked lane reads the all-zero row, but in the 16-byte slot its REAL (off-board) neighbour row would have
+            // used: the 16 lanes of a ds_read_b128 group then still hit 16 distinct slots.  With the zero row's own swizzle
+            // key every group containing a border cell paid a 2-way bank conflict (24 % of the LDS cycles).
+            key[i] = (((rowb[i] + delta) >> 8) & 15) ^ khalf;
         }
     };
     const int vb0 = T8_W_OFF + khalf * 2048 + (l31 << 4);
