@@ -212,24 +212,38 @@ class SearchEngine:
         return out[:n].copy()
 
     # -- the hot loop ------------------------------------------------------------------------------
-    def step(self, forward, mode=1, active=None):
+    def step(self, forward, mode=1, active=None, tap=None, pre_net=None):
         """One lock-step simulation for every tree: select -> forward(planes) -> expand_backup.
         `forward` maps the device planes tensor to (logits [G,2086], value [G,1]) device tensors; if it is a
         PolicyValueNet with the fused hip backend (has `search_eval`) and width is 1, the policy FC is evaluated
-        inside the expansion for the legal moves only (expand_backup_fc) and no logits tensor exists at all."""
+        inside the expansion for the legal moves only (expand_backup_fc) and no logits tensor exists at all.
+        tap (parity tests, bench events): called as tap(planes, z_or_logits, value) between the net and the expansion —
+        the tensors are the ones the expansion kernel is about to read; pre_net() is called between select and the net."""
         net = getattr(forward, "__self__", forward)
         if self.width == 1 and getattr(net, "search_eval", None) is not None and net.fused_search:
             if self.compact:   # terminal / drawn / parked trees cost the net nothing
                 planes, n_rows = self.select_compact(mode, active)
+                if pre_net is not None:
+                    pre_net()
                 z, value = net.search_eval(planes, n_rows)
+                if tap is not None:
+                    tap(planes, z, value)
                 self.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32, compact=True)
             else:
                 planes, _ = self.select(mode, active)
+                if pre_net is not None:
+                    pre_net()
                 z, value = net.search_eval(planes)
+                if tap is not None:
+                    tap(planes, z, value)
                 self.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32)
             return
         planes, _ = self.select(mode, active)
+        if pre_net is not None:
+            pre_net()
         logits, value = forward(planes)
+        if tap is not None:
+            tap(planes, logits, value)
         self.expand_backup(logits, value)
 
     def search(self, forward, playouts, active=None):

@@ -1,0 +1,88 @@
+"""Shared by tests/test_net.py, tests/test_bench_path.py and tests/measure_net_errors.py: weight sets and error metrics
+for the net parity checks (fused bf16 / fp16 MFMA net vs the fp32 NumPy restatement of the reference graph,
+policy_value_network.py:45-74,151-162)."""
+import os
+
+import numpy as np
+import torch
+
+
+def positions(n, seed=0):
+    """Real encoder outputs: planes of corpus positions (one-hot, with quirk Q1), [n,9,10,14] f32."""
+    from oracle import oracle as O
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rules.npz"))
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(len(g["boards"]), n, replace=False)
+    return np.stack([O.encode_planes(g["boards"][i], int(g["side"][i])) for i in idx])
+
+
+def structured_(net, seed=11):
+    """Glorot weights + tap/channel-asymmetric perturbations, non-zero BN statistics and biases (catches tap,
+    channel-order and residual mix-ups that symmetric noise could hide)."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for cb in net.module.convbns():
+            dev = cb.conv.bias.device
+            cb.moving_mean.copy_((torch.randn(cb.moving_mean.shape, generator=gen) * 0.05).to(dev))
+            cb.moving_var.copy_((torch.rand(cb.moving_var.shape, generator=gen) + 0.5).to(dev))
+            cb.conv.bias.copy_((torch.randn(cb.conv.bias.shape, generator=gen) * 0.05).to(dev))
+            w = cb.conv.weight
+            if w.shape[-1] == 3:
+                w[:, :, 0, 1] += 0.01
+                w[:, :, 2, 0] -= 0.015
+                w[:, : w.shape[1] // 2, 1, 2] += 0.02
+    net.refresh()
+    return net
+
+
+def trained_like_(net, seed=5):
+    """A weight set with the statistics of a trained net rather than of Glorot noise: non-negative policy FC weights
+    with a few strong feature -> move links (raw logits are the priors of this engine — quirk Q3 — and a trained net's
+    are positive and peaked on a few moves: |logit| ~ 10, softmax far from uniform), a value head with spread,
+    non-trivial BN statistics and biases."""
+    gen = torch.Generator().manual_seed(seed)
+    m = net.module
+    with torch.no_grad():
+        for cb in m.convbns():
+            dev = cb.conv.bias.device
+            cb.conv.bias.copy_((torch.randn(cb.conv.bias.shape, generator=gen) * 0.05).to(dev))
+            cb.moving_var.copy_((torch.rand(cb.moving_var.shape, generator=gen) * 0.5 + 0.75).to(dev))
+        w = m.policy_fc.weight
+        peaked = (torch.rand(w.shape, generator=gen) < 0.06).to(w.device)
+        w.copy_(w.abs() + peaked * w.abs() * 15.0)
+        m.policy_fc.bias.copy_((torch.rand(2086, generator=gen) * 0.02).to(w.device))
+        # both heads are calibrated on corpus positions, whatever the depth of the tower: the policy FC is scaled so that
+        # the largest logit of a position averages 10; the last value layer so that tanh's argument has mean 0 and std
+        # 0.6 (a Glorot-initialised head answers ~-0.65 +- 0.03 for every position: the search would see no value signal)
+        feats = []
+        hook = m.value_fc2.register_forward_hook(lambda mod, inp, out: feats.append(inp[0].detach()))
+        x = torch.from_numpy(positions(96, 123)).to(w.device).permute(0, 3, 1, 2)
+        logits, _ = m(x)
+        hook.remove()
+        w.mul_(10.0 / float(logits.max(dim=1).values.mean()))
+        pre = feats[0] @ m.value_fc2.weight.t()
+        k = 0.6 / float(pre.std())
+        m.value_fc2.weight.mul_(k)
+        m.value_fc2.bias.fill_(-float(pre.mean()) * k)
+    net.refresh()
+    return net
+
+
+WEIGHT_SETS = {"glorot": lambda net: net, "structured": structured_, "trained_like": trained_like_}
+
+
+def softmax(a):
+    e = np.exp(a - a.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def errors(logits, value, ref_logits, ref_value):
+    """All the quantities the net tolerances are written in."""
+    ml = float(np.abs(ref_logits).max())
+    return dict(max_abs_logit=ml,
+                dlogit=float(np.abs(logits - ref_logits).max()),
+                dlogit_rel=float(np.abs(logits - ref_logits).max() / ml),
+                dprob=float(np.abs(softmax(logits) - softmax(ref_logits)).max()),
+                max_prob=float(softmax(ref_logits).max()),
+                dvalue=float(np.abs(value - ref_value).max()),
+                argmax_agree=float((logits.argmax(axis=1) == ref_logits.argmax(axis=1)).mean()))

@@ -91,3 +91,23 @@ def check_against_golden(results, logs, cases):
             assert r["digest"] == gp["tree_sha256"], "case %s ply %d: whole-tree digest" % (c["name"], ply)
             assert r["evals"] == gp["evals"], "case %s ply %d: number of net evaluations" % (c["name"], ply)
         assert ["%016x" % k for k in logs[g]] == c["eval_keys"], "case %s: evaluated positions / order" % c["name"]
+
+
+def fc_logits_restated(z, w, b):
+    """The arithmetic k_expand_backup<FC> documents (cz_search.hip), restated in NumPy float32 for ALL labels:
+    products p[k] = w[k] * x[k] (x = the (h,w,c) flatten of the two policy channels, padded to 192 with zeros);
+    16 partial sums of 12 consecutive products each, added in order; four symmetric folding steps; + bias.
+    z [G,90,3], w [2086,180], b [2086] -> [G,2086] float32."""
+    G = z.shape[0]
+    x = np.zeros((G, 192), np.float32)
+    x[:, :180] = z[:, :, :2].reshape(G, 180)
+    wp = np.zeros((2086, 192), np.float32)
+    wp[:, :180] = w
+    p = (wp[None, :, :] * x[:, None, :]).astype(np.float32).reshape(G, 2086, 16, 12)
+    s = p[..., 0].copy()
+    for k in range(1, 12):
+        s = (s + p[..., k]).astype(np.float32)
+    l = np.arange(16)
+    for partner in (15 - l, (l & 8) | (7 - (l & 7)), (l & 12) | (3 - (l & 3)), l ^ 1):
+        s = (s + s[..., partner]).astype(np.float32)
+    return (s[..., 0] + b[None, :].astype(np.float32)).astype(np.float32)

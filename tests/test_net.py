@@ -7,17 +7,10 @@ import numpy as np
 import pytest
 import torch
 
+import nethelpers as H
 from oracle import net_numpy
 
-
-def _positions(n, seed=0):
-    """Real encoder outputs: planes of corpus positions (one-hot, with quirk Q1)."""
-    from oracle import oracle as O
-    import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rules.npz"))
-    rng = np.random.default_rng(seed)
-    idx = rng.choice(len(g["boards"]), n, replace=False)
-    return np.stack([O.encode_planes(g["boards"][i], int(g["side"][i])) for i in idx])
+_positions = H.positions
 
 
 @pytest.mark.parametrize("blocks", [1, 2])
@@ -62,21 +55,57 @@ def test_inference_engine_fp32_within_1e3(blocks):
     assert np.allclose(l2, logits[:4], atol=1e-5)
 
 
+# Fused MFMA net (bf16 / fp16 operands, fp32 accumulate) vs the fp32 NumPy restatement of the reference graph.
+# north_star's tolerance (1e-3) is stated for fp32 and is asserted for the fp32 engine above.  A 16-bit tower is a
+# different function: every one of the 2*blocks+1 conv layers rounds its activations to 8 (bf16) or 11 (fp16) mantissa
+# bits, so its error scales with the logits and grows with depth.  Each entry below is (max |dlogit| / max |logit|,
+# max |dsoftmax|, max |dvalue|), set to <= 3x the level MEASURED on an MI355X (tests/measure_net_errors.py ->
+# profiles/r02_net_errors.json; 64 corpus positions) — a kernel regression of 3x fails.  Weight sets (nethelpers.py):
+# glorot = TF-default initialisation (|logit| ~ 0.1, softmax ~ uniform 4.8e-4); trained_like = positive, peaked policy
+# (|logit| ~ 10, top probability 0.2-0.4) and a calibrated value head; structured = tap/channel-asymmetric perturbations.
+NET_TOL = {
+    ("bf16", 2, "glorot"): (2.0e-2, 4.0e-7, 4.0e-4),
+    ("bf16", 7, "glorot"): (2.6e-2, 1.7e-6, 2.1e-3),
+    ("bf16", 19, "glorot"): (7.5e-2, 4.5e-6, 4.5e-3),
+    ("bf16", 3, "structured"): (2.5e-2, 3.0e-6, 1.5e-3),
+    ("bf16", 7, "trained_like"): (3.0e-2, 1.7e-2, 2.3e-1),
+    ("bf16", 19, "trained_like"): (1.1e-1, 8.0e-2, 6.0e-1),
+    ("fp16", 2, "glorot"): (2.4e-3, 5.0e-8, 6.0e-5),
+    ("fp16", 7, "glorot"): (2.8e-3, 1.8e-7, 3.1e-4),
+    ("fp16", 19, "glorot"): (1.0e-2, 5.5e-7, 9.1e-4),
+    ("fp16", 3, "structured"): (3.0e-3, 4.0e-7, 2.0e-4),
+    ("fp16", 7, "trained_like"): (3.3e-3, 2.9e-3, 2.8e-2),
+    ("fp16", 19, "trained_like"): (1.0e-2, 1.4e-2, 8.0e-2),
+}
+
+
 @pytest.mark.gpu
-def test_inference_engine_bf16_probabilities():
+@pytest.mark.parametrize("dname,blocks,wset", sorted(NET_TOL))
+def test_fused_net_vs_fp32_restatement(dname, blocks, wset):
     from cchess_zero_amd.net import PolicyValueNet
-    net = PolicyValueNet(7, "cuda:0", torch.bfloat16, seed=1)
+    net = PolicyValueNet(blocks, "cuda:0", {"bf16": torch.bfloat16, "fp16": torch.float16}[dname], seed=1)
+    assert net.backend == "hip"
+    H.WEIGHT_SETS[wset](net)
     x = _positions(64, 2)
     logits, v = net.forward(x)
-    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, 7)
-
-    def softmax(a):
-        e = np.exp(a - a.max(axis=1, keepdims=True))
-        return e / e.sum(axis=1, keepdims=True)
-    perr = np.abs(softmax(logits) - softmax(ln)).max()
-    print("bf16 tower: max|dlogit| %.4g  max|dprob| %.4g  max|dvalue| %.4g" % (np.abs(logits - ln).max(), perr, np.abs(v - vn).max()))
-    assert perr < 1e-3            # policy compared as probabilities
-    assert np.abs(v - vn).max() < 2e-2   # bf16 storage of 15 conv layers; value head itself is fp32
+    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, blocks)
+    e = H.errors(logits, v, ln, vn)
+    tl, tp, tv = NET_TOL[(dname, blocks, wset)]
+    print("%s %d-block %s: max|logit| %.3g  dlogit %.3g (rel %.3g, tol %.3g)  dprob %.3g (tol %.3g, max prob %.3g)  dvalue %.3g (tol %.3g)" %
+          (dname, blocks, wset, e["max_abs_logit"], e["dlogit"], e["dlogit_rel"], tl, e["dprob"], tp, e["max_prob"], e["dvalue"], tv))
+    assert np.isfinite(logits).all() and np.isfinite(v).all()
+    assert e["dlogit_rel"] <= tl
+    assert e["dprob"] <= tp
+    assert e["dvalue"] <= tv
+    if dname == "fp16" and wset == "glorot" and blocks <= 7:
+        assert e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3   # north_star's absolute 1e-3 is met by fp16 up to 7 blocks
+    # zero-copy 16-channel planes in the net's own dtype (what cz_search_select writes) give the same bits as repacked f32
+    xd = torch.from_numpy(x[:5]).cuda()
+    x16 = torch.zeros((5, 9, 10, 16), dtype=net.dtype, device="cuda")
+    x16[..., :14] = xd.to(net.dtype)
+    l1, v1 = net.forward_device(xd)
+    l2, v2 = net.forward_device(x16)
+    assert torch.equal(l1, l2) and torch.equal(v1, v2)
 
 
 @pytest.mark.gpu
@@ -114,6 +143,10 @@ def test_hip_conv3x3_kernel_vs_torch(B, residual, relu):
     assert bool((err <= tol).all()), "max err %.4g at %s" % (float(err.max()), tuple(int(i) for i in (err == err.max()).nonzero()[0]))
 
 
+# blocks -> (max|dlogit| / max|logit|, max|dsoftmax|, max|dvalue|, max|dtrunk| / max|trunk|)
+HIP_VS_TORCH_TOL = {2: (2.0e-2, 4.0e-7, 4.0e-4, 2.0e-2), 7: (2.0e-2, 1.2e-6, 1.3e-3, 3.0e-2), 19: (7.0e-2, 4.5e-6, 4.5e-3, 6.0e-2)}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend,blocks,n", [("hip", 7, 37), ("hip-layer", 7, 37), ("hip", 2, 1), ("hip", 19, 130)])
 def test_hip_tower_matches_torch_tower(backend, blocks, n):
@@ -128,42 +161,14 @@ def test_hip_tower_matches_torch_tower(backend, blocks, n):
     pa, pb = torch.softmax(la, 1), torch.softmax(lb, 1)
     print("%s vs torch bf16 tower (%d blocks): max|dlogit| %.4g max|dprob| %.4g max|dv| %.4g" %
           (backend, blocks, float((la - lb).abs().max()), float((pa - pb).abs().max()), float((va - vb).abs().max())))
-    assert float((pa - pb).abs().max()) < 1e-3 and float((va - vb).abs().max()) < 2e-2
-    # trunk activations themselves (before the heads), elementwise in bf16 units
+    # two bf16 evaluations of the same folded weights with different rounding points; tolerances <= 3x the measured
+    # level (profiles/r02_net_errors.json: hip_vs_torch_bf16/*), relative to the largest logit / trunk activation
+    tl, tp, tv, tt = HIP_VS_TORCH_TOL[blocks]
+    assert float((la - lb).abs().max()) <= tl * float(lb.abs().max())
+    assert float((pa - pb).abs().max()) <= tp and float((va - vb).abs().max()) <= tv
+    # trunk activations themselves (before the heads), elementwise
     ta, tb = a.tower(x).float(), b.tower(x).float()
-    assert float((ta - tb).abs().max()) <= 0.05 * float(tb.abs().max()) + 1e-2
-
-
-@pytest.mark.gpu
-def test_fused_tower_with_structured_weights():
-    """Tap/channel-asymmetric weights, non-zero BN statistics and biases through the fused tower vs the
-    fp32 NumPy restatement of the TF graph (catches tap, channel-order and residual mix-ups that
-    symmetric Glorot weights could hide)."""
-    from cchess_zero_amd.net import PolicyValueNet
-    net = PolicyValueNet(3, "cuda:0", torch.bfloat16, seed=2, backend="hip")
-    gen = torch.Generator().manual_seed(11)
-    with torch.no_grad():
-        for cb in net.module.convbns():
-            cb.moving_mean.copy_((torch.randn(cb.moving_mean.shape, generator=gen) * 0.05).to(cb.moving_mean.device))
-            cb.moving_var.copy_((torch.rand(cb.moving_var.shape, generator=gen) + 0.5).to(cb.moving_var.device))
-            cb.conv.bias.copy_((torch.randn(cb.conv.bias.shape, generator=gen) * 0.05).to(cb.conv.bias.device))
-            w = cb.conv.weight
-            if w.shape[-1] == 3:
-                w[:, :, 0, 1] += 0.01
-                w[:, :, 2, 0] -= 0.015
-                w[:, : w.shape[1] // 2, 1, 2] += 0.02
-    net.refresh()
-    x = _positions(16, 5)
-    logits, v = net.forward(x)
-    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, 3)
-
-    def softmax(a):
-        e = np.exp(a - a.max(axis=1, keepdims=True))
-        return e / e.sum(axis=1, keepdims=True)
-    print("structured weights: max|dlogit| %.4g, max|dprob| %.4g, max|dv| %.4g" % (np.abs(logits - ln).max(), np.abs(softmax(logits) - softmax(ln)).max(), np.abs(v - vn).max()))
-    assert np.abs(softmax(logits) - softmax(ln)).max() < 1e-3
-    assert np.abs(logits - ln).max() < 0.05 * np.abs(ln).max() + 1e-2
-    assert np.abs(v - vn).max() < 2e-2
+    assert float((ta - tb).abs().max()) <= tt * float(tb.abs().max())
 
 
 @pytest.mark.gpu
@@ -248,34 +253,15 @@ def test_tower_variants_agree(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blocks,n", [(2, 5), (7, 64), (19, 33)])
-def test_inference_engine_fp16_fused(blocks, n):
-    """The fused kernel with fp16 operands (cz_net_trunk_f16, BASELINE.json configs[4]) against the fp32 NumPy
-    restatement of the reference graph: fp16 keeps 11 significant bits, so the raw logits and the value are held
-    to the north-star 1e-3 relative to the largest logit (bf16 only meets that on probabilities)."""
+@pytest.mark.parametrize("blocks,n", [(2, 5), (7, 33)])
+def test_fp16_trunk_route_consistent(blocks, n):
+    """cz_net_trunk_f16: the trunk-output route (tower() + torch heads) agrees with the fused heads route."""
     from cchess_zero_amd.net import PolicyValueNet
     net = PolicyValueNet(blocks, "cuda:0", torch.float16, seed=3)
     assert net.backend == "hip"
-    gen = torch.Generator().manual_seed(5)
-    with torch.no_grad():   # non-trivial biases / BN statistics so every epilogue term is exercised
-        for cb in net.module.convbns():
-            cb.conv.bias.copy_((torch.randn(cb.conv.bias.shape, generator=gen) * 0.05).cuda())
-            cb.moving_var.copy_((torch.rand(cb.moving_var.shape, generator=gen) * 0.5 + 0.75).cuda())
-    net.refresh()
-    x = _positions(n, 11)
-    logits, v = net.forward(x)
-    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, blocks)
-    scale = np.abs(ln).max()
-    print("fp16 fused (%d blocks): max|dlogit| %.4g (max|logit| %.3g)  max|dvalue| %.4g" % (blocks, np.abs(logits - ln).max(), scale, np.abs(v - vn).max()))
-    assert np.abs(logits - ln).max() < 1e-3 * max(scale, 1.0) * (1 + blocks / 4)
-    assert np.abs(v - vn).max() < 1e-3 * (1 + blocks / 4)
-    # zero-copy fp16x16 planes (what cz_search_select writes with CZ_F16) give the same bits as repacked f32 planes
-    xd = torch.from_numpy(x).cuda()
-    x16 = torch.zeros((n, 9, 10, 16), dtype=torch.float16, device="cuda")
-    x16[..., :14] = xd.to(torch.float16)
+    xd = torch.from_numpy(_positions(n, 11)).cuda()
     l1, v1 = net.forward_device(xd)
-    l2, v2 = net.forward_device(x16)
-    assert torch.equal(l1, l2) and torch.equal(v1, v2)
-    # trunk output route (tower()) is consistent with the heads route
     l3, v3 = net.heads(net.tower(xd))
-    assert float((l1 - l3).abs().max()) < 2e-3 * max(float(l3.abs().max()), 1.0) and float((v1 - v3).abs().max()) < 2e-3
+    dl, dv = float((l1 - l3).abs().max()), float((v1 - v3).abs().max())
+    print("fp16 %d-block trunk route vs fused heads: max|dlogit| %.3g (max|logit| %.3g) max|dvalue| %.3g" % (blocks, dl, float(l3.abs().max()), dv))
+    assert dl < 2e-3 * max(float(l3.abs().max()), 1.0) and dv < 2e-3
