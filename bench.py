@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — MCTS simulations/sec of the MI355X hot path (select -> batched net -> expand/backup).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched through
-torch.distributed.run, one rank per GPU.  One "step" = one lock-step simulation of EVERY game tree on
-the rank (G simulations); after every `--playout` simulations the trees advance one ply
-(root-visit argmax -> cz_search_advance, the update_tree of the reference) so long runs stay in the
-self-play regime.  Rank 0 prints ONE JSON line.  Metric/config follow BASELINE.json:
-"MCTS simulations/sec (whole node), playout=1600, 7-block net", 8192 games per GPU (configs[2]).
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it through
+torch.distributed.run, one rank per GPU; run from a bare shell (`python bench.py --gpus 2`, WORLD_SIZE unset) it
+launches the N ranks itself.  One "step" = one lock-step simulation of EVERY game tree on the rank (G simulations);
+after every `--playout` simulations the trees advance one ply (root-visit argmax -> cz_search_advance, the update_tree of
+the reference) so long runs stay in the self-play regime.  Rank 0 prints ONE JSON line.  Metric/config follow
+BASELINE.json: "MCTS simulations/sec (whole node), playout=1600, 7-block net", 8192 games per GPU (configs[2]).
+
+Opt-in modes:
+  --selfplay       the timed region is the whole device-resident self-play loop (cchess_zero_amd/selfplay.py: search,
+                   visit-count policy, Dirichlet-noise sampling, records, re-rooting, adjudication, re-seeding of finished
+                   games); a step is then one PLY of every game (playout + 1 search steps) and sims/s counts completed
+                   simulations from the device counters.
+  --timed-gather   (with --selfplay, N > 1) after every ply each rank drains the records of the games that finished and
+                   all ranks all-gather them over RCCL inside the timed region — the exchange step of configs[3].
 
 Inputs are synthetic: seeded random-playout positions generated on the GPU with the rules kernels,
 Glorot-uniform weights (seed 0).  Nothing here reads /root/reference.
@@ -14,6 +22,8 @@ Glorot-uniform weights (seed 0).  Nothing here reads /root/reference.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +39,23 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense peak
 
 START = np.array([3, 5, 4, 2, 1, 2, 4, 5, 3] + [0] * 9 + [0, 7, 0, 0, 0, 0, 0, 7, 0] + [6, 0, 6, 0, 6, 0, 6, 0, 6] + [0] * 18 +
                  [13, 0, 13, 0, 13, 0, 13, 0, 13] + [0, 14, 0, 0, 0, 0, 0, 14, 0] + [0] * 9 + [10, 12, 11, 9, 8, 9, 11, 12, 10], np.uint8)
+
+# The unmodified reference (pure Python) timed in the build container — it cannot run on the GPU box, where
+# /root/reference does not exist; recorded in BASELINE.md and attached to the line as static, labelled fields.
+REFERENCE_PYTHON = {
+    "search_only_sims_per_s_per_core": 405, "end_to_end_2block_sims_per_s": 237, "end_to_end_7block_sims_per_s": 157,
+    "where": "build container (8 vCPU), tools/time_reference.py on the unmodified reference, recorded in BASELINE.md; "
+             "static numbers, not measured in this run",
+}
+
+
+def default_nodes_per_tree(playout):
+    """Node pool capacity per tree.  A ply adds ~40 nodes per simulation on top of the subtree kept from the previous
+    ply (the most visited child's share of the tree).  One pool per tree (cz_search_advance compacts in place); a tree
+    that does fill its pool stops expanding for the rest of the ply, is flagged, and gets its room back at the advance.
+    128 nodes per simulation: 8192 trees x 205 056 nodes x 28 B = 47 GB (round 1: two pools of 160 per simulation,
+    118 GB)."""
+    return (int(playout) + 2) * 128
 
 
 def synth_positions(rules, G, seed, max_ply=80):
@@ -59,23 +86,21 @@ def synth_positions(rules, G, seed, max_ply=80):
     return boards.contiguous(), side.contiguous(), rr.contiguous()
 
 
-def cpu_baseline(blocks, seconds_target=15.0):
-    """CPU port timed on this host: C oracle search (oracle/) + NumPy fp32 net restatement, a bounded
-    sample of the same workload (same position generator family, playout-style lock-step).  Test
-    infrastructure used as the *baseline being measured*, never as the product path."""
+# ---- CPU baseline: the C oracle's search + a torch-CPU (oneDNN) fp32 net on this host's cores -----------------------------
+def _cpu_worker(args):
+    """One worker process: `games` trees searched in lock-step by the C oracle (oracle/, the pinned restatement of the
+    reference's search), leaves evaluated in one batch by the fp32 torch module on `threads` CPU threads."""
+    idx, games, threads, blocks, seconds = args
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    os.environ["CUDA_VISIBLE_DEVICES"] = ""
+    import torch as T
+    T.set_num_threads(int(threads))
     from oracle import oracle as O
-    from oracle import net_numpy
     from cchess_zero_amd.net import PolicyValueModule
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
-    cores = os.cpu_count() or 1
-    G = 128   # enough rows per net call to keep the BLAS threads of a many-core host busy
-    rng = np.random.default_rng(0)
-    boards = np.tile(START, (G, 1))
-    side = np.zeros(G, np.uint8)
-    for g in range(G):  # short random playouts with the oracle
+    rng = np.random.default_rng(idx)
+    boards = np.tile(START, (games, 1))
+    side = np.zeros(games, np.uint8)
+    for g in range(games):  # short random playouts with the oracle
         b, s = boards[g].copy(), 0
         for _ in range(int(rng.integers(0, 60))):
             mv = O.legal_moves(b, s)
@@ -86,27 +111,65 @@ def cpu_baseline(blocks, seconds_target=15.0):
                 break
             b, s = nb, s ^ 1
         boards[g], side[g] = b, s
-    w = PolicyValueModule(blocks, seed=0).export_tf_layout()
-    s = O.Search(G, 20000)
-    s.reset(boards, side, None)
-    ctxm = threadpool_limits(limits=cores) if threadpool_limits else None
+    m = PolicyValueModule(blocks, seed=0).eval()
+    srch = O.Search(games, 40000)
+    srch.reset(boards, side, None)
     t0 = time.perf_counter()
-    sims = 0
-    step = 0
-    while True:
-        planes, need = s.select(0 if step == 0 else 1)
-        logits, v = net_numpy.forward(w, planes, blocks)
-        s.expand_backup(logits, v)
-        if step > 0:
-            sims += G
-        step += 1
-        if time.perf_counter() - t0 > seconds_target and step > 2:
-            break
-    dt = time.perf_counter() - t0
-    if ctxm is not None:
-        ctxm.__exit__(None, None, None)
-    return {"value": sims / dt, "unit": "sims/s", "cores": cores, "kind": "port",
-            "sample": "%d games x %d lock-step simulations, C oracle search + NumPy fp32 %d-block net, %.1f s" % (G, step - 1, blocks, dt)}
+    sims, step = 0, 0
+    with T.no_grad():
+        while True:
+            planes, need = srch.select(0 if step == 0 else 1)
+            lg, v = m(T.from_numpy(planes).permute(0, 3, 1, 2))
+            srch.expand_backup(lg.numpy(), v.numpy())
+            if step > 0:
+                sims += games
+            step += 1
+            if time.perf_counter() - t0 > seconds and step > 2:
+                break
+    return sims, time.perf_counter() - t0, step - 1
+
+
+def cpu_baseline(blocks, seconds_target=12.0):
+    """The CPU port timed on this host, single core and all cores: C oracle search + fp32 torch-CPU
+    net, a bounded sample of the same workload family.  Test infrastructure used as the *baseline being measured*, never
+    as the product path.  `value` is the all-core figure."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    ctx = mp.get_context("spawn")
+    out = {"unit": "sims/s", "kind": "port", "reference_python": REFERENCE_PYTHON}
+    try:
+        with ctx.Pool(1) as pool:
+            s, dt, steps = pool.map(_cpu_worker, [(0, 8, 1, blocks, seconds_target * 0.5)])[0]
+        out["single_core"] = {"value": s / dt, "cores": 1,
+                              "sample": "8 games x %d lock-step simulations, 1 thread, %.1f s" % (steps, dt)}
+        tpw = 16 if cores >= 32 else max(1, cores // 2)     # threads per worker process
+        workers = max(1, cores // tpw)
+        games = 256
+        with ctx.Pool(workers) as pool:
+            res = pool.map(_cpu_worker, [(i + 1, games, tpw, blocks, seconds_target) for i in range(workers)])
+        out["value"] = float(sum(s / dt for s, dt, _ in res))
+        out["cores"] = workers * tpw
+        out["sample"] = ("%d worker processes x %d threads, each %d games x ~%d lock-step simulations: C oracle search + fp32 "
+                         "torch-CPU (oneDNN) %d-block net, %.1f s" % (workers, tpw, games, int(np.mean([st for _, _, st in res])), blocks,
+                                                                       float(np.mean([dt for _, dt, _ in res]))))
+    except Exception as e:   # the GPU number must survive a failing baseline leg
+        out.setdefault("value", None)
+        out.setdefault("cores", cores)
+        out["error"] = repr(e)
+    return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks through torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -122,18 +185,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
     ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--search-threads", type=int, default=1, help="simulations in flight per tree and step (the reference's search_threads; virtual loss 3); batch = games * search_threads")
     ap.add_argument("--graph", action="store_true", help="replay the four launches of a step as one captured HIP graph (measured: no gain, the host already runs ahead of the GPU)")
     ap.add_argument("--compact", action="store_true", help="compact evaluation batches: no net row for terminal / drawn leaves (no gain at 8192 trees: the trunk runs in rounds of 1024 rows)")
     ap.add_argument("--full-policy-fc", action="store_true", help="compute all 2086 logits per leaf (k_policy_fc) instead of folding the policy FC into the expansion")
-    ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 80: no tree can run out)")
+    ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 128)")
+    ap.add_argument("--selfplay", action="store_true", help="time the device-resident self-play loop; a step = one ply of every game")
+    ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records after every ply, inside the timed region")
+    ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    dist = None
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -150,6 +220,7 @@ def main():
         local_rank = 0
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if (dist_on and args.dist_backend == "nccl") else torch.device("cpu")   # where collectives run
 
     from cchess_zero_amd.engine import Context, SearchEngine
     from cchess_zero_amd.net import PolicyValueNet, flops_per_position
@@ -157,51 +228,43 @@ def main():
 
     G, playout = args.games, args.playout
     tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-    # node pool per tree: a ply adds ~40 nodes per simulation on top of the subtree kept from the previous ply; 160 per
-    # simulation has held over 6+ plies of this workload (80 overflowed 3 000 of 8192 trees by the fourth ply).  Same-box
-    # A/B: the capacity does not change the step time (2.300 ms at 128 160 and at 256 320 nodes per tree).  Simulations
-    # are counted, so an overflowing (parked) tree could not inflate the result anyway.
-    cap = args.nodes_per_tree or (playout + 2) * 160
+    cap = args.nodes_per_tree or default_nodes_per_tree(playout)
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
     # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
     fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16")
     K = max(1, args.search_threads)
+    if args.selfplay and K != 1:
+        ap.error("--selfplay runs one simulation in flight per tree")
     eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx, width=K)
     net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
-    fused_fc = net.fused_search and not args.full_policy_fc and K == 1
+    if args.full_policy_fc:
+        net.fuse_policy_fc = False
+    fused_fc = net.fused_search and K == 1
     compact = fused_fc and args.compact   # leaves that need no net evaluation are not in the net's batch
+    eng.compact = compact
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
-    eng.reset(boards, side, rr)
+    if args.selfplay and args.start_position:
+        boards = torch.from_numpy(np.tile(START, (G, 1))).to(dev)
+        side, rr = torch.zeros_like(side), torch.zeros_like(rr)
 
-    ev_net = []  # (start, end) events around the net forward of every timed step
-    conv_ev = []  # (start, end) events around single launches of the dominant kernel
-
+    ev = []        # per sampled step: (before select, after select, after net, after expand) HIP events
+    conv_ev = []   # (start, end) events around single launches of the dominant kernel (recorded inside the net)
     step_no = [0]
 
     def one_step(mode, timed):
-        # HIP events around every conv launch of every 8th timed step (same stream as the launches)
-        net.conv_events = conv_ev if (timed and step_no[0] % 8 == 0) else None
+        # HIP events around the launches of every 8th timed step (recorded on the stream the kernels are launched on)
+        sample = timed and step_no[0] % 8 == 0
+        net.conv_events = conv_ev if sample else None
         step_no[0] += 1
-        n_rows = None
-        if compact:
-            planes, n_rows = eng.select_compact(mode)
-        else:
-            planes, _ = eng.select(mode)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        if fused_fc:   # trunk + value head; the policy FC runs inside the expansion kernel for the legal moves only
-            z, value = net.search_eval(planes, n_rows)
-        else:
-            logits, value = net.forward_device(planes)
-        if timed:
-            e1.record()
-            ev_net.append((e0, e1))
-        if fused_fc:
-            eng.expand_backup_fc(z, value, net.pfc_w_rows, net.pfc_b_f32, compact=compact)
-        else:
-            eng.expand_backup(logits, value)
+        if not sample:
+            eng.step(net.forward_device, mode=mode)
+            return
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        eng.step(net.forward_device, mode=mode, pre_net=e[1].record, tap=lambda *a: e[2].record())
+        e[3].record()
+        ev.append(e)
 
     gather_ok = None   # N > 1: result of the (untimed) record all-gather
     banked = [0]   # simulations completed in plies that were closed inside the timed region (k > 1 accounting)
@@ -218,7 +281,6 @@ def main():
         one_step(0, False)  # expand roots that were never visited
 
     sims_in_ply = 0
-
     graph = [None]   # the steady-state step (4 launches, static arguments) captured as one HIP graph
 
     def run(nsteps, timed):
@@ -227,7 +289,7 @@ def main():
             if sims_in_ply >= playout:
                 advance_ply()
                 sims_in_ply = 0
-            # every 8th timed step runs eagerly so that HIP events can bracket the trunk launch on its stream
+            # every 8th timed step runs eagerly so that HIP events can bracket the launches on their stream
             if graph[0] is not None and not (timed and step_no[0] % 8 == 0):
                 step_no[0] += 1
                 graph[0].replay()
@@ -235,10 +297,32 @@ def main():
                 one_step(1, timed)
             sims_in_ply += K
 
-    one_step(0, False)          # MCTS_tree.main root expansion (not a simulation)
-    run(args.warmup, False)
+    sp = None
+    gather_stats = {"gathers": 0, "records": 0, "seconds": 0.0}
+    if args.selfplay:
+        from cchess_zero_amd import parallel
+        from cchess_zero_amd.selfplay import SelfPlay
+        sp = SelfPlay(eng, net, playout, exploration=True, temperature=1.0, seed=77 + rank, continuous=True)
+        sp.start(boards, side, rr)
+        eng.compact = compact
+
+        def run_plies(n, timed):
+            for _ in range(n):
+                sp.step_ply()
+                if timed and args.timed_gather and dist_on:
+                    t1 = time.perf_counter()
+                    rec = sp.drain_device()                       # device rows of the games that just finished
+                    allrec, counts = parallel.gather_records_device(rec if cdev.type == "cuda" else rec.cpu())
+                    gather_stats["gathers"] += 1
+                    gather_stats["records"] += int(counts.sum().item())
+                    gather_stats["seconds"] += time.perf_counter() - t1
+        run_plies(args.warmup, False)
+    else:
+        eng.reset(boards, side, rr)
+        one_step(0, False)          # MCTS_tree.main root expansion (not a simulation)
+        run(args.warmup, False)
     torch.cuda.synchronize()
-    if args.graph and fused_fc and not compact:
+    if args.graph and fused_fc and not compact and not args.selfplay:
         try:   # capture AFTER the warm-up (kernel attributes set, allocator warm); a failure falls back to eager launches
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
@@ -253,31 +337,42 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    sims0 = int(eng.status()[2].sum().item())
+    sims0 = int(sp.sims_t.item()) if sp else int(eng.status()[2].sum().item())
     rows0, csteps0 = eng.eval_totals() if compact else (0, 0)
     banked[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, True)
+    if sp:
+        run_plies(args.steps, True)
+    else:
+        run(args.steps, True)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    my_dt = dt
     if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # outside the timed region: the record exchange of the self-play loop (one all-gather of packed
-        # (s, pi, z) records over RCCL) on a token batch, so the N>1 run exercises the collective path too
+        # outside the timed region: the record exchange of the self-play loop (one all-gather of packed (s, pi, z) records,
+        # device-resident end to end) on a ragged token batch, so every N>1 run exercises the collective path
         from cchess_zero_amd import parallel, selfplay
-        tok = np.zeros((4 + rank, selfplay.REC_BYTES), np.uint8)
+        tok = torch.zeros((4 + rank, selfplay.REC_BYTES), dtype=torch.uint8, device=cdev)
         tok[:, 0] = rank + 1
         try:
-            allrec = parallel.gather_records(tok, device=dev if args.dist_backend == "nccl" else "cpu")
-            gather_ok = bool(allrec.shape[0] == sum(4 + r for r in range(world)) and int(allrec[-1, 0]) == world)
+            allrec, counts = parallel.gather_records_device(tok)
+            gather_ok = bool(counts.tolist() == [4 + r for r in range(world)] and int(allrec[world - 1, 0, 0]) == world)
         except Exception as e:   # the throughput number above must survive a failure of this (untimed) exchange
             gather_ok = "failed: %r" % (e,)
+
+    my_sims = (int(sp.sims_t.item()) - sims0) if sp else (banked[0] + int(eng.status()[2].sum().item()) - sims0)
+    if sp:   # the self-play loop launches through SelfPlay.step_ply: sample the kernels' durations on 16 extra, uncounted steps
+        for _ in range(16):
+            step_no[0] = 0
+            one_step(1, True)
+        torch.cuda.synchronize()
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed
     # rocprofv3 --pmc measurement of the same launch shape is attached when the configuration matches.
@@ -296,22 +391,30 @@ def main():
     bad = int((st & ~8).ne(0).sum().item())
     st_bits = {name: int(((st & bit) != 0).sum().item()) for name, bit in
                (("pool_exhausted", 1), ("no_moves", 2), ("move_overflow", 4), ("bad_advance", 8))}
-    net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net])) if ev_net else float("nan")
+    el = lambda a, b: a.elapsed_time(b)
+    net_ms = float(np.mean([el(e[1], e[2]) for e in ev])) if ev else float("nan")
+    sel_us = float(np.mean([el(e[0], e[1]) for e in ev])) * 1e3 if ev else float("nan")
+    exp_us = float(np.mean([el(e[2], e[3]) for e in ev])) * 1e3 if ev else float("nan")
     # simulations are COUNTED (completed backups, per-tree device counters), not assumed: a parked tree (node pool
     # exhausted) or an abandoned descent (k > 1) contributes nothing.  With k = 1 and no parked tree this is G * steps.
-    mine = torch.tensor([banked[0] + int(sims.sum().item()) - sims0], dtype=torch.float64, device=dev if (dist_on and args.dist_backend == "nccl") else "cpu")
+    mine = torch.tensor([float(my_sims)], dtype=torch.float64, device=cdev)
+    per_rank = [float(my_sims) / my_dt]
     if dist_on:
+        pr = torch.zeros(world, dtype=torch.float64, device=cdev)
+        pr[rank] = float(my_sims) / my_dt
+        dist.all_reduce(pr)
+        per_rank = pr.tolist()
         dist.all_reduce(mine)
     total_sims = float(mine.item())
     # rows the net evaluated per launch: all G without compaction, else the measured mean over the timed region
-    rows_per_launch = float(G)
+    rows_per_launch = float(G * K)
     if compact:
         rows1, csteps1 = eng.eval_totals()
         rows_per_launch = (rows1 - rows0) / max(1, csteps1 - csteps0)
     flops = flops_per_position(args.blocks) * rows_per_launch
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     if conv_ev:
-        # dominant kernel: k_conv3x3_c128 (one launch = one fused tower layer over the whole batch)
+        # dominant kernel: the fused trunk (one launch = first conv + all tower layers + head convs over the whole batch)
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
         nl = 2 * args.blocks if net.backend == "hip" else 1   # fused tower: one launch = all 2*blocks conv layers
         conv_flops = 2.0 * rows_per_launch * 90 * 1152 * 128 * nl
@@ -327,6 +430,25 @@ def main():
         roof = {"bound": "mfma", "kernel": "net forward via torch/MIOpen (conv tower + heads), all launches of one step",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                 "ms_per_launch_group": net_ms, "flops_per_step": flops}
+    # second roofline entry: the HBM-bound tree / rules side of a step (k_select = selection descent + make-move + move
+    # generation + plane encoding; k_expand_backup = policy FC at the legal labels + node append + backup).  Algorithmic
+    # bytes per tree: select  depth * L * 20 B of sibling statistics + 96 B root board + 2 B * L pending
+    # moves + the leaf planes (2 880 B in 16-bit x 16 channels, 5 040 B in f32 x 14); expand  1 080 B of head outputs +
+    # 28 B * L new nodes + 12 B * depth of backup (+ the 4 172 B logits row without the folded FC).
+    mean_depth = float(depth.float().mean().item())
+    mean_L = float((eng.root_stats()["count"].to(torch.int64) & 0xFFFF).float().mean().item())
+    plane_b = 2880.0 if fused else 5040.0
+    b_sel = G * (mean_depth * mean_L * 20.0 + 96.0 + 2.0 * mean_L + plane_b)
+    b_exp = G * ((1080.0 if fused_fc else 2086.0 * 4) + 28.0 * mean_L + 12.0 * mean_depth)
+    tree_roof = None
+    if ev and K == 1:
+        ach = (b_sel + b_exp) / ((sel_us + exp_us) * 1e-6) / 1e9
+        tree_roof = {"bound": "hbm", "kernel": "k_select + k_expand_backup%s (tree + rules side of a step)" % ("<FC>" if fused_fc else ""),
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "us_select": sel_us, "us_expand_backup": exp_us, "algorithmic_bytes_select": b_sel, "algorithmic_bytes_expand": b_exp,
+                     "select_GBps": b_sel / (sel_us * 1e-6) / 1e9, "expand_GBps": b_exp / (exp_us * 1e-6) / 1e9,
+                     "mean_leaf_depth": mean_depth, "mean_children": mean_L,
+                     "note": "latency/issue-bound kernels: one dependent HBM round trip per tree level; 3 % of a step"}
     if (G, playout, args.blocks) == (8192, 1600, 7):
         cfg_name = "BASELINE.json configs[2]" + ("; per-GPU share of configs[3]" if world > 1 else "")
     elif (G, playout, args.blocks, args.dtype) == (8192, 1600, 19, "fp16"):
@@ -335,19 +457,27 @@ def main():
         cfg_name = "BASELINE.json configs[1]"
     else:
         cfg_name = "custom configuration"
+    cfg = {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)%s" % (G, playout, args.blocks, args.dtype, cfg_name, "; device-resident self-play loop, step = one ply" if sp else ""),
+           "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits",
+           "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "hip_graph": graph[0] is not None, "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
+           "positions": "seeded random playouts from the start position, ply~U[0,80]",
+           "nodes_per_tree": cap, "node_pool_GB": G * cap * 28 / 1e9,
+           "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "per_rank_sims_per_s": per_rank,
+           "simulations_counted": total_sims, "simulations_nominal": float(G) * args.steps * world * K * ((playout) if sp else 1),
+           "mean_leaf_depth": mean_depth, "mean_nodes_per_tree": float(nodes.float().mean().item()),
+           "trees_with_error_status": bad, "status_bits": st_bits}
+    if sp:
+        s = sp.stats()
+        cfg["selfplay"] = {"plies_timed": args.steps, "games_finished": s["games"], "red_wins": s["red_wins"], "black_wins": s["black_wins"],
+                           "draws": s["draws"], "records": s["plies"], "stalled_games": s["stalled"], "dropped_records": s["dropped"],
+                           "game_generations": s["games"] / float(G), "timed_gather": bool(args.timed_gather and dist_on),
+                           "gathers": gather_stats["gathers"], "gathered_records": gather_stats["records"],
+                           "gather_seconds_rank0": gather_stats["seconds"]}
     out = {
         "metric": "MCTS simulations/sec (whole node), playout=%d, %d-block net" % (playout, args.blocks),
         "value": total_sims / dt, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)" % (G, playout, args.blocks, args.dtype, cfg_name),
-                   "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits",
-                   "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "hip_graph": graph[0] is not None, "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
-                   "positions": "seeded random playouts from the start position, ply~U[0,80]",
-                   "simulations_counted": total_sims, "simulations_nominal": float(G) * args.steps * world * K,
-                   "mean_leaf_depth": float(depth.float().mean().item()), "mean_nodes_per_tree": float(nodes.float().mean().item()),
-                   "trees_with_error_status": bad, "status_bits": st_bits},
-        "roofline": roof,
+        "dtype": args.dtype, "data": "synthetic", "config": cfg, "roofline": roof, "roofline_tree": tree_roof,
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -35,8 +35,9 @@ void carve_pool(Carver &c, CzPool &p, size_t n) {
     p.child_count = c.take<uint16_t>(n); p.move = c.take<uint16_t>(n);
 }
 
-void carve_trees(Carver &c, CzTrees &t, size_t G) {
-    t.cur = c.take<int32_t>(G);
+void carve_trees(Carver &c, CzTrees &t, size_t G, size_t words) {
+    t.mark_bits = c.take<unsigned long long>(G * words);
+    t.mark_rank = c.take<uint32_t>(G * words);
     t.root_board = c.take<uint8_t>(G * CZD_BOARD_LDS);
     t.root_side = c.take<uint8_t>(G);
     t.root_rr = c.take<int32_t>(G); t.root_node = c.take<int32_t>(G); t.n_nodes = c.take<int32_t>(G);
@@ -56,7 +57,7 @@ void carve_trees(Carver &c, CzTrees &t, size_t G) {
 extern "C" {
 
 const char *cz_last_error(void) { return g_err; }
-int cz_version(void) { return 100; }
+int cz_version(void) { return 200; }
 
 int cz_tables(const int16_t **lut, const int16_t **unflip, const char **labels, const uint16_t **srcdst) {
     const CzHostTables &t = cz_host_tables();
@@ -107,26 +108,28 @@ int cz_create(int device, int max_games, int max_nodes_per_tree, cz_ctx **out) {
     {
         Carver m{nullptr};
         CzTrees dummy;
-        carve_trees(m, dummy, (size_t)max_games);
+        const size_t words = ((size_t)max_nodes_per_tree + 63) / 64;
+        carve_trees(m, dummy, (size_t)max_games, words);
         if (hipMalloc(&c->tree_block, m.off) != hipSuccess) { cz_set_error("cz_create: hipMalloc(trees, %zu B) failed", m.off); cz_destroy(c); return CZ_ENOMEM; }
         CZ_HIP(hipMemset(c->tree_block, 0, m.off));
         Carver k{(char *)c->tree_block};
-        carve_trees(k, c->t, (size_t)max_games);
+        carve_trees(k, c->t, (size_t)max_games, words);
         c->t.cap = max_nodes_per_tree;
+        c->t.words = (int)words;
     }
-    // node pools (live + compaction target)
+    // node pool: ONE pool of cap nodes per tree (cz_search_advance compacts the kept subtree in place)
     const size_t n = (size_t)max_games * (size_t)max_nodes_per_tree;
-    for (int w = 0; w < 2; ++w) {
+    {
         Carver m{nullptr};
         CzPool dummy;
         carve_pool(m, dummy, n);
-        if (hipMalloc(&c->pool_block[w], m.off) != hipSuccess) {
-            cz_set_error("cz_create: hipMalloc(node pool %d, %zu B) failed", w, m.off);
+        if (hipMalloc(&c->pool_block, m.off) != hipSuccess) {
+            cz_set_error("cz_create: hipMalloc(node pool, %zu B) failed", m.off);
             cz_destroy(c);
             return CZ_ENOMEM;
         }
-        Carver k{(char *)c->pool_block[w]};
-        carve_pool(k, c->t.pool[w], n);
+        Carver k{(char *)c->pool_block};
+        carve_pool(k, c->t.pool, n);
     }
     *out = c;
     return CZ_OK;
@@ -138,8 +141,8 @@ void cz_destroy(cz_ctx *c) {
     if (c->pend_block) (void)hipFree(c->pend_block);
     if (c->tab_block) (void)hipFree(c->tab_block);
     if (c->tree_block) (void)hipFree(c->tree_block);
-    for (int w = 0; w < 2; ++w)
-        if (c->pool_block[w]) (void)hipFree(c->pool_block[w]);
+    if (c->pool_block) (void)hipFree(c->pool_block);
+    if (c->sp_block) (void)hipFree(c->sp_block);
     delete c;
 }
 
@@ -306,14 +309,68 @@ int cz_search_status(cz_ctx *c, int32_t *status, int32_t *nodes, int32_t *sims, 
     return CZ_OK;
 }
 
+int cz_selfplay_begin(cz_ctx *c, int max_plies, const uint8_t *boards, const uint8_t *side, const int32_t *rr) {
+    CZ_REQUIRE(c && c->G > 0, "cz_selfplay_begin: call cz_search_reset first");
+    CZ_REQUIRE(max_plies >= 1 && max_plies <= 65535, "cz_selfplay_begin: 1 <= max_plies <= 65535");
+    CZ_REQUIRE(boards == nullptr || side != nullptr, "cz_selfplay_begin: start_side required with start_boards");
+    if (!c->sp_block || c->sp.max_plies != max_plies) {
+        CZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->sp_block) { (void)hipFree(c->sp_block); c->sp_block = nullptr; }
+        const size_t G = (size_t)c->max_games;
+        auto carve = [&](Carver &k, CzSelfplay &sp) {
+            sp.hist = k.take<uint8_t>(G * (size_t)max_plies * CZ_REC_BYTES);
+            sp.ply = k.take<int32_t>(G);
+            sp.stalled = k.take<uint8_t>(G);
+            sp.active = k.take<uint8_t>(G);
+            sp.fin_winner = k.take<int8_t>(G);
+            sp.start_board = k.take<uint8_t>(G * CZD_BOARD_LDS);
+            sp.start_side = k.take<uint8_t>(G);
+            sp.start_rr = k.take<int32_t>(G);
+            sp.stats = k.take<long long>(CZ_SP_NSTATS);
+        };
+        Carver m{nullptr};
+        CzSelfplay dummy;
+        carve(m, dummy);
+        if (hipMalloc(&c->sp_block, m.off) != hipSuccess) { c->sp_block = nullptr; cz_set_error("cz_selfplay_begin: hipMalloc(%zu B) failed", m.off); return CZ_ENOMEM; }
+        Carver k{(char *)c->sp_block};
+        carve(k, c->sp);
+        c->sp.max_plies = max_plies;
+    }
+    return czk_selfplay_seed(c, boards, side, rr);
+}
+int cz_selfplay_active(cz_ctx *c, const uint8_t **active) {
+    CZ_REQUIRE(c && c->sp_block && active, "cz_selfplay_active: call cz_selfplay_begin first");
+    *active = c->sp.active;
+    return CZ_OK;
+}
+int cz_selfplay_choose(cz_ctx *c, const float *gamma, const float *u, const uint16_t *forced, double temperature, float eps, uint16_t *played) {
+    CZ_REQUIRE(c && c->sp_block && c->G > 0, "cz_selfplay_choose: call cz_selfplay_begin first");
+    CZ_REQUIRE(u && played, "cz_selfplay_choose: u and played required");
+    CZ_REQUIRE(temperature > 0.0 && eps >= 0.f && eps <= 1.f, "cz_selfplay_choose: temperature > 0 and 0 <= noise_eps <= 1 required");
+    return czk_selfplay_choose(c, gamma, u, forced, temperature, eps, played);
+}
+int cz_selfplay_adjudicate(cz_ctx *c, int reseed, int32_t *fin_n) {
+    CZ_REQUIRE(c && c->sp_block && c->G > 0 && fin_n, "cz_selfplay_adjudicate: call cz_selfplay_begin first / null fin_n");
+    return czk_selfplay_adjudicate(c, reseed, fin_n);
+}
+int cz_selfplay_flush(cz_ctx *c, const int32_t *fin_n, const long long *offset, uint8_t *ring, long long ring_records, const long long *read_cursor) {
+    CZ_REQUIRE(c && c->sp_block && c->G > 0, "cz_selfplay_flush: call cz_selfplay_begin first");
+    CZ_REQUIRE(fin_n && offset && ring && ring_records > 0, "cz_selfplay_flush: null argument / empty ring");
+    return czk_selfplay_flush(c, fin_n, offset, ring, ring_records, read_cursor);
+}
+int cz_selfplay_stats(cz_ctx *c, long long *stats_dev) {
+    CZ_REQUIRE(c && c->sp_block && stats_dev, "cz_selfplay_stats: call cz_selfplay_begin first / null argument");
+    CZ_HIP(hipMemcpyAsync(stats_dev, c->sp.stats, sizeof(long long) * CZ_SP_NSTATS, hipMemcpyDeviceToDevice, c->stream));
+    return CZ_OK;
+}
+
 int cz_search_tree_dump(cz_ctx *c, int g, int32_t *out, int max_records) {
     CZ_REQUIRE(c && c->G > 0 && g >= 0 && g < c->G, "cz_search_tree_dump: bad tree index");
     CZ_HIP(hipStreamSynchronize(c->stream));
-    int32_t cur = 0, root = 0, n = 0;
-    CZ_HIP(hipMemcpy(&cur, c->t.cur + g, 4, hipMemcpyDeviceToHost));
+    int32_t root = 0, n = 0;
     CZ_HIP(hipMemcpy(&root, c->t.root_node + g, 4, hipMemcpyDeviceToHost));
     CZ_HIP(hipMemcpy(&n, c->t.n_nodes + g, 4, hipMemcpyDeviceToHost));
-    const CzPool &p = c->t.pool[cur];
+    const CzPool &p = c->t.pool;
     const size_t base = (size_t)g * (size_t)c->cap;
     std::vector<float> P(n), W(n), Q(n);
     std::vector<int32_t> N(n), cb(n);

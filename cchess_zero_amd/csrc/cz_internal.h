@@ -36,18 +36,37 @@ const CzHostTables &cz_host_tables();
 // ---- tree storage: structure-of-arrays, one fixed-capacity pool per tree -----------------------
 // A node is the edge into it plus its expansion record (the reference's leaf_node, main.py:93-103,
 // minus the eagerly materialised state string, quirk Q8).  Children of a node are contiguous, so a
-// wave scores up to 128 siblings with three coalesced loads (Q, P, N).
+// wave scores up to 128 siblings with three coalesced loads (Q, P, N).  Nodes are allocated in expansion
+// order, so every child has a larger index than its parent — cz_search_advance relies on that to compact
+// the kept subtree IN PLACE (one pool per tree, no spare pool).
 struct CzPool {
     float *P, *W, *Q;
     int32_t *N, *parent, *child_begin;
     uint16_t *child_count, *move;
 };
 
+// cz_selfplay_*: per game slot, the (s, pi, z) records of the game in progress (cchess_main.selfplay keeps
+// states / mcts_probs / current_players lists, main.py:1496-1518) and the counters of finished games
+struct CzSelfplay {
+    int max_plies;               // history capacity per game; a game reaching it is adjudicated a draw
+    uint8_t *hist;               // [max_games][max_plies][CZ_REC_BYTES]
+    int32_t *ply;                // [max_games] plies recorded for the game in progress
+    uint8_t *stalled;            // [max_games] the last choose found no root child (node pool exhausted at the root)
+    uint8_t *active;             // [max_games] 0 = parked (finished, not re-seeded)
+    int8_t *fin_winner;          // [max_games] scratch between adjudicate and flush
+    uint8_t *start_board;        // [max_games][96] position every new game of the slot starts from
+    uint8_t *start_side;         // [max_games]
+    int32_t *start_rr;           // [max_games]
+    long long *stats;            // [CZ_SP_NSTATS]
+};
+
 struct CzTrees {
-    CzPool pool[2];      // [max_games * cap] each; pool[cur] is live, the other is the compaction target
+    CzPool pool;         // [max_games * cap]
     int cap;
+    int words;           // ceil(cap / 64): 64-node words of the advance bitmap
+    unsigned long long *mark_bits;   // [max_games][words] k_advance: which nodes of the tree are kept
+    uint32_t *mark_rank;             // [max_games][words] kept nodes before the word = new index of its first kept node
     // per tree [max_games]
-    int32_t *cur;        // which pool holds tree g
     uint8_t *root_board; // [max_games][96]
     uint8_t *root_side;
     int32_t *root_rr, *root_node, *n_nodes, *status, *sims, *last_depth;
@@ -70,13 +89,38 @@ struct cz_ctx {
     void *tab_block;   // single allocation behind `tab`
     CzTrees t;
     void *tree_block;  // single allocation behind the per-tree arrays
-    void *pool_block[2];
+    void *pool_block;
     bool conv_attr_set, tower_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1
     int step_parity;   // which evcnt entry the current compact step uses
     const int32_t *batch_count;  // cz_set_batch_count: device row count bounding the net launches, or NULL
+    CzSelfplay sp;     // cz_selfplay_begin
+    void *sp_block;
 };
+
+// ---- device helpers shared by cz_search.hip / cz_selfplay.hip -----------------------------------
+struct TreeView {
+    float *P, *W, *Q;
+    int32_t *N, *parent, *child_begin;
+    uint16_t *child_count, *move;
+};
+
+__device__ __forceinline__ TreeView view_of(const CzTrees &t, int g) {
+    const CzPool &p = t.pool;
+    const size_t base = (size_t)g * (size_t)t.cap;
+    TreeView v;
+    v.P = p.P + base; v.W = p.W + base; v.Q = p.Q + base;
+    v.N = p.N + base; v.parent = p.parent + base; v.child_begin = p.child_begin + base;
+    v.child_count = p.child_count + base; v.move = p.move + base;
+    return v;
+}
+
+__device__ __forceinline__ void init_root(TreeView v, int idx) {
+    v.P[idx] = 1.0f;  // p_ = 0.75 + 0.25 * dirichlet([0.3]) == 1 (quirk Q4), main.py:238
+    v.W[idx] = 0.f; v.Q[idx] = 0.f; v.N[idx] = 0; v.parent[idx] = -1; v.child_begin[idx] = -1;
+    v.child_count[idx] = 0; v.move[idx] = 0xFFFF;
+}
 
 // kernels' launch wrappers (cz_rules.hip / cz_search.hip)
 int czk_movegen(cz_ctx *, const uint8_t *, const uint8_t *, int, uint16_t *, uint16_t *, uint32_t *);
@@ -91,3 +135,7 @@ int czk_search_root_stats(cz_ctx *, uint16_t *, int32_t *, float *, float *, flo
 int czk_search_advance(cz_ctx *, const uint16_t *);
 int czk_search_select_k(cz_ctx *, int, int, const uint8_t *, void *, int, int, uint8_t *);
 int czk_search_expand_backup_k(cz_ctx *, int, const void *, const void *, int);
+int czk_selfplay_seed(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *);
+int czk_selfplay_choose(cz_ctx *, const float *, const float *, const uint16_t *, double, float, uint16_t *);
+int czk_selfplay_adjudicate(cz_ctx *, int, int32_t *);
+int czk_selfplay_flush(cz_ctx *, const int32_t *, const long long *, uint8_t *, long long, const long long *);

@@ -16,28 +16,6 @@
 
 namespace {
 
-struct TreeView {
-    float *P, *W, *Q;
-    int32_t *N, *parent, *child_begin;
-    uint16_t *child_count, *move;
-};
-
-__device__ __forceinline__ TreeView view_of(const CzTrees &t, int g, int which) {
-    const CzPool &p = t.pool[which];
-    const size_t base = (size_t)g * (size_t)t.cap;
-    TreeView v;
-    v.P = p.P + base; v.W = p.W + base; v.Q = p.Q + base;
-    v.N = p.N + base; v.parent = p.parent + base; v.child_begin = p.child_begin + base;
-    v.child_count = p.child_count + base; v.move = p.move + base;
-    return v;
-}
-
-__device__ __forceinline__ void init_root(TreeView v, int idx) {
-    v.P[idx] = 1.0f;  // p_ = 0.75 + 0.25 * dirichlet([0.3]) == 1 (quirk Q4), main.py:238
-    v.W[idx] = 0.f; v.Q[idx] = 0.f; v.N[idx] = 0; v.parent[idx] = -1; v.child_begin[idx] = -1;
-    v.child_count[idx] = 0; v.move[idx] = 0xFFFF;
-}
-
 // ---- reset: MCTS_tree.__init__ / reload, main.py:235-259 ---------------------------------------
 __global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restrict__ boards,
                                               const uint8_t *__restrict__ side, const int32_t *__restrict__ rr, int G) {
@@ -46,12 +24,11 @@ __global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restri
     for (int i = lane; i < CZD_BOARD_LDS; i += 64)
         t.root_board[(size_t)g * CZD_BOARD_LDS + i] = i < CZ_NSQ ? boards[(size_t)g * CZ_NSQ + i] : 0;
     if (lane == 0) {
-        t.cur[g] = 0;
         t.root_side[g] = side[g] ? 1 : 0;
         t.root_rr[g] = rr ? rr[g] : 0;
         t.root_node[g] = 0; t.n_nodes[g] = 1; t.status[g] = 0; t.sims[g] = 0; t.last_depth[g] = 0;
         t.pend_kind[g] = 0; t.pend_leaf[g] = 0; t.pend_value[g] = 0.f; t.pend_side[g] = 0; t.pend_nmoves[g] = 0;
-        init_root(view_of(t, g, 0), 0);
+        init_root(view_of(t, g), 0);
     }
 }
 
@@ -85,7 +62,7 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
         for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64)
             ((uint32_t *)b)[i] = ((const uint32_t *)(t.root_board + (size_t)g * CZD_BOARD_LDS))[i];
         __syncthreads();
-        const TreeView v = view_of(t, g, t.cur[g]);
+        const TreeView v = view_of(t, g);
         const int root = t.root_node[g];
         int rr = t.root_rr[g];
         int node = root;
@@ -231,7 +208,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
     }
     const int kind = t.pend_kind[g];
     if (kind == 0) return;
-    const TreeView v = view_of(t, g, t.cur[g]);
+    const TreeView v = view_of(t, g);
     const int leaf = t.pend_leaf[g];
     float val;
     if (kind == 1 || kind == 3) {
@@ -378,7 +355,7 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     const bool parked = (active && !active[g]) || (t.status[g] & ~CZ_ST_BAD_ADVANCE) != 0;
-    const TreeView v = view_of(t, g, t.cur[g]);
+    const TreeView v = view_of(t, g);
     const int root = t.root_node[g];
     bool stop = parked;
     int done_now = 0;   // simulations completed inside this launch (terminal / draw)
@@ -523,7 +500,7 @@ __global__ __launch_bounds__(64) void k_expand_backup_k(CzTrees t, CzTables tab,
     __shared__ float tot_s;
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
-    const TreeView v = view_of(t, g, t.cur[g]);
+    const TreeView v = view_of(t, g);
     const int root = t.root_node[g];
     for (int j = 0; j < K; ++j) {
         const size_t slot = (size_t)g * K + j;
@@ -593,7 +570,7 @@ __global__ __launch_bounds__(64) void k_root_stats(CzTrees t, int G, uint16_t *_
                                                    uint16_t *__restrict__ count) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
-    const TreeView v = view_of(t, g, t.cur[g]);
+    const TreeView v = view_of(t, g);
     const int root = t.root_node[g];
     const int cb = v.child_begin[root];
     const int n = cb < 0 ? 0 : v.child_count[root];
@@ -609,80 +586,137 @@ __global__ __launch_bounds__(64) void k_root_stats(CzTrees t, int G, uint16_t *_
     }
 }
 
-// ---- K7: update_tree (main.py:272-276) with subtree compaction ------------------------------------
-// The played child's subtree is copied breadth-first into the spare pool (sibling groups stay
-// contiguous and keep their order, so selection is unchanged), then the pools swap roles for this
-// tree.  Board / side / restrict_round follow selfplay's bookkeeping, main.py:1522-1528.
-__global__ __launch_bounds__(64) void k_advance(CzTrees t, CzTables tab, int G, const uint16_t *__restrict__ played) {
-    const int g = blockIdx.x, lane = threadIdx.x;
+// ---- K7: update_tree (main.py:272-276) with in-place subtree compaction -------------------------------
+// The played child's subtree is the only part of the tree update_tree keeps (the reference drops the rest with
+// `self.root.parent = None`).  Nodes are allocated in expansion order, so a child always has a larger index than its
+// parent and a sibling group is contiguous: a STABLE compaction (kept nodes keep their relative order) therefore
+// (a) keeps every sibling group contiguous and in generation order — selection is unchanged —, (b) moves every node
+// to an index <= its old one, so it can be done in place, ascending, with no spare pool (round 1 kept a second pool
+// of the same size as the compaction target: 2 x 59 GB at 8192 trees x 256 320 nodes).
+//   pass 1  kept[i] = (i == played child) || kept[parent[i]], ascending in chunks of 256 nodes; a parent inside the
+//           same chunk is resolved by iterating over the chunk (parent < child bounds the iterations by the chunk's
+//           chain depth); one 64-bit word of the bitmap per wave and chunk (ballot)
+//   rank    exclusive prefix count of the bitmap words: new index of node i = rank[i / 64] + popc(bits below i)
+//   pass 2  ascending: a chunk is read into registers, barrier, written to the new indices with parent /
+//           child_begin remapped through the rank
+// Board / side / restrict_round follow selfplay's bookkeeping, main.py:1522-1528.  The tree's POOL_EXHAUSTED status
+// is cleared: the compaction has made room again (a tree that stays full is flagged again by the next expansion).
+__device__ __forceinline__ bool mark_tst(const unsigned long long *bits, int i) { return (bits[i >> 6] >> (i & 63)) & 1ull; }
+__device__ __forceinline__ int mark_rank_of(const unsigned long long *bits, const uint32_t *rank, int i) {
+    const unsigned long long below = (i & 63) ? (bits[i >> 6] & ((1ull << (i & 63)) - 1ull)) : 0ull;
+    return (int)rank[i >> 6] + __popcll(below);
+}
+
+__global__ __launch_bounds__(256) void k_advance(CzTrees t, CzTables tab, int G, const uint16_t *__restrict__ played) {
+    __shared__ int s_found, s_total;
+    __shared__ int s_flag[256];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (g >= G) return;
     const uint16_t l = played[g];
     if (l >= CZ_NLABELS) return;
-    const int cur = t.cur[g];
-    const TreeView s = view_of(t, g, cur), d = view_of(t, g, cur ^ 1);
+    const TreeView v = view_of(t, g);
+    unsigned long long *bits = t.mark_bits + (size_t)g * t.words;
+    uint32_t *rank = t.mark_rank + (size_t)g * t.words;
     const int root = t.root_node[g];
-    // find the played child (first match, children are unique)
-    const int cb = s.child_begin[root];
-    const int cc = cb < 0 ? 0 : s.child_count[root];
-    int found = -1;
-    for (int r = 0; r < 2; ++r) {
-        const int i = lane + 64 * r;
-        const bool hit = i < cc && s.move[cb + i] == l;
-        const unsigned long long m = __ballot(hit);
-        if (found < 0 && m) found = cb + 64 * r + (__ffsll((long long)m) - 1);
-    }
+    const int n = t.n_nodes[g];
+    // find the played child (children are unique; at most 128 of them)
+    const int cb = v.child_begin[root];
+    const int cc = cb < 0 ? 0 : v.child_count[root];
+    if (tid == 0) s_found = -1;
+    __syncthreads();
+    if (tid < cc && v.move[cb + tid] == l) s_found = cb + tid;
     // board bookkeeping
     uint8_t *rb = t.root_board + (size_t)g * CZD_BOARD_LDS;
-    const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
-    const int cap = rb[dst];
-    __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
+        const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+        const int cap = rb[dst];
         rb[dst] = rb[src]; rb[src] = 0;
         t.root_side[g] ^= 1;
         t.root_rr[g] = cap ? 0 : t.root_rr[g] + 1;
         t.sims[g] = 0;
-        t.pend_kind[g] = 0;
     }
+    __syncthreads();
+    const int found = s_found;
     if (found < 0) {
-        if (lane == 0) {
-            t.status[g] |= CZ_ST_BAD_ADVANCE;
-            init_root(d, 0);
-            t.root_node[g] = 0; t.n_nodes[g] = 1; t.cur[g] = cur ^ 1;
+        if (tid == 0) {
+            t.status[g] = (t.status[g] & ~CZ_ST_POOL_EXHAUSTED) | CZ_ST_BAD_ADVANCE;
+            init_root(v, 0);
+            t.root_node[g] = 0; t.n_nodes[g] = 1;
         }
         return;
     }
-    if (lane == 0) {
-        d.P[0] = s.P[found]; d.W[0] = s.W[found]; d.Q[0] = s.Q[found]; d.N[0] = s.N[found];
-        d.parent[0] = -1; d.move[0] = s.move[found];
-        d.child_begin[0] = s.child_begin[found];  // still a SOURCE index until node 0 is processed
-        d.child_count[0] = s.child_count[found];
-    }
+    // ---- pass 1: the kept-node bitmap.  Nothing below `found` can be in its subtree.
+    const int w0 = found >> 6, W = (n + 63) >> 6;
+    for (int w = tid; w < w0; w += 256) bits[w] = 0ull;
     __syncthreads();
-    __threadfence_block();
-    // breadth-first copy, 64 destination nodes per sweep; only expanded ones own a sibling group
-    int n = 1, i0 = 0;
-    while (i0 < n) {
-        const int lim = (n - i0) < 64 ? (n - i0) : 64;
-        const int mycb = lane < lim ? d.child_begin[i0 + lane] : -1;  // SOURCE-pool index of the group
-        const int mycc = lane < lim ? (int)d.child_count[i0 + lane] : 0;
-        unsigned long long m = __ballot(mycb >= 0);
-        while (m) {
-            const int k = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int scb = __shfl(mycb, k, 64), scc = __shfl(mycc, k, 64);
-            for (int j = lane; j < scc; j += 64) {
-                const int a = scb + j, o = n + j;  // o >= i0 + lim: never inside the sweep window
-                d.P[o] = s.P[a]; d.W[o] = s.W[a]; d.Q[o] = s.Q[a]; d.N[o] = s.N[a];
-                d.parent[o] = i0 + k; d.move[o] = s.move[a];
-                d.child_begin[o] = s.child_begin[a]; d.child_count[o] = s.child_count[a];
-            }
-            if (lane == 0) d.child_begin[i0 + k] = n;
-            n += scc;
+    for (int base = w0 << 6; base < n; base += 256) {
+        const int i = base + tid;
+        int st, p = -1;   // st: 0 unknown, 1 kept, 2 dropped
+        if (i >= n || i < found) st = 2;
+        else if (i == found) st = 1;
+        else {
+            p = v.parent[i];
+            if (p < found) st = 2;
+            else if (p == found) st = 1;
+            else if (p < base) st = mark_tst(bits, p) ? 1 : 2;
+            else st = 0;
+        }
+        s_flag[tid] = st;
+        __syncthreads();
+        for (;;) {
+            int open = 0;
+            if (st == 0) { const int ps = s_flag[p - base]; if (ps) st = ps; else open = 1; }
+            open = __syncthreads_or(open);
+            s_flag[tid] = st;
+            __syncthreads();
+            if (!open) break;
+        }
+        const unsigned long long m = __ballot(st == 1);
+        if (lane == 0 && (base >> 6) + wave < W) bits[(base >> 6) + wave] = m;
+        __syncthreads();
+    }
+    // ---- rank: exclusive prefix count over the bitmap words (W <= cap / 64)
+    {
+        const int per = (W + 255) / 256;
+        const int lo = tid * per, hi = min(W, lo + per);
+        int c = 0;
+        for (int w = lo; w < hi; ++w) c += __popcll(bits[w]);
+        s_flag[tid] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int k = 0; k < 256; ++k) { const int x = s_flag[k]; s_flag[k] = acc; acc += x; }
+            s_total = acc;
         }
         __syncthreads();
-        i0 += lim;
+        int acc = s_flag[tid];
+        for (int w = lo; w < hi; ++w) { rank[w] = (uint32_t)acc; acc += __popcll(bits[w]); }
+        __syncthreads();
     }
-    if (lane == 0) { t.root_node[g] = 0; t.n_nodes[g] = n; t.cur[g] = cur ^ 1; }
+    // ---- pass 2: move the kept nodes down, ascending (new index <= old index)
+    for (int base = w0 << 6; base < n; base += 256) {
+        const int i = base + tid;
+        const bool keep = i < n && mark_tst(bits, i);
+        float nP = 0.f, nW = 0.f, nQ = 0.f;
+        int nN = 0, np = -1, ncb = -1;
+        uint16_t ncc = 0, nmv = 0;
+        if (keep) {
+            nP = v.P[i]; nW = v.W[i]; nQ = v.Q[i]; nN = v.N[i]; np = v.parent[i]; ncb = v.child_begin[i];
+            ncc = v.child_count[i]; nmv = v.move[i];
+        }
+        __syncthreads();   // the whole chunk is in registers before any of its slots is overwritten
+        if (keep) {
+            const int o = mark_rank_of(bits, rank, i);
+            v.P[o] = nP; v.W[o] = nW; v.Q[o] = nQ; v.N[o] = nN;
+            v.parent[o] = i == found ? -1 : mark_rank_of(bits, rank, np);
+            v.child_begin[o] = ncb >= 0 ? mark_rank_of(bits, rank, ncb) : -1;
+            v.child_count[o] = ncc; v.move[o] = nmv;
+        }
+    }
+    if (tid == 0) {
+        t.root_node[g] = 0; t.n_nodes[g] = s_total;
+        t.status[g] &= ~CZ_ST_POOL_EXHAUSTED;
+    }
 }
 
 __global__ void k_root_state(CzTrees t, int G, uint8_t *__restrict__ boards, uint8_t *__restrict__ side, int32_t *__restrict__ rr) {
@@ -737,7 +771,7 @@ int czk_search_root_stats(cz_ctx *c, uint16_t *label, int32_t *N, float *Q, floa
 }
 
 int czk_search_advance(cz_ctx *c, const uint16_t *played) {
-    hipLaunchKernelGGL(k_advance, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, played);
+    hipLaunchKernelGGL(k_advance, dim3(c->G), dim3(256), 0, c->stream, c->t, c->tab, c->G, played);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

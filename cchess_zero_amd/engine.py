@@ -14,7 +14,16 @@ from ._lib import BF16, F16, F32, MAXMOVES, NLABELS, NSQ, check, lib
 
 
 def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None or isinstance(t, C.c_void_p):   # a raw device pointer (e.g. cz_selfplay_active) passes through
+        return t
+    return C.c_void_p(t.data_ptr())
+
+
+def _mask(active, dev):
+    """active mask argument -> something _ptr accepts: None, a raw device pointer, or a uint8 device tensor."""
+    if active is None or isinstance(active, C.c_void_p):
+        return active
+    return torch.as_tensor(active).to(dev).to(torch.uint8).contiguous()
 
 
 class Context:
@@ -93,9 +102,7 @@ class SearchEngine:
         self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         k = self.width if k is None else int(k)
         self._k = k
-        act = None
-        if active is not None:
-            act = torch.as_tensor(active).to(self.dev).to(torch.uint8).contiguous()
+        act = _mask(active, self.dev)
         if self.width > 1:
             check(lib().cz_search_select_k(self.ctx.h, int(mode), k, _ptr(act), _ptr(self.planes), self._pd, self.channels,
                                            _ptr(self.need)), "cz_search_select_k")
@@ -143,9 +150,7 @@ class SearchEngine:
         self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         import ctypes as C
         assert self.width == 1
-        act = None
-        if active is not None:
-            act = torch.as_tensor(active).to(self.dev).to(torch.uint8).contiguous()
+        act = _mask(active, self.dev)
         slot_p, n_p = C.c_void_p(), C.c_void_p()
         check(lib().cz_search_select_compact(self.ctx.h, int(mode), _ptr(act), _ptr(self.planes), self._pd, self.channels,
                                              C.byref(slot_p), C.byref(n_p)), "cz_search_select_compact")

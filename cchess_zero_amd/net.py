@@ -102,13 +102,13 @@ class PolicyValueModule(nn.Module):
     def export_tf_layout(self):
         d = {}
         for i, cb in enumerate(self.convbns()):
-            d["conv%d/kernel" % i] = cb.conv.weight.detach().float().permute(2, 3, 1, 0).contiguous().cpu().numpy()  # HWIO
-            d["conv%d/bias" % i] = cb.conv.bias.detach().float().cpu().numpy()
-            d["bn%d/moving_mean" % i] = cb.moving_mean.float().cpu().numpy()
-            d["bn%d/moving_variance" % i] = cb.moving_var.float().cpu().numpy()
+            d["conv%d/kernel" % i] = cb.conv.weight.detach().float().permute(2, 3, 1, 0).contiguous().cpu().numpy().copy()  # HWIO
+            d["conv%d/bias" % i] = cb.conv.bias.detach().float().cpu().numpy().copy()   # copies: never alias live parameters
+            d["bn%d/moving_mean" % i] = cb.moving_mean.float().cpu().numpy().copy()
+            d["bn%d/moving_variance" % i] = cb.moving_var.float().cpu().numpy().copy()
         for name, fc in (("policy_fc", self.policy_fc), ("value_fc1", self.value_fc1), ("value_fc2", self.value_fc2)):
-            d[name + "/weights"] = fc.weight.detach().float().t().contiguous().cpu().numpy()  # [in,out]
-            d[name + "/biases"] = fc.bias.detach().float().cpu().numpy()
+            d[name + "/weights"] = fc.weight.detach().float().t().contiguous().cpu().numpy().copy()  # [in,out]
+            d[name + "/biases"] = fc.bias.detach().float().cpu().numpy().copy()
         return d
 
     def load_tf_layout(self, d):
@@ -121,6 +121,70 @@ class PolicyValueModule(nn.Module):
             for name, fc in (("policy_fc", self.policy_fc), ("value_fc1", self.value_fc1), ("value_fc2", self.value_fc2)):
                 fc.weight.copy_(torch.from_numpy(np.asarray(d[name + "/weights"])).t())
                 fc.bias.copy_(torch.from_numpy(np.asarray(d[name + "/biases"])))
+
+
+def tf_variable_names(res_block_nums):
+    """Names of the reference graph's variables in a TF1 checkpoint -> keys of export_tf_layout()/load_tf_layout().
+
+    The reference builds its graph without variable scopes (tf.name_scope does not rename variables), so TF1 numbers the
+    layers in creation order (policy_value_network.py:45-74,151-162): `conv2d`, `conv2d_1`, ... — input conv, two per
+    residual block, policy head conv, value head conv —, `BatchNorm`, `BatchNorm_1`, ... in the same order (no beta:
+    center=False, no gamma: scale defaults to False), `fully_connected` (policy FC), `fully_connected_1`,
+    `fully_connected_2` (value FCs).  Optimizer slots (`<var>/Momentum`) and `global_step` are not weights."""
+    n_conv = 1 + 2 * res_block_nums + 2
+    names = {}
+    for i in range(n_conv):
+        sfx = "" if i == 0 else "_%d" % i
+        names["conv2d%s/kernel" % sfx] = "conv%d/kernel" % i
+        names["conv2d%s/bias" % sfx] = "conv%d/bias" % i
+        names["BatchNorm%s/moving_mean" % sfx] = "bn%d/moving_mean" % i
+        names["BatchNorm%s/moving_variance" % sfx] = "bn%d/moving_variance" % i
+    for j, ours in enumerate(("policy_fc", "value_fc1", "value_fc2")):
+        sfx = "" if j == 0 else "_%d" % j
+        names["fully_connected%s/weights" % sfx] = ours + "/weights"
+        names["fully_connected%s/biases" % sfx] = ours + "/biases"
+    return names
+
+
+def from_tf_variables(variables, res_block_nums=None):
+    """dict / NpzFile keyed by TF1 variable names (optionally with a ':0' suffix, Momentum slots and global_step
+    present) -> (dict for load_tf_layout, res_block_nums, global_step or None).  The block count is inferred from the
+    number of conv2d kernels when not given.  Shapes are checked against the reference graph."""
+    v = {}
+    for k in (variables.files if hasattr(variables, "files") else variables.keys()):
+        name = k[:-2] if k.endswith(":0") else k
+        v[name] = np.asarray(variables[k])
+    n_conv = sum(1 for k in v if k.startswith("conv2d") and k.endswith("/kernel"))
+    blocks = (n_conv - 3) // 2
+    if n_conv < 3 or 1 + 2 * blocks + 2 != n_conv:
+        raise ValueError("not a cchess-zero checkpoint: %d conv2d kernels" % n_conv)
+    if res_block_nums is not None and res_block_nums != blocks:
+        raise ValueError("checkpoint has %d residual blocks, expected %d" % (blocks, res_block_nums))
+    out = {}
+    for tf_name, ours in tf_variable_names(blocks).items():
+        if tf_name not in v:
+            raise KeyError("variable %s missing from the checkpoint" % tf_name)
+        out[ours] = v[tf_name]
+    want = {"conv0/kernel": (3, 3, 14, FILTERS), "conv%d/kernel" % (n_conv - 2): (1, 1, FILTERS, 2),
+            "conv%d/kernel" % (n_conv - 1): (1, 1, FILTERS, 1), "policy_fc/weights": (180, PROB_SIZE),
+            "value_fc1/weights": (90, 256), "value_fc2/weights": (256, 1)}
+    for i in range(1, n_conv - 2):
+        want["conv%d/kernel" % i] = (3, 3, FILTERS, FILTERS)
+    for k, shp in want.items():
+        if tuple(out[k].shape) != shp:
+            raise ValueError("%s has shape %s, the reference graph has %s" % (k, tuple(out[k].shape), shp))
+    gs = int(np.asarray(v["global_step"]).reshape(-1)[0]) if "global_step" in v else None
+    return out, blocks, gs
+
+
+def to_tf_variables(module, global_step=None):
+    """The inverse: a dict keyed by the reference graph's TF1 variable names (np.savez(**d) gives a file that a
+    three-line TF script can assign back into the reference's graph)."""
+    d = module.export_tf_layout()
+    out = {tf_name: d[ours] for tf_name, ours in tf_variable_names(module.res_block_nums).items()}
+    if global_step is not None:
+        out["global_step"] = np.asarray(int(global_step), np.int64)
+    return out
 
 
 class PolicyValueNet:

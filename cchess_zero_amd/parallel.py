@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .selfplay import REC_BYTES
+from ._lib import REC_BYTES
 
 
 def shard_games(n_games, rank, world):
@@ -20,29 +20,49 @@ def shard_games(n_games, rank, world):
     return np.arange(rank, n_games, world)
 
 
-def gather_records(rec, device=None, group=None):
-    """All-gather packed records [n_r, REC_BYTES] from every rank -> [sum n_r, REC_BYTES] (same on all ranks,
-    ordered by rank).  Two collectives: the per-rank counts (tiny), then one padded uint8 all_gather."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return np.ascontiguousarray(rec, np.uint8).reshape(-1, REC_BYTES)
+def gather_records_device(rec, group=None):
+    """All-gather packed records from every rank WITHOUT leaving the device: rec is a uint8 [n_r, REC_BYTES] tensor on
+    the collective's device (the GPU for RCCL, the CPU for gloo); returns (all [world, m, REC_BYTES] padded to the longest
+    shard m, counts int64 [world]) on that device.  Two collectives: the per-rank counts (8 bytes each), then one padded
+    uint8 all_gather_into_tensor — on the 8-GPU xGMI mesh one hop per peer.  Only the count exchange synchronises with
+    the host (the padded size has to be known to allocate)."""
     world = dist.get_world_size(group)
+    rec = rec.reshape(-1, REC_BYTES)
+    dev = rec.device
+    n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    m = int(counts.max().item())
+    out = torch.empty((world, m, REC_BYTES), dtype=torch.uint8, device=dev)
+    if m == 0:
+        return out, counts
+    if rec.shape[0] == m:
+        pad = rec.contiguous()
+    else:
+        pad = torch.zeros((m, REC_BYTES), dtype=torch.uint8, device=dev)
+        pad[:rec.shape[0]] = rec
+    dist.all_gather_into_tensor(out.view(world * m, REC_BYTES), pad, group=group)
+    return out, counts
+
+
+def gather_records(rec, device=None, group=None):
+    """All-gather packed records [n_r, REC_BYTES] from every rank -> host array [sum n_r, REC_BYTES] (same on all ranks,
+    ordered by rank): the multi-GPU `data_buffer.extend` (main.py:1240).  rec: a device tensor (stays on the device until
+    the gathered result is copied out once) or a host array."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if torch.is_tensor(rec):
+            rec = rec.cpu().numpy()
+        return np.ascontiguousarray(rec, np.uint8).reshape(-1, REC_BYTES)
     backend = dist.get_backend(group)
     dev = torch.device(device) if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
-    rec = np.ascontiguousarray(rec, np.uint8).reshape(-1, REC_BYTES)
-    n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    m = max(counts)
-    if m == 0:
-        return np.zeros((0, REC_BYTES), np.uint8)
-    pad = torch.zeros((m, REC_BYTES), dtype=torch.uint8, device=dev)
-    if rec.shape[0]:
-        pad[:rec.shape[0]] = torch.from_numpy(rec).to(dev)
-    out = torch.empty((world, m, REC_BYTES), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out.view(world * m, REC_BYTES), pad, group=group)
+    if not torch.is_tensor(rec):
+        rec = torch.from_numpy(np.ascontiguousarray(rec, np.uint8).reshape(-1, REC_BYTES))
+    out, counts = gather_records_device(rec.to(dev), group)
+    counts = counts.cpu().numpy()
     out = out.cpu().numpy()
-    return np.concatenate([out[r, :counts[r]] for r in range(world)], axis=0)
+    if out.shape[1] == 0:
+        return np.zeros((0, REC_BYTES), np.uint8)
+    return np.concatenate([out[r, :counts[r]] for r in range(len(counts))], axis=0)
 
 
 def broadcast_weights(module, src=0, group=None):

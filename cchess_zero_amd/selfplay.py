@@ -1,4 +1,4 @@
-"""Batched self-play on top of the lock-step search engine (host side of K7 / rows a17-a18 of SURVEY §8).
+"""Batched, device-resident self-play on top of the lock-step search engine (rows a17-a18 of SURVEY §8).
 
 Mirrors, for G games at once, cchess_main.get_action (main.py:1332-1358) and cchess_main.selfplay
 (main.py:1493-1554) of the reference:
@@ -8,53 +8,69 @@ Mirrors, for G games at once, cchess_main.get_action (main.py:1332-1358) and cch
     rank-flipped for black, main.py:1507-1512 — and the mover),
   * a game ends when a king is captured (z = +1 for the winner's plies, -1 for the loser's) or after
     60 plies without capture (z = 0), main.py:1532-1545.
-Games are independent: with several GPUs every rank plays its own shard of games and only the
-finished (s, pi, z) records are exchanged (parallel.py).
+All of it runs on the device (cz_selfplay_choose / cz_search_advance / cz_selfplay_adjudicate / cz_selfplay_flush,
+csrc/cz_selfplay.hip): there is no per-ply host synchronisation and no per-game Python loop; finished games hand their
+records to a device ring and — in continuous mode — their slot starts the next game at once, so the device stays full
+for as long as the loop runs.  The host only drains the ring (drain()).  With several GPUs every rank plays its own
+games and only the drained records are exchanged (parallel.py).
 
-Records are kept packed (45-byte nibble board + mover + <=128 (label, prob) pairs + z); `to_dense`
-expands them to the reference's training tuples (planes [9,10,14] f32, pi [2086] f32, z).
+Records are packed (include/cchess_hip.h CZ_REC_*: board, mover, <=128 (label, visit count) pairs, z); `to_dense`
+expands them to the reference's training tuples (planes [9,10,14] f32, pi [2086], z).  pi is recomputed from the
+visit counts with the reference's own float64 expression, so it is bit-identical to what get_action returns.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
-from ._lib import MAXMOVES, NLABELS, NSQ, tables
+from ._lib import (MAXMOVES, NLABELS, NSQ, REC_BYTES, REC_COUNT, REC_FLAGS, REC_LABELS, REC_PLY, REC_SIDE, REC_VISITS, REC_Z,
+                   SP_STATS, check, lib, tables)
 
 REC_MAXMOVES = MAXMOVES
-# one fixed-size record (uint8 view): board 90 B, side 1 B, count 1 B, z int8 1 B, pad 1 B, labels 128 x u16, probs 128 x f16
-REC_BYTES = 90 + 4 + 2 * REC_MAXMOVES + 2 * REC_MAXMOVES
 
 
-def pack_records(boards, side, labels, probs, counts, z):
-    """-> uint8 [n, REC_BYTES].  boards u8 [n,90]; labels u16 [n,128]; probs f32 [n,128]; counts; z in {-1,0,1}."""
+def pack_records(boards, side, labels, visits, counts, z, ply=None):
+    """-> uint8 [n, REC_BYTES].  boards u8 [n,90]; labels u16 [n,128]; visits [n,128] ints; counts; z in {-1,0,1}."""
     n = boards.shape[0]
     rec = np.zeros((n, REC_BYTES), np.uint8)
-    rec[:, :90] = boards
-    rec[:, 90] = side
-    rec[:, 91] = counts
-    rec[:, 92] = np.asarray(z, np.int8).view(np.uint8)
-    rec[:, 94:94 + 256] = np.ascontiguousarray(labels, np.uint16).view(np.uint8).reshape(n, 256)
-    rec[:, 94 + 256:] = np.ascontiguousarray(probs, np.float32).astype(np.float16).view(np.uint8).reshape(n, 256)
+    rec[:, :NSQ] = boards
+    rec[:, REC_SIDE] = side
+    rec[:, REC_COUNT] = counts
+    rec[:, REC_Z] = np.asarray(z, np.int8).view(np.uint8)
+    v = np.asarray(visits, np.int64)
+    rec[:, REC_FLAGS] = (v > 65535).any(axis=1)
+    if ply is not None:
+        rec[:, REC_PLY:REC_PLY + 2] = np.ascontiguousarray(ply, np.uint16).view(np.uint8).reshape(n, 2)
+    rec[:, REC_LABELS:REC_LABELS + 256] = np.ascontiguousarray(labels, np.uint16).view(np.uint8).reshape(n, 256)
+    rec[:, REC_VISITS:REC_VISITS + 256] = np.ascontiguousarray(np.minimum(v, 65535), np.uint16).view(np.uint8).reshape(n, 256)
     return rec
 
 
 def unpack_records(rec):
     rec = np.ascontiguousarray(rec, np.uint8).reshape(-1, REC_BYTES)
     n = rec.shape[0]
-    return dict(boards=rec[:, :90].copy(), side=rec[:, 90].copy(), counts=rec[:, 91].copy(),
-                z=rec[:, 92].copy().view(np.int8),
-                labels=rec[:, 94:94 + 256].copy().view(np.uint16).reshape(n, 128),
-                probs=rec[:, 94 + 256:].copy().view(np.float16).reshape(n, 128).astype(np.float32))
+    return dict(boards=rec[:, :NSQ].copy(), side=rec[:, REC_SIDE].copy(), counts=rec[:, REC_COUNT].copy(),
+                z=rec[:, REC_Z].copy().view(np.int8), flags=rec[:, REC_FLAGS].copy(),
+                ply=rec[:, REC_PLY:REC_PLY + 2].copy().view(np.uint16).reshape(n),
+                labels=rec[:, REC_LABELS:REC_LABELS + 256].copy().view(np.uint16).reshape(n, 128),
+                visits=rec[:, REC_VISITS:REC_VISITS + 256].copy().view(np.uint16).reshape(n, 128))
 
 
-def canonical_planes(boards, side):
-    """generate_inputs (main.py:531-557) on the host for record expansion: [n,9,10,14] f32 with quirk Q1."""
+def canonical_boards(boards, side):
+    """try_flip (main.py:560-574) on piece-code boards: for black reverse the rank order and swap the colours."""
     boards = np.asarray(boards, np.uint8).reshape(-1, NSQ)
     n = boards.shape[0]
     b = boards.reshape(n, 10, 9)
     flip = np.asarray(side).astype(bool)
     fb = b[:, ::-1, :]
     fb = np.where(fb == 0, 0, np.where(fb > 7, fb - 7, fb + 7)).astype(np.uint8)
-    canon = np.where(flip[:, None, None], fb, b).reshape(n, NSQ)
+    return np.where(flip[:, None, None], fb, b).reshape(n, NSQ)
+
+
+def canonical_planes(boards, side):
+    """generate_inputs (main.py:531-557) on the host for record expansion: [n,9,10,14] f32 with quirk Q1."""
+    canon = canonical_boards(boards, side)
+    n = canon.shape[0]
     planes = np.zeros((n, 9, 10, 14), np.float32)
     cells = (np.arange(9)[:, None] * 9 + np.arange(10)[None, :])  # the reference's 9-stride read (quirk Q1)
     code = canon[:, cells]  # [n,9,10]
@@ -63,130 +79,171 @@ def canonical_planes(boards, side):
     return planes
 
 
-def to_dense(rec):
-    """Packed records -> (planes [n,9,10,14] f32, pi [n,2086] f32, z [n] f32): the tuples
-    cchess_main.run extends data_buffer with (main.py:1234-1240)."""
+def visit_policy(visits, temperature=1.0):
+    """get_action's probs (main.py:1341, softmax :1111-1116) with the reference's own float64 expression:
+    softmax(1.0 / temperature * np.log(visits)); zero visits -> log 0 = -inf -> probability 0."""
+    with np.errstate(divide="ignore"):
+        x = 1.0 / temperature * np.log(np.asarray(visits, dtype=np.int64))
+    probs = np.exp(x - np.max(x))
+    probs /= np.sum(probs)
+    return probs
+
+
+def to_dense(rec, temperature=1.0, exact=True):
+    """Packed records -> (planes [n,9,10,14] f32, pi [n,2086] f64, z [n] f32): the tuples cchess_main.run extends
+    data_buffer with (main.py:1234-1240).  exact: pi through visit_policy record by record (bit-identical to the
+    reference); otherwise one vectorised pass (same values to the last ulp or two)."""
     u = unpack_records(rec)
     n = len(u["side"])
     unflip = tables()["unflip"].astype(np.int64)
-    pi = np.zeros((n, NLABELS), np.float32)
-    for i in range(n):
-        k = int(u["counts"][i])
-        lab = u["labels"][i, :k].astype(np.int64)
-        if u["side"][i]:
-            lab = unflip[lab]  # rank-flipped labels for black, main.py:1507-1512
-        pi[i, lab] = u["probs"][i, :k]
+    pi = np.zeros((n, NLABELS), np.float64)
+    if exact:
+        for i in range(n):
+            k = int(u["counts"][i])
+            if k == 0:
+                continue
+            lab = u["labels"][i, :k].astype(np.int64)
+            if u["side"][i]:
+                lab = unflip[lab]  # rank-flipped labels for black, main.py:1507-1512
+            pi[i, lab] = visit_policy(u["visits"][i, :k], temperature)
+    elif n:
+        k = u["counts"].astype(np.int64)
+        valid = np.arange(128)[None, :] < k[:, None]
+        with np.errstate(divide="ignore"):
+            x = np.where(valid, np.log(u["visits"].astype(np.float64)) / temperature, -np.inf)
+        e = np.exp(x - x.max(axis=1, keepdims=True))
+        p = e / e.sum(axis=1, keepdims=True)
+        lab = u["labels"].astype(np.int64)
+        lab = np.where(valid, lab, 0)
+        lab = np.where(u["side"][:, None].astype(bool), unflip[lab], lab)
+        rows = np.repeat(np.arange(n), 128).reshape(n, 128)
+        pi[rows[valid], lab[valid]] = p[valid]
     return canonical_planes(u["boards"], u["side"]), pi, u["z"].astype(np.float32)
 
 
 class SelfPlay:
-    """G concurrent self-play games on one GPU."""
+    """G concurrent self-play games on one GPU, device-resident.
 
-    def __init__(self, engine, net, playouts, exploration=True, temperature=1.0, seed=0, max_plies=512):
+    continuous=True : a finished game's slot starts a new game at once (the production loop: the batch never decays);
+    continuous=False: finished games are parked — play() returns when every game has ended (one game per slot).
+    """
+
+    def __init__(self, engine, net, playouts, exploration=True, temperature=1.0, seed=0, max_plies=512, ring_records=None,
+                 continuous=True):
         self.eng, self.net = engine, net
         self.playouts = int(playouts)
-        self.exploration = exploration
+        self.exploration = bool(exploration)
         self.temperature = float(temperature)
-        self.max_plies = max_plies
+        self.max_plies = int(max_plies)
+        self.continuous = bool(continuous)
         self.dev = engine.dev
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
-        self.sims = 0
+        self.ring_records = ring_records
+        self.plies = 0
+        if engine.width != 1:
+            raise ValueError("SelfPlay drives one simulation in flight per tree (thousands of trees fill the net batch)")
 
+    # -- setup -------------------------------------------------------------------------------------
     def start(self, boards, side, rr=None):
-        self.eng.reset(boards, side, rr)
-        self.eng.compact = True   # finished games park their trees: their rows drop out of the net's batch
-        G = self.eng.G
-        self.active = torch.ones(G, dtype=torch.bool, device=self.dev)
-        self.hist = [[] for _ in range(G)]   # per game: list of (board u8[90], side, labels u16[k], probs f32[k])
-        self.result = np.zeros(G, np.int8)   # +1 red ('w') won, -1 black won, 0 draw / unfinished
-        self.done = np.zeros(G, bool)
+        """Fresh trees on the given positions; every later game of a slot starts from the same position."""
+        eng = self.eng
+        eng.reset(boards, side, rr)
+        eng.compact = not self.continuous   # parked games drop out of the net's batch; a full batch needs no compaction
+        G = eng.G
+        check(lib().cz_selfplay_begin(eng.ctx.h, self.max_plies, None, None, None), "cz_selfplay_begin")
+        p = C.c_void_p()
+        check(lib().cz_selfplay_active(eng.ctx.h, C.byref(p)), "cz_selfplay_active")
+        self._active_ptr = p
+        R = int(self.ring_records or max(65536, 64 * G))
+        self.ring = torch.zeros((R, REC_BYTES), dtype=torch.uint8, device=self.dev)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)       # records ever handed to the ring
+        self.read_cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)  # records the host has drained
+        self._read = 0
+        self.sims_t = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.played = torch.empty(G, dtype=torch.int16, device=self.dev)
+        self.fin_n = torch.zeros(G, dtype=torch.int32, device=self.dev)
+        self._alpha = torch.full((G, MAXMOVES), 0.3, dtype=torch.float32, device=self.dev)
+        self._stats = torch.zeros(len(SP_STATS), dtype=torch.int64, device=self.dev)
         self.plies = 0
 
-    def policy_from_visits(self, st):
-        """softmax(log(N)/T) over the root children (main.py:1339-1341); padding -> 0."""
-        N = st["N"].to(torch.float64)
-        cnt = (st["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
-        valid = torch.arange(MAXMOVES, device=self.dev).unsqueeze(0) < cnt
-        logit = torch.where(valid & (N > 0), torch.log(N.clamp(min=1)) / self.temperature, torch.full_like(N, -float("inf")))
-        # all-zero visit rows (cannot happen after >=1 playout) fall back to uniform over the legal moves
-        none = ~torch.isfinite(logit).any(dim=1, keepdim=True)
-        logit = torch.where(none & valid, torch.zeros_like(logit), logit)
-        pi = torch.softmax(logit, dim=1)
-        return torch.where(valid, torch.nan_to_num(pi, nan=0.0), torch.zeros_like(pi)), valid
-
-    def step_ply(self, forward=None):
-        """One ply for every active game: search, sample, record, advance, adjudicate."""
-        eng = self.eng
+    # -- one ply of every game ------------------------------------------------------------------------
+    def step_ply(self, forward=None, forced=None):
+        """Search, choose, record, advance, adjudicate, flush — all enqueued, nothing synchronised.
+        forced: int16/uint16 [G] labels overriding the sampled moves (0xFFFF = sample), for replaying recorded games."""
+        eng, h = self.eng, self.eng.ctx.h
         fwd = forward or self.net.forward_device
-        act = self.active.to(torch.uint8)
-        eng.search(fwd, self.playouts, active=act)
-        self.sims += int(self.active.sum().item()) * self.playouts
-        st = eng.root_stats()
-        pi, valid = self.policy_from_visits(st)
-        p = pi
-        if self.exploration:  # 0.75*pi + 0.25*Dirichlet(0.3 * ones(k)), main.py:1346
-            g = torch._standard_gamma(torch.full(pi.shape, 0.3, dtype=torch.float64, device=self.dev), generator=self.gen)
-            g = torch.where(valid, g, torch.zeros_like(g))
-            d = g / g.sum(dim=1, keepdim=True).clamp(min=1e-300)
-            p = 0.75 * pi + 0.25 * d
-        p = torch.where(valid, torch.nan_to_num(p, nan=0.0, posinf=0.0, neginf=0.0), torch.zeros_like(p))
-        # rows without any child (finished / parked games) still need a well-formed distribution for the
-        # batched sampler; their draw is discarded below
-        dead = p.sum(dim=1, keepdim=True) <= 0
-        onehot0 = torch.zeros_like(p)
-        onehot0[:, 0] = 1.0
-        p = torch.where(dead, onehot0, p)
-        p = p / p.sum(dim=1, keepdim=True)
-        choice = torch.multinomial(p.clamp(min=0), 1, generator=self.gen).squeeze(1)
-        played = st["label"].gather(1, choice.unsqueeze(1)).squeeze(1)
-        played = torch.where(self.active & ~dead.squeeze(1), played, torch.full_like(played, -1))
-        # host-side record of (state, pi, mover) for the active games
-        rb, rs, _ = eng.root_state()
-        rb, rs = rb.cpu().numpy(), rs.cpu().numpy()
-        lab = st["label"].cpu().numpy().view(np.uint16)
-        cnt = st["count"].cpu().numpy().view(np.uint16)
-        pih = pi.float().cpu().numpy()
-        act_h = self.active.cpu().numpy()
-        for g_ in np.nonzero(act_h)[0]:
-            k = int(cnt[g_])
-            self.hist[g_].append((rb[g_].copy(), int(rs[g_]), lab[g_, :k].copy(), pih[g_, :k].copy()))
-        eng.advance(played)
+        eng.search(fwd, self.playouts, active=None if self.continuous else self._active_ptr)
+        self.sims_t += eng.status()[2].sum()            # completed simulations of this ply (device counter)
+        gamma = None
+        if self.exploration:   # np.random.dirichlet(0.3 * ones(k)) = normalised Gamma(0.3) variates, main.py:1346
+            gamma = torch._standard_gamma(self._alpha, generator=self.gen)
+        u = torch.rand(eng.G, generator=self.gen, device=self.dev, dtype=torch.float32)
+        f = None
+        if forced is not None:
+            f = torch.as_tensor(np.ascontiguousarray(forced).view(np.int16) if not torch.is_tensor(forced) else forced).to(self.dev).contiguous()
+        vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        eng.ctx.bind_stream()
+        check(lib().cz_selfplay_choose(h, vp(gamma), vp(u), vp(f), self.temperature, 0.25 if self.exploration else 0.0,
+                                       vp(self.played)), "cz_selfplay_choose")
+        eng.advance(self.played)
+        check(lib().cz_selfplay_adjudicate(h, 1 if self.continuous else 0, vp(self.fin_n)), "cz_selfplay_adjudicate")
+        csum = torch.cumsum(self.fin_n, 0, dtype=torch.int64)
+        offset = csum - self.fin_n + self.cursor
+        check(lib().cz_selfplay_flush(h, vp(self.fin_n), vp(offset), vp(self.ring), self.ring.shape[0], vp(self.read_cursor)),
+              "cz_selfplay_flush")
+        self.cursor += csum[-1:]
         self.plies += 1
-        # adjudication on the new root positions, main.py:1532-1545
-        nb, ns, nrr = eng.root_state()
-        nb_h, nrr_h = nb.cpu().numpy(), nrr.cpu().numpy()
-        K = (nb_h == 1).any(axis=1)
-        k = (nb_h == 8).any(axis=1)
-        for g_ in np.nonzero(act_h)[0]:
-            if not K[g_] or not k[g_]:
-                self.result[g_] = 1 if not k[g_] else -1
-                self.done[g_] = True
-            elif nrr_h[g_] >= 60 or len(self.hist[g_]) >= self.max_plies:
-                self.result[g_] = 0
-                self.done[g_] = True
-        self.active = torch.from_numpy(~self.done).to(self.dev)
-        return int(self.active.sum().item())
+
+    def run(self, plies, forward=None):
+        for _ in range(int(plies)):
+            self.step_ply(forward)
 
     def play(self, forward=None, max_plies=None):
+        """continuous=False: play until every game has ended (or max_plies plies); returns the drained records."""
         n = 0
-        while bool(self.active.any().item()) and (max_plies is None or n < max_plies):
+        out = []
+        while max_plies is None or n < max_plies:
             self.step_ply(forward)
             n += 1
-        return self.records()
+            if n % 8 == 0 or (max_plies is not None and n >= max_plies):
+                out.append(self.drain())
+                if not self.continuous and not bool(self.active().any().item()):
+                    break
+        out.append(self.drain())
+        return np.concatenate(out, axis=0) if out else np.zeros((0, REC_BYTES), np.uint8)
 
-    def records(self, only_finished=True):
-        """Packed (s, pi, z) records of all (finished) games."""
-        B, S, L, P, C, Z = [], [], [], [], [], []
-        for g_, h in enumerate(self.hist):
-            if only_finished and not self.done[g_]:
-                continue
-            for (b, s, lab, pr) in h:
-                k = len(lab)
-                l2 = np.full(128, 0xFFFF, np.uint16); l2[:k] = lab
-                p2 = np.zeros(128, np.float32); p2[:k] = pr
-                r = int(self.result[g_])
-                z = 0 if r == 0 else (1 if (r == 1) == (s == 0) else -1)  # winner's plies +1, loser's -1
-                B.append(b); S.append(s); L.append(l2); P.append(p2); C.append(k); Z.append(z)
-        if not B:
-            return np.zeros((0, REC_BYTES), np.uint8)
-        return pack_records(np.stack(B), np.asarray(S, np.uint8), np.stack(L), np.stack(P), np.asarray(C, np.uint8), np.asarray(Z, np.int8))
+    # -- host side --------------------------------------------------------------------------------------
+    def active(self):
+        """uint8 [G] host tensor: 1 = game in progress (synchronises)."""
+        self.eng.ctx.bind_stream()
+        buf = np.empty(self.eng.G, np.uint8)
+        check(lib().cz_download(self.eng.ctx.h, buf.ctypes.data_as(C.c_void_p), self._active_ptr, self.eng.G), "cz_download")
+        return torch.from_numpy(buf)
+
+    def drain_device(self):
+        """-> uint8 [n, REC_BYTES] DEVICE tensor with the records finished since the last drain (synchronises on the
+        cursor only).  The returned rows stay valid until the ring wraps over them."""
+        c = int(self.cursor.item())
+        r, R = self._read, self.ring.shape[0]
+        n = min(c - r, R)
+        if n <= 0:
+            return self.ring[:0]
+        lo = (c - n) % R
+        out = self.ring[lo:lo + n] if lo + n <= R else torch.cat([self.ring[lo:], self.ring[:lo + n - R]], 0)
+        self._read = c
+        self.read_cursor.fill_(c)
+        return out
+
+    def drain(self):
+        """-> uint8 [n, REC_BYTES] host array of the records finished since the last drain."""
+        return self.drain_device().cpu().numpy().reshape(-1, REC_BYTES)
+
+    def stats(self):
+        """Running totals since start(): games, red_wins, black_wins, draws, plies (records), stalled, dropped, sims."""
+        self.eng.ctx.bind_stream()
+        check(lib().cz_selfplay_stats(self.eng.ctx.h, C.c_void_p(self._stats.data_ptr())), "cz_selfplay_stats")
+        s = self._stats.cpu().numpy()
+        d = {k: int(v) for k, v in zip(SP_STATS, s) if k != "reserved"}
+        d["sims"] = int(self.sims_t.item())
+        d["plies_played"] = self.plies
+        return d

@@ -57,6 +57,30 @@ extern "C" {
 #define CZ_ST_MOVE_OVERFLOW 4  /* > 128 moves or a move without a label */
 #define CZ_ST_BAD_ADVANCE 8    /* played move is not a child of the root (reference: KeyError) */
 
+/* One self-play training record (cz_selfplay_*): the tuple cchess_main.selfplay appends per ply (main.py:1504-1518) in
+ * packed form.  board = root position BEFORE the move in real coordinates (the canonical, side-to-move-first state of
+ * the reference is try_flip of it for black, main.py:1505), side = mover, count = number of root children,
+ * z = game result from the mover's point of view (main.py:1533-1544), labels/visits = the root's children in generation
+ * order (root.child.items(), main.py:1339) with their visit counts N — pi = softmax(1/T * log(visits)) (main.py:1341) is
+ * recomputed from them on the host in float64, bit for bit.  Unused label slots hold 0xFFFF, unused visits 0. */
+#define CZ_REC_BYTES 608
+#define CZ_REC_SIDE 90    /* uint8 */
+#define CZ_REC_COUNT 91   /* uint8 */
+#define CZ_REC_Z 92       /* int8: +1 / -1 / 0 */
+#define CZ_REC_FLAGS 93   /* uint8: bit 0 = a visit count saturated at 65535 */
+#define CZ_REC_PLY 94     /* uint16: index of the ply in its game */
+#define CZ_REC_LABELS 96  /* uint16[128] */
+#define CZ_REC_VISITS 352 /* uint16[128] */
+/* cz_selfplay_stats slots */
+#define CZ_SP_NSTATS 8
+#define CZ_SP_GAMES 0      /* games finished (including stalled ones) */
+#define CZ_SP_RED_WINS 1   /* 'k' captured: "w" wins */
+#define CZ_SP_BLACK_WINS 2 /* 'K' captured: "b" wins */
+#define CZ_SP_DRAWS 3      /* restrict_round >= 60 (main.py:1542) or the history capacity reached */
+#define CZ_SP_PLIES 4      /* records handed to the ring */
+#define CZ_SP_STALLED 5    /* games dropped because the root had no child to play (node pool exhausted) */
+#define CZ_SP_DROPPED 6    /* records dropped because the ring was full */
+
 typedef struct cz_ctx cz_ctx;
 
 const char *cz_last_error(void);
@@ -157,8 +181,8 @@ int cz_search_expand_backup_k(cz_ctx *, int k, const void *logits, const void *v
 int cz_search_root_stats(cz_ctx *, uint16_t *move_label, int32_t *N, float *Q, float *P, float *W,
                          uint16_t *count);
 /* K7  replaces MCTS_tree.update_tree (main.py:272-276) + the board bookkeeping of selfplay
- *   (:1522-1528): re-root on the played child keeping its subtree (compacted into the spare
- *   pool).  played_label 0xFFFF leaves the tree untouched. */
+ *   (:1522-1528): re-root on the played child keeping its subtree (compacted in place: one node
+ *   pool per tree); clears CZ_ST_POOL_EXHAUSTED.  played_label 0xFFFF leaves the tree untouched. */
 int cz_search_advance(cz_ctx *, const uint16_t *played_label);
 int cz_search_status(cz_ctx *, int32_t *status, int32_t *nodes_used, int32_t *sims,
                      int32_t *last_depth); /* device [G] arrays, any may be NULL */
@@ -167,6 +191,39 @@ int cz_search_root_state(cz_ctx *, uint8_t *boards, uint8_t *side, int32_t *rest
  *   {depth, label, N, bits(W), bits(Q), bits(P), child_count or -1}.  Returns the record count
  *   (>= 0; at most max_records are written) or a negative error. */
 int cz_search_tree_dump(cz_ctx *, int g, int32_t *host_out, int max_records);
+
+/* ---- device-resident self-play bookkeeping (one wave per game; no host round trip per ply) ------------------------
+ * replaces: cchess_main.get_action (main.py:1332-1358) and the per-ply / end-of-game bookkeeping of cchess_main.selfplay
+ * (:1493-1554) for the G games of the ctx at once.  One ply of every game =
+ *     cz_search_select/expand_backup... (the playouts; pass cz_selfplay_active as the select `active` mask)
+ *     cz_selfplay_choose      pi from the root visits, the sampled move, the (s, pi) record of the ply
+ *     cz_search_advance       update_tree + board bookkeeping with the chosen moves
+ *     cz_selfplay_adjudicate  game end tests on the new positions, z for the finished games' records, re-seed
+ *     cz_selfplay_flush       finished games' records -> the caller's record ring
+ * cz_selfplay_begin (after cz_search_reset): allocates the per-slot histories [G][max_plies] records and makes the
+ *   given positions (NULL: the trees' current roots) the ones every new game of a slot starts from; zeroes the statistics.
+ *   A game that reaches max_plies plies is adjudicated a draw (the reference has no such limit; its games end by the
+ *   60-ply no-capture rule).
+ * cz_selfplay_choose: gamma [G][128] f32 Gamma(0.3, 1) variates (normalised per game = Dirichlet(0.3), main.py:1346) or
+ *   NULL, u [G] f32 uniforms in [0, 1), forced [G] labels overriding the sampled move (0xFFFF = none; NULL) for replaying
+ *   recorded games; temperature as in get_action; noise_eps = 0.25 when exploring, 0 otherwise.  played [G] out
+ *   (0xFFFF for parked games and for games whose root has no child).
+ * cz_selfplay_adjudicate: reseed != 0: a finished slot starts a new game at once; 0: it is parked (cz_selfplay_active
+ *   turns 0).  fin_n [G] out: records the finished game contributes (0 otherwise).
+ * cz_selfplay_flush: offset [G] int64 = first ring index (before the modulo) of each finished game, i.e. an exclusive
+ *   prefix sum of fin_n on top of the running cursor, computed by the caller; ring [ring_records][CZ_REC_BYTES];
+ *   read_cursor: device int64 the caller advances after draining (records that would overwrite undrained ones are
+ *   dropped and counted), or NULL.
+ * cz_selfplay_stats: device int64 [CZ_SP_NSTATS] <- running totals. */
+int cz_selfplay_begin(cz_ctx *, int max_plies, const uint8_t *start_boards, const uint8_t *start_side,
+                      const int32_t *start_rr);
+int cz_selfplay_active(cz_ctx *, const uint8_t **active_dev /* [G] */);
+int cz_selfplay_choose(cz_ctx *, const float *gamma, const float *u, const uint16_t *forced, double temperature,
+                       float noise_eps, uint16_t *played);
+int cz_selfplay_adjudicate(cz_ctx *, int reseed, int32_t *fin_n);
+int cz_selfplay_flush(cz_ctx *, const int32_t *fin_n, const long long *offset, uint8_t *ring, long long ring_records,
+                      const long long *read_cursor);
+int cz_selfplay_stats(cz_ctx *, long long *stats_dev);
 
 /* ---- N1: policy/value network kernels ---------------------------------------------------------
  * One residual-tower layer: 3x3 SAME convolution 128->128 over [B][9][10] boards, NHWC bf16, with the

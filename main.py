@@ -329,6 +329,7 @@ class cchess_main(object):
         self.human_color = human_color
         self.games = games
         self.num_gpus = num_gpus
+        self.update_seed = 20260925   # mini-batch / shuffle seed shared by all ranks (rank-consistent control flow)
 
     @staticmethod
     def flip_policy(prob):
@@ -474,58 +475,63 @@ class cchess_main(object):
         return zip(states, mcts_probs, z), len(z)
 
     # ---- the batched training loop (main.py:1157-1248) ------------------------------------------------------
-    def selfplay_batch(self, games=None, max_plies=None):
-        """`games` self-play games in lock-step on this GPU; returns packed (s, pi, z) records of all ranks."""
+    def selfplay_batch(self, games=None, max_plies=None, target_games=None):
+        """Self-play on `games` game slots of this GPU, device-resident and continuous (a finished game's slot starts
+        the next game at once, cchess_zero_amd/selfplay.py) until `target_games` games (default: one per slot) have
+        finished; returns the packed (s, pi, z) records of all ranks (one all-gather).  max_plies bounds the number of
+        plies played (tests)."""
         import torch
         from cchess_zero_amd import parallel
         from cchess_zero_amd.engine import SearchEngine
         from cchess_zero_amd.selfplay import SelfPlay
         G = games or self.games
-        # a ply adds ~40 nodes per simulation on top of the subtree kept from the previous ply (160 has held over many plies;
-        # a tree that does overflow is parked and its game adjudicated a draw at max_plies)
-        cap = max(4096, (self.playout_counts + 2) * 160)
-        if getattr(self, "_batch_eng", None) is None or self._batch_eng.ctx.max_games < G:
+        target = target_games or G
+        # a ply adds ~40 nodes per simulation on top of the subtree kept from the previous ply; a tree that fills its pool
+        # stops expanding for the rest of that ply (the move is chosen from the visits it has) and gets its room back when
+        # cz_search_advance compacts it
+        cap = max(4096, (self.playout_counts + 2) * 128)
+        if getattr(self, "_batch_eng", None) is None or self._batch_eng.ctx.max_games < G or self._batch_eng.ctx.cap < cap:
             self._batch_eng = SearchEngine(G, cap, torch.cuda.current_device())
+        # every rank seeds its games differently but reproducibly from the shared Python RNG state
+        base_seed = random.randrange(1 << 30)
+        rank = int(os.environ.get("RANK", "0"))
         sp = SelfPlay(self._batch_eng, self.policy_value_netowrk.net, self.playout_counts, self.exploration, self.temperature,
-                      seed=random.randrange(1 << 30))
+                      seed=base_seed + 7919 * rank, continuous=True)
         b0 = np.tile(state_to_board(START_STATE), (G, 1))
         sp.start(b0, np.zeros(G, np.uint8), np.zeros(G, np.int32))
-        rec = sp.play(max_plies=max_plies)
-        self.last_selfplay_sims = sp.sims
+        chunks, plies = [], 0
+        while True:
+            sp.step_ply()
+            plies += 1
+            if plies % 8 == 0 or (max_plies is not None and plies >= max_plies):
+                chunks.append(sp.drain_device().clone())
+                st = sp.stats()
+                if st["games"] >= target or (max_plies is not None and plies >= max_plies):
+                    break
+        self.last_selfplay_stats = sp.stats()
+        self.last_selfplay_sims = self.last_selfplay_stats["sims"]
+        rec = torch.cat(chunks, 0) if chunks else sp.ring[:0]
         return parallel.gather_records(rec)
 
     def policy_update(self):
-        mini_batch = random.sample(self.data_buffer, self.batch_size)
-        state_batch = [d[0] for d in mini_batch]
-        mcts_probs_batch = [d[1] for d in mini_batch]
-        winner_batch = np.expand_dims([d[2] for d in mini_batch], 1)
-        start_time = time.time()
-        net = self.policy_value_netowrk
-        old_probs, old_v = net.forward(state_batch)
-        kl, loss, accuracy, new_v = 0.0, 0.0, 0.0, old_v
-        for i in range(self.epochs):
-            accuracy, loss, self.global_step = net.train_step(state_batch, mcts_probs_batch, winner_batch, self.learning_rate * self.lr_multiplier)
-            new_probs, new_v = net.forward(state_batch)
-            with np.errstate(all="ignore"):   # the reference feeds raw logits into its KL estimate (main.py:1175)
-                kl_tmp = old_probs * (np.log((old_probs + 1e-10) / (new_probs + 1e-10)))
-            kl = float(np.mean([np.sum(line[np.isfinite(line)]) for line in kl_tmp]))
-            if kl > self.kl_targ * 4:
-                break
-        net.save(self.global_step)
-        print("train using time {} s".format(time.time() - start_time))
-        if kl > self.kl_targ * 2 and self.lr_multiplier > 0.1:
-            self.lr_multiplier /= 1.5
-        elif kl < self.kl_targ / 2 and self.lr_multiplier < 10:
-            self.lr_multiplier *= 1.5
-        wb = np.array(winner_batch).flatten()
-        var = np.var(wb) + 1e-12
+        from cchess_zero_amd.train import policy_update
+        self.lr_multiplier, info = policy_update(self.policy_value_netowrk, self.data_buffer, self.batch_size, self.epochs,
+                                                 self.learning_rate, self.lr_multiplier, self.kl_targ, seed=self.update_seed)
+        self.global_step = self.policy_value_netowrk.global_step
         msg = "kl:{:.5f},lr_multiplier:{:.3f},loss:{},accuracy:{},explained_var_old:{:.3f},explained_var_new:{:.3f}".format(
-            kl, self.lr_multiplier, loss, accuracy, 1 - np.var(wb - old_v.flatten()) / var, 1 - np.var(wb - new_v.flatten()) / var)
+            info["kl"], self.lr_multiplier, info["loss"], info["accuracy"], info["explained_var_old"], info["explained_var_new"])
         print(msg)
         self.log_file.write(msg + '\n')
         self.log_file.flush()
+        return info
 
     def run(self, max_batches=None):
+        """The training loop (main.py:1206-1248).  One iteration = a self-play batch of `games` slots per GPU (thousands
+        of samples where the reference's single game gives ~100), so the reference's cadence is rescaled: the buffer
+        holds at least the last two batches (the reference: 10 000 samples = ~100 games), the gathered records are
+        shuffled before they enter it (so that a bounded buffer is not biased towards the last ranks' games), and the
+        number of policy updates per batch grows with the number of new samples (the reference: one update of
+        `batch_size` samples x `epochs` per ~100 new samples; here one per `batch_size` new samples, at most 64)."""
         from cchess_zero_amd.selfplay import to_dense
         batch_iter = 0
         try:
@@ -533,12 +539,18 @@ class cchess_main(object):
                 batch_iter += 1
                 t0 = time.time()
                 rec = self.selfplay_batch()
-                planes, pi, z = to_dense(rec)
+                planes, pi, z = to_dense(rec, self.temperature, exact=False)
                 dt = time.time() - t0
-                print("batch i:{}, games:{}, samples:{}, sims/s:{:.0f}".format(batch_iter, self.games, len(z), self.last_selfplay_sims / max(dt, 1e-9)))
-                self.data_buffer.extend(zip(planes, pi, z))
+                st = self.last_selfplay_stats
+                print("batch i:{}, game slots:{}, games finished:{}, samples:{}, sims/s:{:.0f}".format(
+                    batch_iter, self.games, st["games"], len(z), self.last_selfplay_sims / max(dt, 1e-9)))
+                if self.data_buffer.maxlen < 2 * len(z):
+                    self.data_buffer = deque(self.data_buffer, maxlen=2 * len(z))
+                order = np.random.RandomState(self.update_seed + batch_iter).permutation(len(z))   # same on every rank
+                self.data_buffer.extend((planes[i], pi[i], z[i]) for i in order)
                 if len(self.data_buffer) > self.batch_size:
-                    self.policy_update()
+                    for _ in range(max(1, min(64, len(z) // self.batch_size))):
+                        self.policy_update()
         except KeyboardInterrupt:
             self.log_file.close()
             self.policy_value_netowrk.save(self.global_step)

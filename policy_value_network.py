@@ -4,11 +4,13 @@
 
   reference (TF1 graph + session)                       here
   policy_value_network.py:45-74,151-162  graph          cchess_zero_amd/net.py (PyTorch-ROCm), tower convs by
-                                                         the fused MFMA kernel cz_tower_c128_bf16 (csrc/)
+                                                         the fused MFMA kernel cz_net_trunk_bf16 (csrc/)
   :202-214  forward(positions)->(logits[B,2086], v[B,1]) identical signature; ndarray or list of [9,10,14]
-  :77-126,186-199  loss / Nesterov-momentum SGD / clip   train_step(): CE + MSE + 1e-4*sum(w^2)/2, momentum 0.9,
-                                                         use_nesterov, clip_by_global_norm(100), NaN check
-  :164-184  tf.train.Saver, ./models/best_model.ckpt-N   torch checkpoints under the same directory/prefix
+  :77-126,186-199  loss / Nesterov-momentum SGD / clip   cchess_zero_amd/train.py Trainer: CE + MSE + 1e-4*sum(w^2)/2,
+                                                         momentum 0.9, use_nesterov, clip_by_global_norm(100), NaN check
+  :164-184  tf.train.Saver, ./models/best_model.ckpt-N   torch checkpoints under the same directory/prefix (weights,
+                                                         momentum slots, global step); restore() also takes an .npz of
+                                                         the reference's TF1 variables (net.from_tf_variables)
 There is no CPU fallback: constructing the network without a HIP device raises.
 """
 import glob
@@ -17,9 +19,9 @@ import re
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
-from cchess_zero_amd.net import PolicyValueModule, PolicyValueNet
+from cchess_zero_amd.net import PolicyValueModule, PolicyValueNet, from_tf_variables, to_tf_variables
+from cchess_zero_amd.train import Trainer
 
 
 class policy_value_network(object):
@@ -36,9 +38,19 @@ class policy_value_network(object):
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.net = PolicyValueNet(res_block_nums, self.device, dtype, seed=seed)
         self.module = self.net.module
-        self.global_step = 0
-        self._opt = None
+        self.trainer = Trainer(self.module, self.c_l2, self.momentum, self.global_norm)
         self.train_restore()
+
+    @property
+    def global_step(self):
+        return self.trainer.global_step
+
+    @global_step.setter
+    def global_step(self, v):
+        self.trainer.global_step = int(v)
+
+    def refresh(self):
+        self.net.refresh()
 
     # ---- inference --------------------------------------------------------------------------
     def forward(self, positions):
@@ -50,42 +62,14 @@ class policy_value_network(object):
         return self.net.forward_device(planes)
 
     # ---- training (policy_value_network.py:77-126,186-199) -------------------------------------------
-    def _optimizer(self, lr):
-        if self._opt is None:
-            self._opt = torch.optim.SGD(self.module.parameters(), lr=lr, momentum=self.momentum, nesterov=True)
-        for g in self._opt.param_groups:
-            g["lr"] = lr
-        return self._opt
-
     def loss(self, positions, probs, winners, training=True):
-        x = torch.as_tensor(np.asarray(positions, dtype=np.float32)).to(self.device).permute(0, 3, 1, 2)
-        pi = torch.as_tensor(np.asarray(probs, dtype=np.float32)).to(self.device)
-        z = torch.as_tensor(np.asarray(winners, dtype=np.float32)).to(self.device).reshape(-1, 1)
-        logits, v = self.module(x, training=training)
-        policy_loss = -(pi * F.log_softmax(logits, dim=1)).sum(dim=1).mean()   # softmax_cross_entropy_with_logits
-        value_loss = F.mse_loss(v, z)                                          # tf.losses.mean_squared_error
-        l2 = sum((p * p).sum() for p in self.module.parameters()) * (self.c_l2 / 2.0)  # l2_regularizer over ALL trainables
-        accuracy = (logits.argmax(dim=1) == pi.argmax(dim=1)).float().mean()
-        return value_loss + policy_loss + l2, accuracy
+        return self.trainer.loss(positions, probs, winners, training)
 
     def train_step(self, positions, probs, winners, learning_rate):
         """-> (accuracy, loss, global_step), like policy_value_network.py:186-199."""
-        opt = self._optimizer(float(learning_rate))
-        self.module.train()
-        opt.zero_grad(set_to_none=True)
-        loss, accuracy = self.loss(positions, probs, winners, training=True)
-        loss.backward()
-        from cchess_zero_amd.parallel import allreduce_gradients
-        allreduce_gradients(self.module)                                       # no-op without a process group
-        torch.nn.utils.clip_grad_norm_(self.module.parameters(), self.global_norm)   # tf.clip_by_global_norm
-        for p in self.module.parameters():                                     # tf.check_numerics('NaN Found!')
-            if p.grad is not None and not torch.isfinite(p.grad).all():
-                raise FloatingPointError("NaN Found!")
-        opt.step()
-        self.module.eval()
-        self.net.refresh()
-        self.global_step += 1
-        return float(accuracy.detach()), float(loss.detach()), self.global_step
+        out = self.trainer.train_step(positions, probs, winners, learning_rate)
+        self.net.refresh()   # re-fold BN and re-pack the MFMA operands for the new weights
+        return out
 
     # ---- checkpoints (policy_value_network.py:164-184) ----------------------------------------------------
     def _ckpts(self):
@@ -107,15 +91,31 @@ class policy_value_network(object):
             print("Could not find old network weights")
 
     def restore(self, file):
+        """A checkpoint written by save(), or an .npz holding the reference's TF1 variables by name (`conv2d/kernel`,
+        `BatchNorm_3/moving_variance`, `fully_connected/weights`, ... — what `tf.train.load_checkpoint(ckpt)` lists for a
+        cchess-zero model; HWIO kernels and [in,out] FC weights are converted by load_tf_layout)."""
         print("Restoring from {0}".format(file))
-        d = torch.load(file, map_location=self.device)
-        self.module.load_state_dict(d["model"])
-        self.global_step = int(d.get("global_step", 0))
+        if str(file).endswith(".npz"):
+            d, blocks, gs = from_tf_variables(np.load(file), self.module.res_block_nums)
+            self.module.load_tf_layout(d)
+            if gs is not None:
+                self.global_step = gs
+        else:
+            self.trainer.load_state_dict(torch.load(file, map_location=self.device))
         self.net.refresh()
 
     def save(self, in_global_step):
         os.makedirs(self.save_dir, exist_ok=True)
         path = os.path.join(self.save_dir, "best_model.ckpt-%d.pt" % int(in_global_step))
-        torch.save({"model": self.module.state_dict(), "global_step": int(in_global_step)}, path)
+        d = self.trainer.state_dict()
+        d["global_step"] = int(in_global_step)
+        torch.save(d, path)
         print("Model saved in file: {}".format(path))
         return path
+
+    def export_tf_variables(self, file=None):
+        """The weights under the reference graph's TF1 variable names (optionally written as .npz)."""
+        d = to_tf_variables(self.module, self.global_step)
+        if file is not None:
+            np.savez(file, **d)
+        return d

@@ -16,6 +16,9 @@ Fixtures
   mcts.json    MCTS_tree.main (main.py:473) runs with search_threads=1 and the exact-integer
                fake forward of tests/fakenet.py: root children (label, N, W, Q, P bit
                patterns), whole-tree digests, the ordered list of evaluated positions.
+  selfplay.npz cchess_main.selfplay (main.py:1493) games with search_threads=1, the fake forward and
+               a seeded np.random: per ply (canonical state, pi[2086] float64, z), the root
+               children's visit counts and the sampled move (get_action, main.py:1332-1358).
 """
 import hashlib
 import json
@@ -280,12 +283,104 @@ def gen_mcts(m, out, positions, king_roots, seed=7):
     json.dump(dict(numpy=np.__version__, cases=cases), open(os.path.join(out, "mcts.json"), "w"), separators=(",", ":"))
 
 
+SELFPLAY_CASES = [
+    # (name, train_playout, fakenet mode, fakenet salt, np.random seed)
+    dict(name="sp_pos30", playout=30, mode="pos", salt=101, seed=11),
+    dict(name="sp_signed24", playout=24, mode="signed", salt=202, seed=12),
+    dict(name="sp_pos12", playout=12, mode="pos", salt=303, seed=13),
+    # GameBoard.reload patched to start at restrict_round 59: the 60-ply no-capture tie (main.py:1542-1545) is reached
+    dict(name="sp_tie", playout=10, mode="pos", salt=404, seed=14, rr0=59),
+]
+
+
+def gen_selfplay(m, out):
+    """cchess_main.selfplay() of the UNMODIFIED reference (main.py:1493-1554) with search_threads = 1, the exact-integer
+    fake forward and a seeded np.random: per ply the canonical state, the root children with their visit counts, pi
+    (float64, as returned: scattered over the 2086 canonical labels), the move np.random.choice picked, and z."""
+    import tempfile
+
+    class FakePV(object):   # stands in for policy_value_network(res_block_nums): only forward() is used by selfplay()
+        def __init__(self, *a, **k):
+            self.forward = None
+
+        def train_step(self, *a, **k):
+            raise RuntimeError("not used")
+
+        def save(self, *a, **k):
+            pass
+
+    m.policy_value_network = FakePV
+    cols = dict(case=[], state=[], side=[], played=[], count=[], labels=[], visits=[], z=[], pi_ptr=[0], pi_idx=[], pi_val=[])
+    meta = []
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)   # cchess_main.__init__ opens ./log_file.txt
+    try:
+        for ci, c in enumerate(SELFPLAY_CASES):
+            log = []
+            fwd = fakenet.make_forward(c["mode"], c["salt"], log)
+            with rh.quiet():
+                cm = m.cchess_main(c["playout"], 512, True, 1, "cpu", 1, 2)
+            cm.policy_value_netowrk.forward = fwd
+            cm.mcts.forward = fwd
+            trace = []   # (player, [(label, N)], played label) captured where get_action hands the move to update_tree
+            orig_update = cm.mcts.update_tree
+
+            def update_tree(act, cm=cm, trace=trace, orig_update=orig_update):
+                kids = [(m.label2i[a], int(n.N)) for a, n in cm.mcts.root.child.items()]
+                trace.append((cm.game_borad.current_player, kids, m.label2i[act]))
+                return orig_update(act)
+            cm.mcts.update_tree = update_tree
+            if c.get("rr0"):
+                orig_reload = cm.game_borad.reload
+
+                def reload(cm=cm, orig_reload=orig_reload, rr0=c["rr0"]):
+                    orig_reload()
+                    cm.game_borad.restrict_round = rr0
+                cm.game_borad.reload = reload
+            np.random.seed(c["seed"])
+            with rh.quiet(), np.errstate(all="ignore"):
+                play_data, n = cm.selfplay()
+            play_data = list(play_data)
+            assert n == len(play_data) == len(trace)
+            for (state, prob, z), (player, kids, played) in zip(play_data, trace):
+                cols["case"].append(ci)
+                cols["state"].append(fen_to_board(state))   # canonical: try_flip'ed for black (main.py:1505)
+                cols["side"].append(1 if player == "b" else 0)
+                cols["played"].append(played)
+                cols["count"].append(len(kids))
+                lab = np.full(128, 0xFFFF, np.uint16)
+                vis = np.zeros(128, np.int32)
+                lab[:len(kids)] = [k for k, _ in kids]
+                vis[:len(kids)] = [v for _, v in kids]
+                cols["labels"].append(lab)
+                cols["visits"].append(vis)
+                cols["z"].append(float(z))
+                nz = np.nonzero(prob)[0]
+                cols["pi_idx"].extend(int(i) for i in nz)
+                cols["pi_val"].extend(float(prob[i]) for i in nz)
+                cols["pi_ptr"].append(len(cols["pi_idx"]))
+            meta.append(dict(c, plies=n, evals=len(log), z_first=float(play_data[0][2]), z_values=sorted(set(float(d[2]) for d in play_data))))
+            print("selfplay case %-12s plies=%d evals=%d z=%s" % (c["name"], n, len(log), meta[-1]["z_values"]))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(out, "selfplay.npz"),
+                        case=np.asarray(cols["case"], np.int32), state=np.stack(cols["state"]).astype(np.uint8),
+                        side=np.asarray(cols["side"], np.uint8), played=np.asarray(cols["played"], np.uint16),
+                        count=np.asarray(cols["count"], np.uint8), labels=np.stack(cols["labels"]), visits=np.stack(cols["visits"]),
+                        z=np.asarray(cols["z"], np.float64), pi_ptr=np.asarray(cols["pi_ptr"], np.int64),
+                        pi_idx=np.asarray(cols["pi_idx"], np.int32), pi_val=np.asarray(cols["pi_val"], np.float64),
+                        meta=np.asarray(json.dumps(meta)))
+
+
 def main():
     m = rh.load_main()
     out = HERE
-    gen_tables(m, out)
-    positions, king_roots = gen_rules(m, out)
-    gen_mcts(m, out, positions, king_roots)
+    if "--selfplay-only" not in sys.argv:
+        gen_tables(m, out)
+        positions, king_roots = gen_rules(m, out)
+        gen_mcts(m, out, positions, king_roots)
+    gen_selfplay(m, out)
 
 
 if __name__ == "__main__":

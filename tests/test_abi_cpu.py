@@ -64,8 +64,9 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     from cchess_zero_amd import build
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cchess_zero_amd", "csrc")
     flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
-    hot = {"cz_conv.hip": ["k_tower8_c128"], "cz_search.hip": ["k_select", "k_expand_backup"],
-           "cz_heads.hip": ["k_policy_fc", "k_value_fc"], "cz_rules.hip": ["k_movegen", "k_encode_planes"]}
+    hot = {"cz_conv.hip": ["k_tower8_c128"], "cz_search.hip": ["k_select", "k_expand_backup", "k_advance", "k_root_stats"],
+           "cz_heads.hip": ["k_policy_fc", "k_value_fc"], "cz_rules.hip": ["k_movegen", "k_encode_planes"],
+           "cz_selfplay.hip": ["k_sp_choose", "k_sp_adjudicate", "k_sp_flush"]}
 
     def asm(src):
         out = str(tmp_path / (src + ".s"))
@@ -78,7 +79,8 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     for src, names in hot.items():
         # metadata entries look like:  .name: <mangled>  ...  .private_segment_fixed_size: N
         for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", texts[src]):
-            if any(n in m.group(1) for n in names) and "k_select_k" not in m.group(1):
+            if any(n in m.group(1) for n in names):   # k_select also matches k_select_k, k_expand_backup the _k variant
                 assert int(m.group(2)) == 0, "%s uses %s bytes of scratch" % (m.group(1), m.group(2))
                 checked += 1
-    assert checked >= 4 + 2 + 2 + 2 + 2, checked   # 4 trunk instantiations, 2+2 select/expand, 2 heads, 2 rules
+    # 4 trunk instantiations; 4 select + 2 select_k + 3 expand + 2 expand_k + advance + root_stats; 2 heads; 3 rules; 3 self-play
+    assert checked >= 4 + 13 + 2 + 3 + 3, checked

@@ -39,6 +39,48 @@ def test_module_matches_numpy_restatement_cpu(blocks):
     assert torch.equal(l2, lt) and torch.equal(v2, vt)
 
 
+def test_tf1_variable_names_roundtrip_cpu():
+    """a cchess-zero TF1 checkpoint's variables by name (`conv2d_3/kernel`, `BatchNorm_3/moving_variance`,
+    `fully_connected_1/weights` ... as tf.train.load_checkpoint lists them, with Momentum slots and global_step mixed in,
+    ':0' suffixes allowed) load into the module; HWIO / [in,out] layouts are converted; shapes are checked."""
+    from cchess_zero_amd.net import PolicyValueModule, from_tf_variables, tf_variable_names, to_tf_variables
+    names = tf_variable_names(7)
+    assert len(names) == 4 * 17 + 6 and names["conv2d/kernel"] == "conv0/kernel" and names["conv2d_16/bias"] == "conv16/bias"
+    assert names["BatchNorm_15/moving_mean"] == "bn15/moving_mean" and names["fully_connected_2/weights"] == "value_fc2/weights"
+    m = PolicyValueModule(2, seed=3)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for cb in m.convbns():
+            cb.moving_mean.copy_(torch.randn(cb.moving_mean.shape, generator=gen) * 0.1)
+            cb.moving_var.copy_(torch.rand(cb.moving_var.shape, generator=gen) + 0.5)
+    ck = {k + ":0": v for k, v in to_tf_variables(m, global_step=1234).items()}
+    assert ck["conv2d/kernel:0"].shape == (3, 3, 14, 128) and ck["conv2d_5/kernel:0"].shape == (1, 1, 128, 2)
+    assert ck["fully_connected/weights:0"].shape == (180, 2086) and ck["fully_connected_2/weights:0"].shape == (256, 1)
+    for k in list(ck):                                  # what a real checkpoint also holds
+        if k.endswith("kernel:0") or k.endswith("weights:0"):
+            ck[k[:-2] + "/Momentum:0"] = np.zeros_like(ck[k])
+    d, blocks, gs = from_tf_variables(ck)
+    assert blocks == 2 and gs == 1234
+    m2 = PolicyValueModule(2, seed=8)
+    m2.load_tf_layout(d)
+    x = torch.from_numpy(_positions(5, 1)).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        a, b = m(x), m2(x)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # and the NumPy restatement of the TF graph consumes the very same arrays
+    ln, vn = net_numpy.forward(d, _positions(5, 1), 2)
+    assert np.abs(a[0].numpy() - ln).max() < 1e-4 and np.abs(a[1].numpy() - vn).max() < 1e-5
+    with pytest.raises(ValueError):
+        from_tf_variables(ck, res_block_nums=7)
+    bad = dict(ck)
+    bad["conv2d_1/kernel:0"] = np.zeros((3, 3, 64, 128), np.float32)
+    with pytest.raises(ValueError):
+        from_tf_variables(bad)
+    del bad["BatchNorm/moving_mean:0"]
+    with pytest.raises((KeyError, ValueError)):
+        from_tf_variables(bad)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("blocks", [2, 7])
 def test_inference_engine_fp32_within_1e3(blocks):

@@ -24,10 +24,9 @@ def _fake_records(rank, n, seed=0):
     for i in range(n):
         mv = O.legal_moves(b, s)
         k = len(mv)
-        pr = rng.random(k).astype(np.float32)
-        pr /= pr.sum()
         l2 = np.full(128, 0xFFFF, np.uint16); l2[:k] = mv
-        p2 = np.zeros(128, np.float32); p2[:k] = pr
+        p2 = np.zeros(128, np.int64); p2[:k] = rng.integers(0, 400, k)   # root visit counts (some zero)
+        p2[int(rng.integers(k))] += 1 + int(rng.integers(1600))
         B.append(b.copy()); S.append(s); L.append(l2); P.append(p2); C.append(k); Z.append(int(rng.integers(-1, 2)))
         nb, cap, term = O.apply_move(b, int(mv[rng.integers(k)]))
         if term:
@@ -101,6 +100,15 @@ def test_record_roundtrip_and_dense_expansion():
         lab = u["labels"][i, :k].astype(np.int64)
         if u["side"][i]:
             lab = unflip[lab]
-        assert abs(float(pi[i].sum()) - 1.0) < 2e-2          # fp16 storage of the probabilities
-        assert np.count_nonzero(pi[i]) <= k and np.all(pi[i, lab] >= 0)
+        # pi = the reference's softmax(1/T * log(visits)) (main.py:1341), bit for bit from the stored visit counts
+        v = tuple(int(x) for x in u["visits"][i, :k])
+        with np.errstate(divide="ignore"):
+            x = 1.0 / 1 * np.log(v)
+        probs = np.exp(x - np.max(x))
+        probs /= np.sum(probs)
+        assert np.array_equal(pi[i, lab], probs) and abs(float(pi[i].sum()) - 1.0) < 1e-12
+        assert np.count_nonzero(pi[i]) == np.count_nonzero(v)
         assert z[i] in (-1.0, 0.0, 1.0)
+    # the vectorised expansion agrees to the last bits
+    _, pi_fast, _ = SP.to_dense(rec, exact=False)
+    assert np.allclose(pi_fast, pi, rtol=1e-14, atol=0)

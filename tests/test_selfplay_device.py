@@ -1,0 +1,119 @@
+"""The device-resident self-play loop (cchess_zero_amd/selfplay.py over cz_selfplay_* / cz_search_advance) with the real
+fused net: continuous re-seeding keeps every slot busy, the records are well-formed training tuples of the reference's
+self-play (main.py:1493-1554), a tree that fills its node pool recovers at the next advance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+START_FEN = "RNBAKABNR/9/1C5C1/P1P1P1P1P/9/9/p1p1p1p1p/1c5c1/9/rnbakabnr"
+
+
+def _setup(G, cap, playouts, continuous=True, seed=3, **kw):
+    from cchess_zero_amd.engine import SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet
+    from cchess_zero_amd.selfplay import SelfPlay
+    from oracle import oracle as O
+    net = PolicyValueNet(2, "cuda:0", torch.bfloat16, seed=2)
+    eng = SearchEngine(G, cap, plane_dtype=torch.bfloat16, channels=16)
+    sp = SelfPlay(eng, net, playouts, exploration=True, temperature=1.0, seed=seed, continuous=continuous, **kw)
+    sp.start(np.tile(O.fen_to_board(START_FEN), (G, 1)), np.zeros(G, np.uint8), np.zeros(G, np.int32))
+    return net, eng, sp
+
+
+def _check_records(rec, playouts):
+    """Every record is a (state, visit policy, z) tuple of a legal self-play game; returns the number of games."""
+    from cchess_zero_amd.selfplay import to_dense, unpack_records
+    from oracle import oracle as O
+    u = unpack_records(rec)
+    n = len(rec)
+    starts = list(np.nonzero(u["ply"] == 0)[0]) + [n]
+    assert starts[0] == 0
+    for a, b in zip(starts[:-1], starts[1:]):
+        assert np.array_equal(u["ply"][a:b], np.arange(b - a)), "records of a game are contiguous and in ply order"
+        assert np.array_equal(u["side"][a:b], np.arange(b - a) % 2), "red moves first, sides alternate"
+        assert np.array_equal(u["boards"][a], O.fen_to_board(START_FEN))
+        z = u["z"][a:b].astype(int)
+        # one result per game, seen from the mover: constant up to the side
+        res = z * np.where(u["side"][a:b] == 0, 1, -1)
+        assert len(set(res.tolist())) == 1 and res[0] in (-1, 0, 1)
+        board = u["boards"][a].copy()
+        for j in range(a, b):
+            k = int(u["counts"][j])
+            mv = O.legal_moves(u["boards"][j], int(u["side"][j]))
+            assert k == len(mv) and np.array_equal(u["labels"][j, :k], mv), "root children = legal moves, generation order"
+            assert np.all(u["labels"][j, k:] == 0xFFFF) and np.all(u["visits"][j, k:] == 0)
+            v = int(u["visits"][j, :k].astype(np.int64).sum())
+            assert v >= playouts if j > a else v == playouts, (j - a, v)   # a fresh root has exactly `playouts` visits below it
+            if j + 1 < b:   # the next recorded position follows from this one by one of its legal moves
+                nxt = u["boards"][j + 1]
+                diff = np.nonzero(nxt != u["boards"][j])[0]
+                assert 1 <= len(diff) <= 2
+        last = u["boards"][b - 1]
+        assert (last == 1).any() and (last == 8).any(), "both kings are on the board before the last move"
+    planes, pi, z = to_dense(rec, 1.0, exact=False)
+    assert np.allclose(pi.sum(axis=1), 1.0, atol=1e-12) and planes.shape == (n, 9, 10, 14)
+    return len(starts) - 1
+
+
+def test_continuous_selfplay_keeps_every_slot_busy():
+    G, playouts, plies = 96, 6, 260
+    net, eng, sp = _setup(G, 4096, playouts)
+    recs = []
+    for chunk in range(plies // 20):
+        sp.run(20)
+        recs.append(sp.drain())
+    st = sp.stats()
+    rec = np.concatenate(recs, axis=0)
+    print("continuous self-play: %d plies x %d slots: %d games finished (%d red, %d black, %d draws), %d records, %d stalled" %
+          (plies, G, st["games"], st["red_wins"], st["black_wins"], st["draws"], st["plies"], st["stalled"]))
+    # every slot searched every ply: the batch never decayed
+    assert st["sims"] == plies * G * playouts
+    assert st["stalled"] == 0 and st["dropped"] == 0 and st["games"] >= G // 2
+    assert st["games"] == st["red_wins"] + st["black_wins"] + st["draws"] and st["plies"] == len(rec)
+    assert not bool(eng.status()[0].any())
+    games = _check_records(rec, playouts)
+    assert games == st["games"]
+    # games in progress keep their partial histories on the device: the plies recorded so far
+    assert sp.active().all()
+
+
+def test_parking_mode_plays_one_game_per_slot():
+    G, playouts = 24, 4
+    net, eng, sp = _setup(G, 4096, playouts, continuous=False, max_plies=400)
+    rec = sp.play()
+    st = sp.stats()
+    assert st["games"] == G and not bool(sp.active().any())
+    assert _check_records(rec, playouts) == G
+    # parked slots cost the search nothing afterwards
+    before = st["sims"]
+    sp.step_ply()
+    assert sp.stats()["sims"] == before
+
+
+def test_full_node_pool_recovers_at_the_advance():
+    """A pool too small for a ply's expansions: the tree stops expanding (CZ_ST_POOL_EXHAUSTED), its move is still chosen
+    from the visits it has, and cz_search_advance — which compacts the kept subtree in place — clears the flag, so the
+    game goes on (round 1 parked such a tree for the rest of its game and recorded junk plies)."""
+    G, playouts = 16, 24
+    net, eng, sp = _setup(G, 400, playouts)   # ~40 new nodes per simulation: 400 nodes fill up within a ply
+    saw_full = 0
+    for ply in range(30):
+        eng.search(net.forward_device, playouts)
+        st = eng.status()[0].cpu().numpy()
+        saw_full += int((st & 1).sum())
+        assert not np.any(st & ~1)
+        # the rest of step_ply: choose / advance / adjudicate / flush (search again on top would double the playouts)
+        sp.playouts = 0
+        sp.step_ply()
+        sp.playouts = playouts
+        assert not np.any(eng.status()[0].cpu().numpy() & 1), "advance clears POOL_EXHAUSTED"
+    assert saw_full > 0, "the pool was meant to overflow"
+    s = sp.stats()
+    assert s["stalled"] == 0
+    rec = sp.drain()
+    if len(rec):
+        from cchess_zero_amd.selfplay import unpack_records
+        u = unpack_records(rec)
+        assert np.all(u["counts"] > 0) and np.all(u["visits"].astype(np.int64).sum(axis=1) > 0)

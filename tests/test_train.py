@@ -1,0 +1,205 @@
+"""SURVEY §8 row f1 — the training step and the policy update (policy_value_network.py:77-126,186-199; main.py:1157-1204).
+
+  * Trainer.train_step (cchess_zero_amd/train.py, fp32 torch) against an independent float64 restatement of the
+    reference graph's loss and optimiser written from the TF semantics (NHWC activations, HWIO kernels, batch-statistic
+    BatchNorm without affine terms, softmax cross-entropy + MSE + 1e-4 * sum(w^2)/2 over ALL trainables, global-norm clip
+    100, Nesterov momentum 0.9 applied the way tf.train.MomentumOptimizer does): loss, gradient norm and the weight
+    updates of two consecutive steps (the second exercises the momentum slots).
+  * policy_update under torch.distributed (gloo, world 2, CPU): every rank takes the same number of steps (the KL that
+    drives the early stop is all-reduced), ends with bit-identical weights and the same lr_multiplier; rank 0 alone saves.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _batch(n, seed):
+    import nethelpers as H
+    rng = np.random.default_rng(seed)
+    x = H.positions(n, seed)
+    pi = rng.random((n, 2086)) ** 8
+    pi = (pi / pi.sum(axis=1, keepdims=True)).astype(np.float32)
+    z = rng.choice([-1.0, 0.0, 1.0], size=(n, 1)).astype(np.float32)
+    return x, pi, z
+
+
+def _tf_loss64(w, x, pi, z, blocks, c_l2=1e-4):
+    """The reference graph in float64, TF layout (policy_value_network.py:45-92), training mode."""
+    idx = [0]
+
+    def convbn(h, relu):
+        i = idx[0]
+        idx[0] += 1
+        k = w["conv%d/kernel" % i]                                      # HWIO
+        y = F.conv2d(h.permute(0, 3, 1, 2), k.permute(3, 2, 0, 1), w["conv%d/bias" % i], padding=k.shape[0] // 2).permute(0, 2, 3, 1)
+        m = y.mean(dim=(0, 1, 2))
+        v = ((y - m) ** 2).mean(dim=(0, 1, 2))                            # fused batch norm normalises with the biased variance
+        y = (y - m) / torch.sqrt(v + 1e-5)
+        return torch.relu(y) if relu else y
+    h = convbn(x, True)
+    for _ in range(blocks):
+        t = convbn(h, True)
+        t = convbn(t, False)
+        h = torch.relu(h + t)
+    p = convbn(h, True).reshape(x.shape[0], 180)
+    logits = p @ w["policy_fc/weights"] + w["policy_fc/biases"]
+    v = convbn(h, True).reshape(x.shape[0], 90)
+    v = torch.relu(v @ w["value_fc1/weights"] + w["value_fc1/biases"])
+    v = torch.tanh(v @ w["value_fc2/weights"] + w["value_fc2/biases"])
+    policy_loss = (-(pi * torch.log_softmax(logits, dim=1)).sum(dim=1)).mean()
+    value_loss = ((z - v) ** 2).mean()
+    trainables = [t for k, t in w.items() if not k.startswith("bn")]
+    l2 = c_l2 * sum((t * t).sum() / 2 for t in trainables)
+    return value_loss + policy_loss + l2, trainables
+
+
+def _run_restatement(w0, batches, lr, blocks, momentum=0.9, clip=100.0):
+    w = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=not k.startswith("bn")) for k, v in w0.items()}
+    names = [k for k in w if not k.startswith("bn")]
+    accum = {k: torch.zeros_like(w[k]) for k in names}
+    out = []
+    for (x, pi, z) in batches:
+        loss, _ = _tf_loss64(w, torch.tensor(x, dtype=torch.float64), torch.tensor(pi, dtype=torch.float64),
+                             torch.tensor(z, dtype=torch.float64), blocks)
+        grads = torch.autograd.grad(loss, [w[k] for k in names])
+        gn = torch.sqrt(sum((g * g).sum() for g in grads))
+        scale = clip / max(float(gn), clip)                                # tf.clip_by_global_norm
+        with torch.no_grad():
+            for k, g in zip(names, grads):
+                g = g * scale
+                accum[k] = momentum * accum[k] + g                         # MomentumOptimizer, use_nesterov=True:
+                w[k] -= lr * g + lr * momentum * accum[k]                  #   var -= lr * grad + lr * momentum * accum
+        out.append((float(loss.detach()), float(gn), {k: w[k].detach().numpy().copy() for k in names}))
+    return out
+
+
+@pytest.mark.parametrize("blocks,lr", [(1, 0.05), (2, 0.2)])
+def test_train_step_matches_float64_restatement(blocks, lr):
+    from cchess_zero_amd.net import PolicyValueModule
+    from cchess_zero_amd.train import Trainer
+    m = PolicyValueModule(blocks, seed=4)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():   # non-zero biases: the L2 term covers them too
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+    w0 = m.export_tf_layout()
+    batches = [_batch(12, 3), _batch(12, 4)]
+    ref = _run_restatement(w0, batches, lr, blocks)
+    tr = Trainer(m)
+    prev = w0
+    for step, (x, pi, z) in enumerate(batches):
+        acc, loss, gs = tr.train_step(x, pi, z, lr)
+        rl, rgn, rw = ref[step]
+        assert gs == step + 1 and 0.0 <= acc <= 1.0
+        assert abs(loss - rl) <= 2e-5 * abs(rl), (step, loss, rl)
+        assert abs(tr.last_grad_norm - rgn) <= 2e-4 * rgn, (step, tr.last_grad_norm, rgn)
+        now = m.export_tf_layout()
+        for k in rw:
+            d_got = now[k].astype(np.float64) - prev[k].astype(np.float64)
+            d_ref = rw[k] - (ref[step - 1][2][k] if step else np.asarray(w0[k], np.float64))
+            scale = np.abs(d_ref).max()
+            # conv biases in front of a batch-statistic BatchNorm have an analytically ZERO data gradient (the mean is
+            # subtracted again): in fp32 what remains is cancellation noise, hence the small absolute term
+            assert np.abs(d_got - d_ref).max() <= 2e-3 * scale + 5e-6 * lr, (step, k, np.abs(d_got - d_ref).max(), scale)
+        prev = now
+    # the moving statistics are never touched (quirk Q5: the reference never runs the update ops)
+    for k, v in m.export_tf_layout().items():
+        if k.startswith("bn"):
+            assert np.array_equal(v, w0[k])
+
+
+def test_clip_and_nan_check():
+    from cchess_zero_amd.net import PolicyValueModule
+    from cchess_zero_amd.train import Trainer
+    m = PolicyValueModule(1, seed=0)
+    tr = Trainer(m, global_norm=0.01)       # force clipping: the applied update has global norm 0.01 * lr
+    w_before = torch.cat([p.detach().reshape(-1).clone() for p in m.parameters()])
+    x, pi, z = _batch(6, 9)
+    tr.train_step(x, pi, z, 1.0)
+    w_after = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert tr.last_grad_norm > 0.01
+    # first Nesterov step from zero slots: delta = lr * (1 + momentum) * clipped gradient
+    assert abs(float((w_after - w_before).norm()) - 0.01 * 1.9) < 1e-4
+    bad = z.copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(FloatingPointError):
+        tr.train_step(x, pi, bad, 0.1)
+
+
+class _CpuNet:
+    """policy_value_network's training surface on a CPU module (the product class needs a HIP device)."""
+
+    def __init__(self, blocks, save_dir):
+        from cchess_zero_amd.net import PolicyValueModule
+        from cchess_zero_amd.train import Trainer
+        self.module = PolicyValueModule(blocks, seed=0)
+        self.trainer = Trainer(self.module)
+        self.save_dir = save_dir
+        self.saved = []
+
+    @property
+    def global_step(self):
+        return self.trainer.global_step
+
+    def forward(self, positions):
+        with torch.no_grad():
+            lg, v = self.module(torch.as_tensor(np.asarray(positions, np.float32)).permute(0, 3, 1, 2))
+        return lg.numpy(), v.numpy()
+
+    def train_step(self, *a):
+        return self.trainer.train_step(*a)
+
+    def save(self, step):
+        self.saved.append(int(step))
+
+
+def _update_worker(rank, world, port, q, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cchess_zero_amd.train import policy_update
+    net = _CpuNet(1, tmp)
+    x, pi, z = _batch(48, 21)          # every rank holds the same gathered buffer
+    buf = [(x[i], pi[i], float(z[i, 0])) for i in range(len(x))]
+    lrm, infos = 1.0, []
+    # the second update uses a large learning rate: the KL estimate crosses 4 * kl_targ and the early stop must fire on
+    # the same epoch everywhere
+    for lr in (0.01, 0.5, 0.01):
+        lrm, info = policy_update(net, buf, 16, 5, lr, lrm, 0.025, seed=5, log=lambda *a: None)
+        infos.append((info["steps"], round(info["kl"], 12), lrm))
+    flat = torch.cat([p.detach().reshape(-1) for p in net.module.parameters()])
+    q.put((rank, infos, flat.numpy().tobytes(), net.saved, net.global_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_policy_update_is_rank_consistent_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_update_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, i0, w0, s0, g0), (r1, i1, w1, s1, g1) = res
+    assert i0 == i1, (i0, i1)                       # same number of steps, same all-reduced KL, same lr_multiplier
+    assert w0 == w1                                 # replicas bit-identical after the updates
+    assert g0 == g1 == sum(st for st, _, _ in i0)
+    assert len(s0) == 3 and s1 == []                # only rank 0 writes checkpoints
+    assert any(st < 5 for st, _, _ in i0), "the large-learning-rate update should stop early: %r" % (i0,)
