@@ -90,9 +90,17 @@ def synth_positions(rules, G, seed, max_ply=80):
 def _cpu_worker(args):
     """One worker process: `games` trees searched in lock-step by the C oracle (oracle/, the pinned restatement of the
     reference's search), leaves evaluated in one batch by the fp32 torch module on `threads` CPU threads."""
-    idx, games, threads, blocks, seconds = args
+    idx, games, threads, blocks, seconds, first_core = args
     os.environ["HIP_VISIBLE_DEVICES"] = ""
     os.environ["CUDA_VISIBLE_DEVICES"] = ""
+    # pin the worker (and the OpenMP threads it creates later) to its own cores: without it every worker's OpenMP pool
+    # ends up on the same cores (measured: 16 workers x 16 threads gave 2.2x ONE core)
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        mine = avail[first_core:first_core + int(threads)] or avail[:int(threads)]
+        os.sched_setaffinity(0, mine)
+    except Exception:
+        pass
     import torch as T
     T.set_num_threads(int(threads))
     from oracle import oracle as O
@@ -139,14 +147,14 @@ def cpu_baseline(blocks, seconds_target=12.0):
     out = {"unit": "sims/s", "kind": "port", "reference_python": REFERENCE_PYTHON}
     try:
         with ctx.Pool(1) as pool:
-            s, dt, steps = pool.map(_cpu_worker, [(0, 8, 1, blocks, seconds_target * 0.5)])[0]
+            s, dt, steps = pool.map(_cpu_worker, [(0, 8, 1, blocks, seconds_target * 0.5, 0)])[0]
         out["single_core"] = {"value": s / dt, "cores": 1,
                               "sample": "8 games x %d lock-step simulations, 1 thread, %.1f s" % (steps, dt)}
         tpw = 16 if cores >= 32 else max(1, cores // 2)     # threads per worker process
         workers = max(1, cores // tpw)
         games = 256
         with ctx.Pool(workers) as pool:
-            res = pool.map(_cpu_worker, [(i + 1, games, tpw, blocks, seconds_target) for i in range(workers)])
+            res = pool.map(_cpu_worker, [(i + 1, games, tpw, blocks, seconds_target, i * tpw) for i in range(workers)])
         out["value"] = float(sum(s / dt for s, dt, _ in res))
         out["cores"] = workers * tpw
         out["sample"] = ("%d worker processes x %d threads, each %d games x ~%d lock-step simulations: C oracle search + fp32 "
@@ -307,15 +315,17 @@ def main():
         eng.compact = compact
 
         def run_plies(n, timed):
-            for _ in range(n):
+            for i in range(n):
                 sp.step_ply()
                 if timed and args.timed_gather and dist_on:
+                    rec = sp.drain_device()                       # device rows of the games that just finished (syncs on the cursor)
                     t1 = time.perf_counter()
-                    rec = sp.drain_device()                       # device rows of the games that just finished
                     allrec, counts = parallel.gather_records_device(rec if cdev.type == "cuda" else rec.cpu())
                     gather_stats["gathers"] += 1
-                    gather_stats["records"] += int(counts.sum().item())
+                    gather_stats["records"] += int(counts.sum().item())   # the host looks at the result: the collective is done
                     gather_stats["seconds"] += time.perf_counter() - t1
+                elif i % 4 == 3:   # the consumer of the records: every 4 plies the finished games leave the device
+                    gather_stats["records"] += len(sp.drain())
         run_plies(args.warmup, False)
     else:
         eng.reset(boards, side, rr)
@@ -441,10 +451,20 @@ def main():
     b_sel = G * (mean_depth * mean_L * 20.0 + 96.0 + 2.0 * mean_L + plane_b)
     b_exp = G * ((1080.0 if fused_fc else 2086.0 * 4) + 28.0 * mean_L + 12.0 * mean_depth)
     tree_roof = None
+    tree_traffic, tree_traffic_src = None, None
+    try:   # committed counter traffic of the same launch shapes (tools/profile_round.sh -> tools/summarize_profile.py)
+        tt = json.load(open(os.path.join(ROOT, "profiles", "pmc_tree_traffic.json")))
+        if {k: tt["config"].get(k) for k in ("B", "res_block_nums", "dtype")} == {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype} and fused_fc and not compact:
+            kk = tt["kernels"]
+            tree_traffic = sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in ("k_select", "k_expand_backup") if n in kk)
+            tree_traffic_src = "profiles/pmc_tree_traffic.json (FETCH_SIZE x2 + WRITE_SIZE of k_select + k_expand_backup, per step)"
+    except Exception:
+        pass
     if ev and K == 1:
         ach = (b_sel + b_exp) / ((sel_us + exp_us) * 1e-6) / 1e9
         tree_roof = {"bound": "hbm", "kernel": "k_select + k_expand_backup%s (tree + rules side of a step)" % ("<FC>" if fused_fc else ""),
-                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tree_traffic,
+                     "traffic_source": tree_traffic_src,
                      "us_select": sel_us, "us_expand_backup": exp_us, "algorithmic_bytes_select": b_sel, "algorithmic_bytes_expand": b_exp,
                      "select_GBps": b_sel / (sel_us * 1e-6) / 1e9, "expand_GBps": b_exp / (exp_us * 1e-6) / 1e9,
                      "mean_leaf_depth": mean_depth, "mean_children": mean_L,

@@ -46,6 +46,7 @@ _SIGS = {
     "cz_set_batch_count": (C.c_int, [C.c_void_p, _vp]),
     "cz_search_eval_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "cz_search_set_width": (C.c_int, [C.c_void_p, C.c_int]),
+    "cz_search_set_sim_target": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_select_k": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup_k": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int]),
     "cz_search_root_stats": (C.c_int, [C.c_void_p, _u16p, _i32p, _f32p, _f32p, _f32p, _u16p]),

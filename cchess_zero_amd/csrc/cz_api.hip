@@ -47,6 +47,8 @@ void carve_trees(Carver &c, CzTrees &t, size_t G, size_t words) {
     t.pend_side = c.take<uint8_t>(G);
     t.pend_nmoves = c.take<uint16_t>(G);
     t.pend_moves = c.take<uint16_t>(G * CZD_MAXMOVES);
+    t.pend_depth = c.take<int32_t>(G);
+    t.pend_path = c.take<int32_t>(G * CZ_PATH_MAX);
     t.slot_of = c.take<int32_t>(G);
     t.evcnt = c.take<int32_t>(2);
     t.evtotal = c.take<unsigned long long>(2);
@@ -226,6 +228,12 @@ int cz_search_set_width(cz_ctx *c, int width) {
     if (c->pend_block) (void)hipFree(c->pend_block);
     c->pend_block = blk;
     c->width = width;
+    return CZ_OK;
+}
+
+int cz_search_set_sim_target(cz_ctx *c, int target) {
+    CZ_REQUIRE(c && target >= 0, "cz_search_set_sim_target: null ctx / negative target");
+    c->sim_target = target;
     return CZ_OK;
 }
 

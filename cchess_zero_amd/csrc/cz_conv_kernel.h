@@ -29,6 +29,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CZ_CONV_WAVES_PER_EU
 #define CZ_CONV_WAVES_PER_EU 2
 #endif
+#define CZ_STR_(x) #x
+#define CZ_STR(x) CZ_STR_(x)
 // ablation switches for tools/conv_ubench.hip (all 0 in the product build)
 #ifndef CZ_ABL
 #define CZ_ABL 0
@@ -821,6 +823,15 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         }
 
     int g = 0;
+#if defined(CZ_T8_PRIO)   // experiment (tools/tower_ubench): static priority for the second-dispatched half of the waves
+    if (wave_u >= P) asm volatile("s_setprio 1");
+#endif
+#if defined(CZ_T8_PAD)    // experiment: shift the instruction stream of the hand-scheduled loop by CZ_T8_PAD * 4 bytes
+    asm volatile(".rept " CZ_STR(CZ_T8_PAD) "\n\ts_nop 0\n\t.endr" ::: "memory");
+#endif
+#if defined(CZ_T8_ALIGN)  // experiment: align the layer loop
+    asm volatile(".p2align " CZ_STR(CZ_T8_ALIGN) ::: "memory");
+#endif
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
         f32x16 acc[CV_RT][CV_CT];

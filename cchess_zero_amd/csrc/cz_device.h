@@ -162,38 +162,89 @@ __device__ __forceinline__ int czd_gen_piece(int c, int sq, int side, const CzdB
     return n;
 }
 
-// Ordered pseudo-legal move list of one position (GameBoard.get_legal_moves, main.py:743-1109).
-//   b     LDS board [96]; stage LDS [64*18] u16; out LDS [128] u16.
-// Returns the move count (wave-uniform), or -1 on overflow / unlabeled move.
-// Scan order = ascending sq (y outer, x inner, main.py:754-755): lanes take squares 0..63 then
-// 64..89; a wave prefix sum of the per-piece counts places every piece's run of (src, dst) pairs; the pairs are
-// turned into labels afterwards, two coalesced LUT loads per lane instead of one load per emitted move inside
-// the divergent generator.
-__device__ __forceinline__ int czd_wave_movegen(const uint8_t *b, int side, const int16_t *lut,
-                                                uint16_t *stage, uint16_t *out, int lane) {
-    bool err = false;
-    int base = 0;
-    uint16_t *st = stage + lane * CZD_STAGE_STRIDE;
-    const CzdBoardSets S = czd_board_sets(b, side, lane);
-#pragma unroll 1
-    for (int r = 0; r < 2; ++r) {
-        const int sq = lane + 64 * r;
-        int n = 0;
-        if (sq < CZD_NSQ) n = czd_gen_piece(b[sq], sq, side, S, st);
-        int total;
-        const int off = base + czd_wave_excl_scan(n, lane, &total);
-        if (off + n > CZD_MAXMOVES) { err = true; n = 0; }
-        for (int k = 0; k < n; ++k) out[off + k] = st[k];  // own staging row: no cross-lane hazard
-        base += total;
-        if (base > CZD_MAXMOVES) base = CZD_MAXMOVES;
+// ---- ordered pseudo-legal move lists (GameBoard.get_legal_moves, main.py:743-1109), lane = piece ----------------------
+// A position has at most 16 pieces of the side to move, so a wave64 generates for up to FOUR positions at once: lanes
+// 16 q .. 16 q + 15 own position q, lane 16 q + s the s-th piece of the mover in scan order (ascending square = y outer,
+// x inner, main.py:754-755).  Round 1 put one SQUARE on every lane of a whole wave per position: two passes of the
+// divergent per-piece generator with two thirds of the lanes idle — the kernels were issue-bound at 0.6 G positions/s.
+//   stage A  per position (whole wave, lane = square): occupancy bit sets by ballot, the mover's piece list by
+//            popcount-rank, king squares; bit sets and piece list go through LDS to the position's 16 lanes
+//   stage B  once: lane = (position, piece) runs czd_gen_piece into its staging row
+//   stage C  16-lane segmented prefix sum of the per-piece counts (DPP row shifts: a row IS 16 lanes), runs copied to
+//            the position's output list, flying general appended (main.py:1097-1107), (src, dst) -> label through the LUT
+struct CzdGroupLds {
+    unsigned long long sets[4][8];   // occ, enemy, occT, enemyT (lo, hi)
+    uint16_t pl[4][16];              // mover's pieces: sq | code << 8
+    int16_t kings[4][2];             // square of 'K', 'k' (or -1)
+    int16_t npc[4];
+};
+
+__device__ __forceinline__ int czd_row_excl_scan16(int v, int *total, int lane) {
+    int x = v;   // inclusive scan inside each row of 16 lanes
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1, out-of-row lanes read 0
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    *total = __shfl(x, lane | 15, 64);
+    return x - v;
+}
+
+// b: LDS boards, position p at b + p * CZD_BOARD_LDS; side_of(p) its side to move; NP positions (1..4).
+// out: LDS [NP][128] u16 (labels on return); stage: LDS [64 * 18] u16; G: LDS scratch.
+// Returns, in every lane of group q, the move count of position q (-1 on overflow / unlabeled move; 0 for q >= NP).
+template <int NP, typename SideFn>
+__device__ __forceinline__ int czd_group_movegen(const uint8_t *b, SideFn side_of, const int16_t *lut, CzdGroupLds &G,
+                                                 uint16_t *stage, uint16_t *out, int lane) {
+    // ---- stage A
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint8_t *bp = b + p * CZD_BOARD_LDS;
+        const int side = side_of(p);
+        const CzdBoardSets S = czd_board_sets(bp, side, lane);
+        const int c0 = bp[lane], c1 = (lane + 64 < CZD_NSQ) ? bp[lane + 64] : 0;
+        const bool own0 = c0 != 0 && (c0 > 7) == (side != 0), own1 = c1 != 0 && (c1 > 7) == (side != 0);
+        const unsigned long long o0 = __ballot(own0), o1 = __ballot(own1);
+        const int n0 = __popcll(o0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (own0) { const int i = __popcll(o0 & below); if (i < 16) G.pl[p][i] = (uint16_t)(lane | (c0 << 8)); }
+        if (own1) { const int i = n0 + __popcll(o1 & below); if (i < 16) G.pl[p][i] = (uint16_t)((lane + 64) | (c1 << 8)); }
+        const unsigned long long K0 = __ballot(c0 == 1), K1 = __ballot(c1 == 1), k0 = __ballot(c0 == 8), k1 = __ballot(c1 == 8);
+        if (lane == 0) {
+            G.sets[p][0] = S.occ.lo; G.sets[p][1] = S.occ.hi; G.sets[p][2] = S.enemy.lo; G.sets[p][3] = S.enemy.hi;
+            G.sets[p][4] = S.occT.lo; G.sets[p][5] = S.occT.hi; G.sets[p][6] = S.enemyT.lo; G.sets[p][7] = S.enemyT.hi;
+            G.kings[p][0] = (int16_t)(K0 ? __ffsll((long long)K0) - 1 : (K1 ? 64 + __ffsll((long long)K1) - 1 : -1));
+            G.kings[p][1] = (int16_t)(k0 ? __ffsll((long long)k0) - 1 : (k1 ? 64 + __ffsll((long long)k1) - 1 : -1));
+            const int np_ = n0 + __popcll(o1);
+            G.npc[p] = (int16_t)(np_ > 16 ? -1 : np_);   // more than 16 pieces of one colour: not a Xiangqi position
+        }
     }
-    // flying general, main.py:1097-1107: kings on one file with nothing between -> mover's king captures
-    const int c0 = b[lane], c1 = (lane + 64 < CZD_NSQ) ? b[lane + 64] : 0;
-    const unsigned long long K0 = __ballot(c0 == 1), K1 = __ballot(c1 == 1);
-    const unsigned long long k0 = __ballot(c0 == 8), k1 = __ballot(c1 == 8);
-    const int Ksq = K0 ? __ffsll((long long)K0) - 1 : (K1 ? 64 + __ffsll((long long)K1) - 1 : -1);
-    const int ksq = k0 ? __ffsll((long long)k0) - 1 : (k1 ? 64 + __ffsll((long long)k1) - 1 : -1);
-    if (Ksq >= 0 && ksq >= 0 && (Ksq % 9) == (ksq % 9)) {
+    __syncthreads();
+    // ---- stage B
+    const int q = lane >> 4, s = lane & 15;
+    const bool live = q < NP;
+    const int qq = live ? q : 0;
+    const int side = live ? side_of(qq) : 0;
+    const int npc = G.npc[qq];
+    bool err = live && npc < 0;
+    CzdBoardSets S;
+    S.occ.lo = G.sets[qq][0]; S.occ.hi = G.sets[qq][1]; S.enemy.lo = G.sets[qq][2]; S.enemy.hi = G.sets[qq][3];
+    S.occT.lo = G.sets[qq][4]; S.occT.hi = G.sets[qq][5]; S.enemyT.lo = G.sets[qq][6]; S.enemyT.hi = G.sets[qq][7];
+    uint16_t *st = stage + lane * CZD_STAGE_STRIDE;
+    int n = 0;
+    if (live && s < npc) {
+        const int pc = G.pl[qq][s];
+        n = czd_gen_piece(pc >> 8, pc & 0xFF, side, S, st);
+    }
+    // ---- stage C
+    int total;
+    const int off = czd_row_excl_scan16(n, &total, lane);
+    uint16_t *o = out + qq * CZD_MAXMOVES;
+    if (off + n > CZD_MAXMOVES) { err = true; n = 0; }
+    for (int k = 0; k < n; ++k) o[off + k] = st[k];   // own staging row: no cross-lane hazard
+    int base = total > CZD_MAXMOVES ? CZD_MAXMOVES : total;
+    // flying general, main.py:1097-1107: kings on one file with nothing between -> the mover's king captures
+    const int Ksq = G.kings[qq][0], ksq = G.kings[qq][1];
+    if (live && Ksq >= 0 && ksq >= 0 && (Ksq % 9) == (ksq % 9)) {
         // the reference walks from the red king towards higher ranks (main.py:1100-1104)
         const int fx = Ksq % 9, y0 = Ksq / 9, y1 = ksq / 9;
         const unsigned col = czd_bits(S.occT, fx * 10) & 0x3FFu;
@@ -201,31 +252,30 @@ __device__ __forceinline__ int czd_wave_movegen(const uint8_t *b, int side, cons
         if ((col & between) == 0u) {
             const int src = side ? ksq : Ksq, dst = side ? Ksq : ksq;
             if (base >= CZD_MAXMOVES) err = true;
-            else { if (lane == 0) out[base] = (uint16_t)(src | (dst << 8)); base += 1; }
+            else { if (s == 0) o[base] = (uint16_t)(src | (dst << 8)); base += 1; }
         }
     }
     __syncthreads();
-    // (src, dst) -> label (label2i, main.py:217)
-    uint16_t lab[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = lane + 64 * r;
-        lab[r] = 0;
-        if (i < base) {
-            const int sd = out[i];
+    // (src, dst) -> label (label2i, main.py:217); every entry is read and rewritten by the same lane
+    if (live)
+        for (int i = s; i < base; i += 16) {
+            const int sd = o[i];
             const int l = lut[(sd & 0xFF) * CZD_NSQ + (sd >> 8)];
-            if (l < 0) err = true; else lab[r] = (uint16_t)l;
+            if (l < 0) err = true; else o[i] = (uint16_t)l;
         }
-    }
+    // an error anywhere in the group spoils the group
+    const unsigned long long em = __ballot(err);
+    const bool gerr = ((em >> (lane & 48)) & 0xFFFFull) != 0ull;
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = lane + 64 * r;
-        if (i < base) out[i] = lab[r];
-    }
-    const bool any_err = __ballot(err) != 0ull;
-    __syncthreads();
-    return any_err ? -1 : base;
+    return live ? (gerr ? -1 : base) : 0;
+}
+
+// One position per wave (the search kernels: one wave = one tree): group 0 does the work.
+//   b LDS board [96]; stage LDS [64*18] u16; out LDS [128] u16.  Returns the move count (wave-uniform) or -1.
+__device__ __forceinline__ int czd_wave_movegen(const uint8_t *b, int side, const int16_t *lut, CzdGroupLds &G,
+                                                uint16_t *stage, uint16_t *out, int lane) {
+    const int n = czd_group_movegen<1>(b, [side](int) { return side; }, lut, G, stage, out, lane);
+    return __shfl(n, 0, 64);
 }
 
 // MCTS_tree.generate_inputs (main.py:531-533): try_flip (:560-574) for black — reverse the rank

@@ -33,6 +33,8 @@ struct CzHostTables {
 };
 const CzHostTables &cz_host_tables();
 
+#define CZ_PATH_MAX 32   // deeper paths fall back to the parent walk
+
 // ---- tree storage: structure-of-arrays, one fixed-capacity pool per tree -----------------------
 // A node is the edge into it plus its expansion record (the reference's leaf_node, main.py:93-103,
 // minus the eagerly materialised state string, quirk Q8).  Children of a node are contiguous, so a
@@ -75,6 +77,10 @@ struct CzTrees {
     float *pend_value;
     uint8_t *pend_side;
     uint16_t *pend_nmoves, *pend_moves;  // [max_games][128]
+    // the selected path of the pending simulation (width 1): node index per level below the root, so that the backup
+    // updates all levels in parallel instead of chasing parent pointers (one dependent round trip per level)
+    int32_t *pend_depth;              // [max_games]
+    int32_t *pend_path;               // [max_games][CZ_PATH_MAX]
     // compact evaluation batches (cz_search_select_compact): row of the step's leaf in planes / z / value, or -1
     int32_t *slot_of;                 // [max_games]
     int32_t *evcnt;                   // [2] rows handed out this step / next step (ping-pong, zeroed one step ahead)
@@ -93,6 +99,7 @@ struct cz_ctx {
     bool conv_attr_set, tower_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1
+    int sim_target;    // cz_search_set_sim_target: completed simulations per tree a k > 1 search stops at (0: no limit)
     int step_parity;   // which evcnt entry the current compact step uses
     const int32_t *batch_count;  // cz_set_batch_count: device row count bounding the net launches, or NULL
     CzSelfplay sp;     // cz_selfplay_begin

@@ -1,6 +1,5 @@
-// cz_rules.hip — stand-alone rules kernels K1 (move generation), K2 (make move + hash + flags),
-// K3 (input planes).  One wave64 workgroup per position; boards are staged in LDS with one
-// coalesced 90-byte read, results leave with coalesced stores.  These are HBM/issue-bound byte
+// cz_rules.hip — stand-alone rules kernels K1 (move generation: four positions per wave64), K2 (make move + hash +
+// flags), K3 (input planes: one wave per position).  Boards are staged in LDS, results leave with coalesced stores.  These are HBM/issue-bound byte
 // kernels: no MFMA here by design.
 #include "cz_internal.h"
 
@@ -18,30 +17,55 @@ __device__ __forceinline__ void load_board(const uint8_t *__restrict__ g, uint8_
     __syncthreads();
 }
 
+// K1: FOUR positions per wave64 (czd_group_movegen: lane = (position, piece of the side to move)); boards come in with
+// 2-byte loads (the ABI only promises byte alignment), the ordered lists leave as one 16-byte store per lane.
 __global__ __launch_bounds__(64) void k_movegen(CzTables tab, const uint8_t *__restrict__ boards,
                                                 const uint8_t *__restrict__ side, int G,
                                                 uint16_t *__restrict__ moves, uint16_t *__restrict__ count,
                                                 uint32_t *__restrict__ mask) {
-    __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t b[4 * CZD_BOARD_LDS];
     __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
-    __shared__ uint16_t out[CZD_MAXMOVES];
-    __shared__ uint32_t m[CZ_MASK_WORDS + 2];
-    const int lane = threadIdx.x;
-    for (int g = blockIdx.x; g < G; g += gridDim.x) {
-        load_board(boards + (size_t)g * CZ_NSQ, b, lane);
-        const int sd = side[g] ? 1 : 0;
-        const int n = czd_wave_movegen(b, sd, tab.lut, stage, out, lane);
+    __shared__ __attribute__((aligned(16))) uint16_t out[4 * CZD_MAXMOVES];
+    __shared__ CzdGroupLds GL;
+    __shared__ uint32_t m[4 * (CZ_MASK_WORDS + 2)];
+    __shared__ uint8_t sd[4];
+    const int lane = threadIdx.x, q = lane >> 4, s = lane & 15;
+    const int ngroups = (G + 3) >> 2;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int g0 = grp * 4;
+        const int np = min(4, G - g0);
+        for (int j = lane; j < 4 * (CZD_BOARD_LDS / 2); j += 64) {
+            const int p = j / (CZD_BOARD_LDS / 2), w = j - p * (CZD_BOARD_LDS / 2);
+            uint16_t v = 0;
+            if (p < np && w < CZ_NSQ / 2) {
+                const uint8_t *src = boards + (size_t)(g0 + p) * CZ_NSQ + 2 * w;
+                v = (uint16_t)(src[0] | (src[1] << 8));
+            }
+            reinterpret_cast<uint16_t *>(b)[j] = v;
+        }
+        if (lane < 4) sd[lane] = (lane < np && side[g0 + lane]) ? 1 : 0;
+        __syncthreads();
+        const int n = czd_group_movegen<4>(b, [&](int p) { return (int)sd[p]; }, tab.lut, GL, stage, out, lane);
         const int nn = n < 0 ? 0 : n;
-        if (lane == 0) count[g] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
+        if (s == 0 && q < np) count[g0 + q] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
         if (moves) {
-            for (int i = lane; i < CZD_MAXMOVES; i += 64) moves[(size_t)g * CZD_MAXMOVES + i] = i < nn ? out[i] : (uint16_t)0xFFFF;
+            for (int i = s; i < CZD_MAXMOVES; i += 16)
+                if (i >= nn) out[q * CZD_MAXMOVES + i] = (uint16_t)0xFFFF;
+            __syncthreads();
+            if (q < np) reinterpret_cast<uint4 *>(moves + (size_t)g0 * CZD_MAXMOVES)[lane] = reinterpret_cast<const uint4 *>(out)[lane];
         }
         if (mask) {
-            for (int i = lane; i < CZ_MASK_WORDS; i += 64) m[i] = 0;
+            for (int i = lane; i < 4 * (CZ_MASK_WORDS + 2); i += 64) m[i] = 0;
             __syncthreads();
-            for (int i = lane; i < nn; i += 64) atomicOr(&m[out[i] >> 5], 1u << (out[i] & 31));
+            for (int i = s; i < nn; i += 16) {
+                const int l = out[q * CZD_MAXMOVES + i];
+                atomicOr(&m[q * (CZ_MASK_WORDS + 2) + (l >> 5)], 1u << (l & 31));
+            }
             __syncthreads();
-            for (int i = lane; i < CZ_MASK_WORDS; i += 64) mask[(size_t)g * CZ_MASK_WORDS + i] = m[i];
+            for (int i = lane; i < np * CZ_MASK_WORDS; i += 64) {
+                const int p = i / CZ_MASK_WORDS, w = i - p * CZ_MASK_WORDS;
+                mask[(size_t)g0 * CZ_MASK_WORDS + i] = m[p * (CZ_MASK_WORDS + 2) + w];
+            }
         }
         __syncthreads();
     }
@@ -107,7 +131,8 @@ inline int grid_for(int G) { return G < 65536 ? G : 65536; }
 
 int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves, uint16_t *count, uint32_t *mask) {
     if (G == 0) return CZ_OK;
-    hipLaunchKernelGGL(k_movegen, dim3(grid_for(G)), dim3(64), 0, c->stream, c->tab, boards, side, G, moves, count, mask);
+    if (moves && (reinterpret_cast<uintptr_t>(moves) & 15u)) { cz_set_error("cz_movegen: moves must be 16-byte aligned"); return CZ_EINVAL; }
+    hipLaunchKernelGGL(k_movegen, dim3(grid_for((G + 3) / 4)), dim3(64), 0, c->stream, c->tab, boards, side, G, moves, count, mask);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

@@ -44,13 +44,16 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
 // atomic counter (t.evcnt[parity]); t.slot_of[g] records the row (or -1), the other counter is zeroed for the next
 // step.  Terminal / drawn / parked trees then cost the net nothing (they are 9 % of the simulations on the bench
 // workload), and which row a tree gets does not matter: every row of the net is computed independently.
+// amdgpu_num_sgpr(80): 8192 trees are exactly 32 waves per CU; at 82 SGPRs (what hipcc picked) only 7 waves fit a SIMD
+// (MI355X_MICROARCH.md: floor(800 / (ceil(sgpr / 16) * 16 + 16))), and the 4 left-over waves per CU cost a second pass.
 template <typename T, bool COMPACT>
-__global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, int mode,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_select(CzTrees t, CzTables tab, int G, int mode,
                                                const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                                T one, uint8_t *__restrict__ needs_eval, int parity) {
     __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
     __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
     __shared__ uint16_t mv[CZD_MAXMOVES];
+    __shared__ CzdGroupLds GL;
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     T *pl = planes ? planes + (size_t)g * 90 * C : nullptr;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
                 __syncthreads();
                 side ^= 1;                  // main.py:392
                 rr = cap ? 0 : rr + 1;      // main.py:393-396
+                if (lane == 0 && depth < CZ_PATH_MAX) t.pend_path[(size_t)g * CZ_PATH_MAX + depth] = c;
                 ++depth;
                 if (cap == 1) Kmiss = true;
                 if (cap == 8) kmiss = true;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
     }
     int nmoves = 0;
     if (kind == 1 || kind == 3) {
-        nmoves = czd_wave_movegen(b, side, tab.lut, stage, mv, lane);  // main.py:374 / :483
+        nmoves = czd_wave_movegen(b, side, tab.lut, GL, stage, mv, lane);  // main.py:374 / :483
         if (nmoves < 0) { if (lane == 0) t.status[g] |= CZ_ST_MOVE_OVERFLOW; kind = 0; nmoves = 0; }
     }
     if constexpr (COMPACT) {
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(64) void k_select(CzTrees t, CzTables tab, int G, i
     if (lane == 0) {
         t.pend_kind[g] = kind; t.pend_leaf[g] = leaf; t.pend_value[g] = pend;
         t.pend_side[g] = (uint8_t)side; t.pend_nmoves[g] = (uint16_t)nmoves;
+        t.pend_depth[g] = depth;
         if (!parked) t.last_depth[g] = depth;
         if (needs_eval) needs_eval[g] = (kind == 1 || kind == 3) ? 1 : 0;
     }
@@ -242,36 +247,59 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
                 float xr[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) xr[k] = xin[l16 * 12 + k];
+                // two groups of four moves per iteration: the weight rows of both are requested before either is reduced
+                // (each row fetch is a dependent chain label -> unflip -> 3 x 16 bytes of the row)
 #pragma unroll 1
-                for (int base = 0; base < n; base += 4) {
-                    const int i = base + grp;
-                    int idx = 0;
-                    float sum = 0.f;
-                    if (i < n) {
-                        const int l = t.pend_moves[(size_t)g * CZD_MAXMOVES + i];
-                        idx = sd ? tab.unflip[l] : l;
-                        if (l16 < 15) {
-                            const float4 *w4 = reinterpret_cast<const float4 *>(fcw + (size_t)idx * 180 + l16 * 12);
-                            const float4 a = w4[0], bq = w4[1], cq = w4[2];
-                            sum = a.x * xr[0];
-                            sum = sum + a.y * xr[1];
-                            sum = sum + a.z * xr[2];
-                            sum = sum + a.w * xr[3];
-                            sum = sum + bq.x * xr[4];
-                            sum = sum + bq.y * xr[5];
-                            sum = sum + bq.z * xr[6];
-                            sum = sum + bq.w * xr[7];
-                            sum = sum + cq.x * xr[8];
-                            sum = sum + cq.y * xr[9];
-                            sum = sum + cq.z * xr[10];
-                            sum = sum + cq.w * xr[11];
+                for (int base = 0; base < n; base += 8) {
+                    int idx[2] = {0, 0};
+                    float sum[2] = {0.f, 0.f};
+                    float4 wa[2], wb[2], wc4[2];
+                    bool on[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = base + 4 * h + grp;
+                        on[h] = i < n;
+                        if (on[h]) {
+                            const int l = t.pend_moves[(size_t)g * CZD_MAXMOVES + i];
+                            idx[h] = sd ? tab.unflip[l] : l;
                         }
                     }
-                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x140, 0xF, 0xF, false));  // row_mirror
-                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xF, 0xF, false));  // row_half_mirror
-                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x1B, 0xF, 0xF, false));   // quad_perm [3,2,1,0]
-                    sum = sum + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-                    if (i < n && l16 == 0) pr[i] = sum + fcb[idx];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        wa[h] = wb[h] = wc4[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (on[h] && l16 < 15) {
+                            const float4 *w4 = reinterpret_cast<const float4 *>(fcw + (size_t)idx[h] * 180 + l16 * 12);
+                            wa[h] = w4[0]; wb[h] = w4[1]; wc4[h] = w4[2];
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (on[h] && l16 < 15) {
+                            const float4 a = wa[h], bq = wb[h], cq = wc4[h];
+                            float sm = a.x * xr[0];
+                            sm = sm + a.y * xr[1];
+                            sm = sm + a.z * xr[2];
+                            sm = sm + a.w * xr[3];
+                            sm = sm + bq.x * xr[4];
+                            sm = sm + bq.y * xr[5];
+                            sm = sm + bq.z * xr[6];
+                            sm = sm + bq.w * xr[7];
+                            sm = sm + cq.x * xr[8];
+                            sm = sm + cq.y * xr[9];
+                            sm = sm + cq.z * xr[10];
+                            sm = sm + cq.w * xr[11];
+                            sum[h] = sm;
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float sm = sum[h];
+                        sm = sm + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sm), 0x140, 0xF, 0xF, false));  // row_mirror
+                        sm = sm + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sm), 0x141, 0xF, 0xF, false));  // row_half_mirror
+                        sm = sm + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sm), 0x1B, 0xF, 0xF, false));   // quad_perm [3,2,1,0]
+                        sm = sm + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sm), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                        if (on[h] && l16 == 0) pr[base + 4 * h + grp] = sm + fcb[idx[h]];
+                    }
                 }
             } else {
                 const T *lg = logits + (size_t)g * CZ_NLABELS;
@@ -312,9 +340,24 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
     } else {
         val = t.pend_value[g];
     }
-    if (lane == 0) {
-        // back_up_value on every selected node of the path, main.py:189-194,426-435; the root is
-        // never updated (quirk Q2).  (W + -3) + 3 reproduces the float32 rounding of the virtual loss.
+    // back_up_value on every selected node of the path, main.py:189-194,426-435; the root is never updated (quirk Q2).
+    // (W + -3) + 3 reproduces the float32 rounding of the virtual loss.  The value alternates in sign level by level and
+    // the levels are independent, so lane d updates the node k_select recorded for level d: one memory round trip for
+    // the whole path instead of one per level along the parent pointers.
+    const int depth = t.pend_depth[g];
+    if (depth <= CZ_PATH_MAX) {
+        if (lane < depth) {
+            const int n = t.pend_path[(size_t)g * CZ_PATH_MAX + lane];
+            const float x = ((depth - 1 - lane) & 1) ? val * -1.0f : val;
+            float w = v.W[n];
+            w = w + -3.0f;
+            w = w + 3.0f;
+            const int cnt = v.N[n] + 1;
+            w = w + x;
+            v.N[n] = cnt; v.W[n] = w; v.Q[n] = w / (float)cnt;
+        }
+        if (lane == 0) { t.sims[g] += 1; t.pend_kind[g] = 0; }
+    } else if (lane == 0) {
         const int root = t.root_node[g];
         int n = leaf;
         float x = val;
@@ -346,12 +389,13 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
 // the reference for K > 1 depends on wall-clock sleeps, so K > 1 is checked against the C oracle's restatement of
 // THIS schedule and through invariants, not against reference golden trees.
 template <typename T>
-__global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G, int mode, int K,
+__global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G, int mode, int K, int sim_target,
                                                  const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                                  T one, uint8_t *__restrict__ needs_eval) {
     __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
     __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
     __shared__ uint16_t mv[CZD_MAXMOVES];
+    __shared__ CzdGroupLds GL;
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     const bool parked = (active && !active[g]) || (t.status[g] & ~CZ_ST_BAD_ADVANCE) != 0;
@@ -359,7 +403,13 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
     const int root = t.root_node[g];
     bool stop = parked;
     int done_now = 0;   // simulations completed inside this launch (terminal / draw)
+    // cz_search_set_sim_target: a tree issues no descent beyond its budget of completed simulations (every descent
+    // issued here completes: inside this launch or in the following expand_backup_k), so a search ends with EXACTLY the
+    // requested number of playouts per tree, as MCTS_tree.main does (main.py:489-493)
+    const int budget = sim_target > 0 ? sim_target - t.sims[g] : 0x7FFFFFFF;
+    int issued = 0;
     for (int j = 0; j < K; ++j) {
+        if (mode != 0 && issued >= budget) stop = true;
         const size_t slot = (size_t)g * K + j;
         T *pl = planes ? planes + slot * 90 * C : nullptr;
         int kind = 0, leaf = 0, depth = 0, side = t.root_side[g];
@@ -382,7 +432,7 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
                     const int cb = v.child_begin[node];
                     bool abandon = false;
                     if (cb == -1) {   // not expanded: this descent owns the expansion
-                        kind = 1; leaf = node;
+                        kind = 1; leaf = node; ++issued;
                         if (lane == 0) v.child_begin[node] = -2;
                         break;
                     }
@@ -454,6 +504,7 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
                         __threadfence_block();
                         __syncthreads();
                         ++done_now;
+                        ++issued;
                         kind = 0;
                         break;
                     }
@@ -463,7 +514,7 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
         }
         int nmoves = 0;
         if (kind == 1 || kind == 3) {
-            nmoves = czd_wave_movegen(b, side, tab.lut, stage, mv, lane);
+            nmoves = czd_wave_movegen(b, side, tab.lut, GL, stage, mv, lane);
             if (nmoves < 0) {   // > 128 moves / unlabeled move: report, give the node and the virtual loss back
                 if (lane == 0) {
                     t.status[g] |= CZ_ST_MOVE_OVERFLOW;
@@ -472,6 +523,7 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
                         for (int n = leaf; n != root; n = v.parent[n]) { v.N[n] -= 3; v.W[n] = v.W[n] + 3.0f; }
                     }
                 }
+                if (kind == 1) --issued;
                 kind = 0; nmoves = 0; stop = true;
             }
         }
@@ -786,9 +838,9 @@ int cz_search_root_state(cz_ctx *c, uint8_t *boards, uint8_t *side, int32_t *rr)
 
 int czk_search_select_k(cz_ctx *c, int mode, int K, const uint8_t *active, void *planes, int dtype, int C, uint8_t *needs_eval) {
     if (dtype == CZ_F32)
-        hipLaunchKernelGGL(k_select_k<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, active, (float *)planes, C, 1.0f, needs_eval);
+        hipLaunchKernelGGL(k_select_k<float>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, c->sim_target, active, (float *)planes, C, 1.0f, needs_eval);
     else
-        hipLaunchKernelGGL(k_select_k<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, active, (uint16_t *)planes, C, (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80), needs_eval);
+        hipLaunchKernelGGL(k_select_k<uint16_t>, dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, K, c->sim_target, active, (uint16_t *)planes, C, (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80), needs_eval);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

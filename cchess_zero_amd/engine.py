@@ -252,8 +252,41 @@ class SearchEngine:
         self.expand_backup(logits, value)
 
     def search(self, forward, playouts, active=None):
-        """MCTS_tree.main (main.py:473-493) for all trees: expand unexpanded roots, then `playouts` simulations
-        (with width k: ceil(playouts / k) lock-step batches of up to k simulations per tree)."""
+        """MCTS_tree.main (main.py:473-493) for all trees: expand unexpanded roots, then EXACTLY `playouts` simulations
+        per (active, unparked) tree.  With width k > 1 up to k simulations are in flight per tree and step; a descent
+        that runs into a pending expansion is abandoned (see k_select_k), so a step can complete fewer than k — the
+        per-tree budget (cz_search_set_sim_target) and a few extra steps make up for it.  Returns the number of steps."""
+        playouts = int(playouts)
         self.step(forward, mode=0, active=active)
-        for _ in range((int(playouts) + self.width - 1) // self.width):
-            self.step(forward, mode=1, active=active)
+        if self.width == 1:
+            for _ in range(playouts):
+                self.step(forward, mode=1, active=active)
+            return playouts
+        base = self.status()[2].clone()      # searches may be stacked on one root: the target is relative
+        check(lib().cz_search_set_sim_target(self.ctx.h, 0), "cz_search_set_sim_target")
+        # per-tree targets differ only if `base` does; the kernel takes one number, so stacked searches on trees with
+        # different counters fall back to the unbudgeted schedule for the bulk and finish one simulation at a time
+        uniform = bool((base == base[0]).all().item())
+        target = int(base[0].item()) + playouts
+        steps = 0
+        try:
+            if uniform:
+                check(lib().cz_search_set_sim_target(self.ctx.h, target), "cz_search_set_sim_target")
+            n = (playouts + self.width - 1) // self.width
+            for _ in range(n):
+                self.step(forward, mode=1, active=active)
+            steps = n
+            if uniform:
+                act = None if active is None or isinstance(active, C.c_void_p) else torch.as_tensor(active).to(self.dev).bool()
+                for _ in range(4 * n + 8):   # the shortfall of abandoned descents, usually 1-3 steps
+                    st, _, sims, _ = self.status()
+                    live = (st & ~8) == 0
+                    if act is not None:
+                        live = live & act
+                    if not bool(((sims < target) & live).any().item()):
+                        break
+                    self.step(forward, mode=1, active=active)
+                    steps += 1
+        finally:
+            check(lib().cz_search_set_sim_target(self.ctx.h, 0), "cz_search_set_sim_target")
+        return steps

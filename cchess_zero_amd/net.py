@@ -267,8 +267,8 @@ class PolicyValueNet:
             def frag(w):
                 return w.view(66, 32, 12, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
             self.hip_pfc_hi, self.hip_pfc_lo = frag(hi), frag(lo)
-            self.hip_pfc_b = m.policy_fc.bias.float().contiguous()
-            self.pfc_w_rows = m.policy_fc.weight.float().contiguous()   # [2086,180]: rows the expansion kernel gathers
+            self.hip_pfc_b = m.policy_fc.bias.detach().float().contiguous()
+            self.pfc_w_rows = m.policy_fc.weight.detach().float().contiguous()   # [2086,180]: rows the expansion kernel gathers
             self.pfc_b_f32 = self.hip_pfc_b
             self.hip_v1_wt = m.value_fc1.weight.float().t().contiguous()      # [90,256]
             self.hip_v1_b = m.value_fc1.bias.float().contiguous()

@@ -173,6 +173,11 @@ int cz_search_eval_totals(cz_ctx *, unsigned long long *rows, unsigned long long
  * G*k rows, slot g*k + j = j-th descent of tree g; slots a tree does not use have needs_eval = 0.  k = 1 is
  * arithmetically identical to cz_search_select / cz_search_expand_backup. */
 int cz_search_set_width(cz_ctx *, int width);
+/* cz_search_set_sim_target: with k > 1 a tree stops issuing descents once `target` simulations (counted since the last
+ * cz_search_reset / cz_search_advance, cz_search_status `sims`) are completed or in flight, so that a search of
+ * ceil(playouts / k) + a few steps ends with EXACTLY `playouts` simulations per tree like MCTS_tree.main (main.py:489-493:
+ * `playouts` coroutines, at most search_threads of them in flight).  0 = no limit (default). */
+int cz_search_set_sim_target(cz_ctx *, int target);
 int cz_search_select_k(cz_ctx *, int mode, int k, const uint8_t *active, void *leaf_planes, int dtype,
                        int channels, uint8_t *needs_eval);
 int cz_search_expand_backup_k(cz_ctx *, int k, const void *logits, const void *value, int dtype);

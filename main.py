@@ -241,9 +241,10 @@ class MCTS_tree(object):
         return current_player == 'b'
 
     def main(self, state, current_player, restrict_round, playouts):
-        if state != self._state or current_player != self._player:
+        # the reference passes restrict_round into every search (main.py:1337); the device tree carries it in its root, so a
+        # caller that changes it behind the tree's back (a fresh game set up at another count) gets a fresh root
+        if state != self._state or current_player != self._player or int(restrict_round) != int(self._rr):
             self._set_root(state, current_player, restrict_round)
-        self._rr = restrict_round
         self._step(0)                       # root expansion if needed (main.py:475-487)
         if self._width == 1:
             for _ in range(int(playouts)):

@@ -634,12 +634,19 @@ static int select_child_vl(const otree *t, int node) {
     return best;
 }
 
+static int g_sim_target = 0;
+/* per-tree budget of completed + in-flight simulations for the k > 1 schedule (mirrors cz_search_set_sim_target) */
+int czo_search_set_sim_target(czo_search *s, int target) { (void)s; g_sim_target = target; return 0; }
+
 int czo_search_select_k(czo_search *s, int mode, int K, float *planes, uint8_t *needs_eval) {
     for (int g = 0; g < s->G; g++) {
         otree *t = &s->t[g];
         if (t->nslots < K) { free(t->slots); t->slots = calloc((size_t)K, sizeof(*t->slots)); t->nslots = K; }
         int stop = (t->status & ~8) != 0;
+        const int budget = g_sim_target > 0 ? g_sim_target - t->sims : 0x7FFFFFFF;
+        int issued = 0;
         for (int j = 0; j < K; j++) {
+            if (mode != 0 && issued >= budget) stop = 1;
             size_t slot = (size_t)g * K + j;
             float *pl = planes ? planes + slot * CZO_PLANE_ELEMS : NULL;
             if (pl) memset(pl, 0, sizeof(float) * CZO_PLANE_ELEMS);
@@ -656,7 +663,7 @@ int czo_search_select_k(czo_search *s, int mode, int K, float *planes, uint8_t *
                 for (;;) {
                     onode *p = &t->nodes[node];
                     int abandon = 0;
-                    if (p->child_begin == -1) { sl->kind = 1; sl->leaf = node; p->child_begin = -2; break; }
+                    if (p->child_begin == -1) { sl->kind = 1; sl->leaf = node; p->child_begin = -2; issued++; break; }
                     if (p->child_begin == -2) abandon = 1;
                     else if (p->child_count == 0) { t->status |= 2; abandon = 1; }
                     if (abandon) {
@@ -679,6 +686,7 @@ int czo_search_select_k(czo_search *s, int mode, int K, float *planes, uint8_t *
                             q->N = cnt; q->W = w; q->Q = w / (float)cnt; x = x * -1;
                         }
                         t->sims++;
+                        issued++;
                         break;
                     }
                     node = c;
@@ -690,6 +698,7 @@ int czo_search_select_k(czo_search *s, int mode, int K, float *planes, uint8_t *
                 if (n < 0) {
                     t->status |= 4;
                     if (sl->kind == 1) {
+                        issued--;
                         t->nodes[sl->leaf].child_begin = -1;
                         for (int m = sl->leaf; m != t->root; m = t->nodes[m].parent) { t->nodes[m].N -= 3; t->nodes[m].W = t->nodes[m].W + 3.0f; }
                     }

@@ -98,6 +98,9 @@ int czo_search_last_depth(const czo_search *, int32_t *depth);
  * k_select_k / k_expand_backup_k (see cchess_oracle.c).  planes [G*K][9][10][14], needs_eval [G*K],
  * logits [G*K][2086], value [G*K]. */
 int czo_search_select_k(czo_search *, int mode, int K, float *planes, uint8_t *needs_eval);
+/* budget of completed + in-flight simulations per tree for the k > 1 schedule (0 = none): a tree issues no descent
+ * beyond it, so a search ends with exactly `playouts` simulations like MCTS_tree.main (main.py:489-493) */
+int czo_search_set_sim_target(czo_search *, int target);
 int czo_search_expand_backup_k(czo_search *, int K, const float *logits, const float *value);
 
 /* pre-order dump of tree g: records of 7 int32 {depth, label, N, bits(W), bits(Q), bits(P),

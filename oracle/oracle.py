@@ -45,7 +45,7 @@ def lib():
         L.czo_search_destroy.argtypes = [C.c_void_p]
         for name in ("czo_search_reset", "czo_search_select", "czo_search_expand_backup", "czo_search_root_stats",
                      "czo_search_advance", "czo_search_status", "czo_search_root_state", "czo_search_last_depth",
-                     "czo_search_tree_dump", "czo_search_select_k", "czo_search_expand_backup_k"):
+                     "czo_search_tree_dump", "czo_search_select_k", "czo_search_expand_backup_k", "czo_search_set_sim_target"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -163,6 +163,9 @@ class Search:
         logits = np.ascontiguousarray(logits, np.float32).reshape(self.G, NLABELS)
         value = np.ascontiguousarray(value, np.float32).reshape(self.G)
         lib().czo_search_expand_backup(self.h, _p(logits), _p(value))
+
+    def set_sim_target(self, target):
+        lib().czo_search_set_sim_target(self.h, int(target))
 
     def select_k(self, mode, K):
         planes = np.zeros((self.G * K, 9, 10, 14), np.float32)

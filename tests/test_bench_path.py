@@ -40,8 +40,8 @@ class _Shadow:
         self.sub_t = torch.from_numpy(self.sub).to(eng.dev)
         self.orc = O.Search(len(self.sub), cap)
         self.orc.reset(boards.cpu().numpy()[self.sub], side.cpu().numpy()[self.sub], rr.cpu().numpy()[self.sub])
-        self.w = net.pfc_w_rows.cpu().numpy()
-        self.b = net.pfc_b_f32.cpu().numpy()
+        self.w = net.pfc_w_rows.detach().cpu().numpy()
+        self.b = net.pfc_b_f32.detach().cpu().numpy()
         self.steps = 0
 
     def tap(self, planes, z, value):
@@ -138,11 +138,13 @@ def test_fused_step_configs2_8192_playout1600_across_advance_vs_oracle():
     print("configs[2] fused step across an advance: %d trees shadowed, kept subtree + 100 sims: mean nodes/tree %.0f" % (len(sh.sub), nodes.mean()))
 
 
-# (dtype, minimum root-argmax agreement, maximum mean visit L1).  CPU emulation of the bf16 / fp16 roundings on 48 trees
-# (tests/agree_emulation.py) gave 0.94 / 0.064 for bf16 and 1.00 / 0.002 for fp16: with a peaked, trained-like net PUCT
-# amplifies the 0.7 % logit noise of a 15-layer bf16 tower into a different most-visited move for a few trees in a
-# hundred; that is a property of bf16 inference, not of the kernels (whose arithmetic the two tests above pin exactly).
-_AGREE = {"bf16": (torch.bfloat16, 0.90, 0.12), "fp16": (torch.float16, 0.985, 0.02)}
+# (dtype, minimum root-argmax agreement, maximum mean visit L1).  Measured on an MI355X (1024 trees x 400 playouts):
+# bf16 0.9453 / 0.0827, fp16 0.9854 / 0.0200; the CPU emulation of the two roundings (tests/agree_emulation.py, 48 trees)
+# predicted 0.94 / 0.064 for bf16.  With a peaked, trained-like net PUCT amplifies the 0.9 % logit noise of a 15-layer
+# bf16 tower (0.1 % for fp16) into a different most-visited move for a few trees in a hundred — a property of 16-bit
+# inference, not of the kernels, whose arithmetic the two tests above pin exactly.  The thresholds sit just below the
+# measured levels: a numerically worse kernel fails.
+_AGREE = {"bf16": (torch.bfloat16, 0.93, 0.10), "fp16": (torch.float16, 0.975, 0.03)}
 
 
 @pytest.mark.parametrize("dname", ["bf16", "fp16"])

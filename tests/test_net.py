@@ -106,18 +106,30 @@ def test_inference_engine_fp32_within_1e3(blocks):
 # glorot = TF-default initialisation (|logit| ~ 0.1, softmax ~ uniform 4.8e-4); trained_like = positive, peaked policy
 # (|logit| ~ 10, top probability 0.2-0.4) and a calibrated value head; structured = tap/channel-asymmetric perturbations.
 NET_TOL = {
-    ("bf16", 2, "glorot"): (2.0e-2, 4.0e-7, 4.0e-4),
-    ("bf16", 7, "glorot"): (2.6e-2, 1.7e-6, 2.1e-3),
-    ("bf16", 19, "glorot"): (7.5e-2, 4.5e-6, 4.5e-3),
-    ("bf16", 3, "structured"): (2.5e-2, 3.0e-6, 1.5e-3),
-    ("bf16", 7, "trained_like"): (3.0e-2, 1.7e-2, 2.3e-1),
-    ("bf16", 19, "trained_like"): (1.1e-1, 8.0e-2, 6.0e-1),
-    ("fp16", 2, "glorot"): (2.4e-3, 5.0e-8, 6.0e-5),
-    ("fp16", 7, "glorot"): (2.8e-3, 1.8e-7, 3.1e-4),
-    ("fp16", 19, "glorot"): (1.0e-2, 5.5e-7, 9.1e-4),
-    ("fp16", 3, "structured"): (3.0e-3, 4.0e-7, 2.0e-4),
-    ("fp16", 7, "trained_like"): (3.3e-3, 2.9e-3, 2.8e-2),
-    ("fp16", 19, "trained_like"): (1.0e-2, 1.4e-2, 8.0e-2),
+    # measured (profiles/r02_net_errors.json)     rel 0.00642  dprob 1.19e-07  dvalue 1.14e-04
+    ("bf16", 2, "glorot"): (1.6e-2, 3.0e-7, 2.9e-4),
+    #                                              rel 0.00789  dprob 4.71e-07  dvalue 8.31e-04
+    ("bf16", 7, "glorot"): (2.0e-2, 1.2e-6, 2.1e-3),
+    #                                              rel 0.0283   dprob 1.56e-06  dvalue 1.61e-03
+    ("bf16", 19, "glorot"): (7.0e-2, 3.9e-6, 4.0e-3),
+    #                                              rel 0.00382  dprob 5.68e-06  dvalue 8.0e-03
+    ("bf16", 3, "structured"): (9.6e-3, 1.4e-5, 2.0e-2),
+    #                                              rel 0.00899  dprob 4.85e-03  dvalue 8.36e-02
+    ("bf16", 7, "trained_like"): (2.3e-2, 1.2e-2, 2.1e-1),
+    #                                              rel 0.0364   dprob 2.32e-02  dvalue 2.5e-01
+    ("bf16", 19, "trained_like"): (9.0e-2, 5.8e-2, 6.0e-1),
+    #                                              rel 8.11e-04 dprob 1.5e-08   dvalue 1.88e-05
+    ("fp16", 2, "glorot"): (2.0e-3, 3.8e-8, 4.7e-5),
+    #                                              rel 9.56e-04 dprob 5.74e-08  dvalue 1.14e-04
+    ("fp16", 7, "glorot"): (2.4e-3, 1.4e-7, 2.9e-4),
+    #                                              rel 3.66e-03 dprob 2.06e-07  dvalue 2.08e-04
+    ("fp16", 19, "glorot"): (9.2e-3, 5.2e-7, 5.2e-4),
+    #                                              rel 6.04e-04 dprob 9.1e-07   dvalue 9.62e-04
+    ("fp16", 3, "structured"): (1.5e-3, 2.3e-6, 2.4e-3),
+    #                                              rel 1.09e-03 dprob 6.6e-04   dvalue 7.2e-03
+    ("fp16", 7, "trained_like"): (2.7e-3, 1.65e-3, 1.8e-2),
+    #                                              rel 3.51e-03 dprob 2.28e-03  dvalue 2.87e-02
+    ("fp16", 19, "trained_like"): (8.8e-3, 5.7e-3, 7.2e-2),
 }
 
 
@@ -186,7 +198,9 @@ def test_hip_conv3x3_kernel_vs_torch(B, residual, relu):
 
 
 # blocks -> (max|dlogit| / max|logit|, max|dsoftmax|, max|dvalue|, max|dtrunk| / max|trunk|)
-HIP_VS_TORCH_TOL = {2: (2.0e-2, 4.0e-7, 4.0e-4, 2.0e-2), 7: (2.0e-2, 1.2e-6, 1.3e-3, 3.0e-2), 19: (7.0e-2, 4.5e-6, 4.5e-3, 6.0e-2)}
+# measured (profiles/r02_net_errors.json hip_vs_torch_bf16/*, GPUTEST log): 2 blocks (8.5e-3, 1.6e-7, 1.9e-4, 7.7e-3); 7 blocks
+# (1.1e-2, 6.6e-7, 1.2e-3, 8.2e-3); 19 blocks (3.6e-2, 2.0e-6, 3.4e-3, 2.0e-2)
+HIP_VS_TORCH_TOL = {2: (2.2e-2, 4.0e-7, 5.0e-4, 2.0e-2), 7: (2.8e-2, 1.7e-6, 3.0e-3, 2.1e-2), 19: (9.0e-2, 5.0e-6, 8.6e-3, 5.0e-2)}
 
 
 @pytest.mark.gpu
@@ -306,4 +320,5 @@ def test_fp16_trunk_route_consistent(blocks, n):
     l3, v3 = net.heads(net.tower(xd))
     dl, dv = float((l1 - l3).abs().max()), float((v1 - v3).abs().max())
     print("fp16 %d-block trunk route vs fused heads: max|dlogit| %.3g (max|logit| %.3g) max|dvalue| %.3g" % (blocks, dl, float(l3.abs().max()), dv))
-    assert dl < 2e-3 * max(float(l3.abs().max()), 1.0) and dv < 2e-3
+    # measured: 5.5e-6 of the largest logit, 2e-7 on the value (fp32 summation order of the head convs only)
+    assert dl <= 2e-5 * float(l3.abs().max()) and dv <= 1e-6

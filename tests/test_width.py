@@ -176,3 +176,78 @@ def test_hip_width_k_equals_oracle(rules_golden, K, mode):
                 played[t] = os_["label"][t, int(np.argmax(os_["N"][t, :n]))]
         hip.advance(played)
         orc.advance(played)
+
+
+def _budget_search_oracle(s, fwd, K, playouts):
+    """SearchEngine.search's k > 1 schedule on the oracle: budgeted steps until every tree has its playouts."""
+    planes, need = s.select_k(0, K)
+    lg, v = fwd(planes)
+    s.expand_backup_k(K, lg, v)
+    base = s.status()[2].copy()
+    assert np.all(base == base[0])
+    target = int(base[0]) + playouts
+    s.set_sim_target(target)
+    steps = 0
+    try:
+        while steps < 5 * playouts + 8:
+            st, _, sims = s.status()
+            if steps >= (playouts + K - 1) // K and not np.any((sims < target) & ((st & ~8) == 0)):
+                break
+            planes, need = s.select_k(1, K)
+            lg, v = fwd(planes)
+            s.expand_backup_k(K, lg, v)
+            steps += 1
+    finally:
+        s.set_sim_target(0)
+    return steps
+
+
+@pytest.mark.parametrize("K,playouts", [(4, 50), (16, 200), (16, 37)])
+def test_oracle_width_k_budget_gives_exact_playouts(rules_golden, K, playouts):
+    """with k simulations in flight a step can complete fewer than k (abandoned descents); the per-tree budget
+    makes a search end with exactly `playouts` simulations per tree, like MCTS_tree.main (main.py:489-493)."""
+    g = rules_golden
+    ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
+    idx = np.nonzero(ok)[0][::61][:32]
+    G = len(idx)
+    s = O.Search(G, 60000)
+    s.reset(g["boards"][idx], g["side"][idx], np.zeros(G, np.int32))
+    steps = _budget_search_oracle(s, fakenet.make_forward("pos", 9), K, playouts)
+    st, nodes, sims = s.status()
+    assert np.all(sims == playouts), (sims.min(), sims.max())
+    assert steps >= (playouts + K - 1) // K
+    rs = s.root_stats()
+    assert np.array_equal(rs["N"].sum(axis=1), np.full(G, playouts))
+    for t in range(0, G, 7):
+        _invariants(s.tree_dump(t), playouts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,playouts", [(4, 50), (16, 200)])
+def test_hip_search_width_k_exact_playouts_equals_oracle(rules_golden, K, playouts):
+    """SearchEngine.search(width = k): exactly `playouts` simulations per tree, trees bit-identical to the oracle running
+    the same budgeted schedule."""
+    import torch
+    from cchess_zero_amd.engine import SearchEngine
+    g = rules_golden
+    ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
+    idx = np.nonzero(ok)[0][::61][:32]
+    G = len(idx)
+    boards, side = g["boards"][idx], g["side"][idx]
+    fk = fakenet.make_forward("pos", 9)
+
+    def fwd_dev(planes):
+        lg, v = fk(planes.float().cpu().numpy())
+        return torch.from_numpy(lg).cuda(), torch.from_numpy(v).cuda()
+    hip = SearchEngine(G, 60000, width=K)
+    hip.reset(boards, side, np.zeros(G, np.int32))
+    steps = hip.search(fwd_dev, playouts)
+    orc = O.Search(G, 60000)
+    orc.reset(boards, side, np.zeros(G, np.int32))
+    osteps = _budget_search_oracle(orc, fk, K, playouts)
+    st, nodes, sims, _ = (x.cpu().numpy() for x in hip.status())
+    assert np.all(sims == playouts) and steps == osteps
+    hs, os_ = hip.root_stats_host(), orc.root_stats()
+    assert np.array_equal(hs["N"], os_["N"]) and np.array_equal(hs["Q"].view(np.uint32), os_["Q"].view(np.uint32))
+    for t in range(0, G, 5):
+        assert np.array_equal(hip.tree_dump(t), orc.tree_dump(t))

@@ -1,8 +1,21 @@
 #!/usr/bin/env python3
-"""Print selected fields of a bench.py JSON line read from stdin: tools/jline.py [label]"""
+"""Print selected fields of a bench.py JSON line: tools/jline.py [file] (default: stdin)"""
 import json
 import sys
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+src = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+lines = [l for l in src.strip().splitlines() if l.startswith("{")]
+d = json.loads(lines[-1])
 r = d["roofline"]
-print(sys.argv[1] if len(sys.argv) > 1 else "", "%.0f sims/s  %.3f ms/step  trunk %.1f us  %.1f TF/s  errors %s" % (
-    d["value"], d["ms_per_step"], r.get("us_per_launch", float("nan")), r["achieved"], d["config"].get("trees_with_error_status")))
+print("%.0f sims/s  %.3f ms/step  n_gpus %d  trunk %.1f us  %.1f TF/s (frac %.3f)  errors %s" % (
+    d["value"], d["ms_per_step"], d["n_gpus"], r.get("us_per_launch", float("nan")), r["achieved"], r["frac"], d["config"].get("trees_with_error_status")))
+t = d.get("roofline_tree")
+if t:
+    print("  tree side: select %.1f us, expand %.1f us, %.0f GB/s (frac %.4f)" % (t["us_select"], t["us_expand_backup"], t["achieved"], t["frac"]))
+c = d.get("cpu_baseline")
+if c:
+    print("  cpu: %s sims/s on %s cores; single core %s" % (c.get("value"), c.get("cores"), (c.get("single_core") or {}).get("value")))
+sp = d["config"].get("selfplay")
+if sp:
+    print("  selfplay:", sp)
+print("  per rank:", d["config"].get("per_rank_sims_per_s"), "backend", d["config"].get("dist_backend"), "gather", d["config"].get("record_gather"),
+      "status", d["config"].get("status_bits"))

@@ -33,6 +33,24 @@ def main():
     print("LDS bank conflict / idx active = %.3f ; LDS idx active per slab %.0f ; wait_inst_lds per slab %.0f"
           % (b["SQ_LDS_BANK_CONFLICT"] / b["SQ_LDS_IDX_ACTIVE"], b["SQ_LDS_IDX_ACTIVE"] / slabs, b["SQ_WAIT_INST_LDS"] * 4 / slabs))
     print("raw:", {k: "%.4g" % v for k, v in {**a, **b}.items()})
+    if len(sys.argv) > 5:   # machine-readable copy for profiles/
+        import json
+        out = {"kernel": "k_tower8_c128 (tools/ubench/tower_base %d positions, %d blocks, random bf16 data)" % (B, nb),
+               "method": "rocprofv3 --kernel-trace --pmc, two separate passes (tools/pmc_ubench.sh): a = GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SALU "
+                         "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES; b = SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM "
+                         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles",
+               "kernel_us": dur / 1e3, "effective_clock_GHz": clk,
+               "mfma_busy_frac_of_simd_cycles": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur * clk * 1024),
+               "per_workgroup_slab": {"wave_cycles": wc / slabs, "active_inst": a["SQ_ACTIVE_INST_ANY"] * 4 / slabs,
+                                      "wait_inst_any": a["SQ_WAIT_INST_ANY"] * 4 / slabs, "wait_any": a["SQ_WAIT_ANY"] * 4 / slabs,
+                                      "mfma_busy": a["SQ_VALU_MFMA_BUSY_CYCLES"] / slabs, "insts_valu": a["SQ_INSTS_VALU"] / slabs,
+                                      "insts_salu": a["SQ_INSTS_SALU"] / slabs, "insts_lds": b["SQ_INSTS_LDS"] / slabs,
+                                      "insts_vmem": b["SQ_INSTS_VMEM"] / slabs, "lds_idx_active": b["SQ_LDS_IDX_ACTIVE"] / slabs,
+                                      "wait_inst_lds": b["SQ_WAIT_INST_LDS"] * 4 / slabs},
+               "lds_bank_conflict_frac": b["SQ_LDS_BANK_CONFLICT"] / b["SQ_LDS_IDX_ACTIVE"],
+               "algorithmic_TFLOPs": 2.0 * B * 90 * 1152 * 128 * 2 * nb / (dur * 1e-9) / 1e12,
+               "raw_counters": {**a, **b}}
+        json.dump(out, open(sys.argv[5], "w"), indent=1)
 
 
 if __name__ == "__main__":

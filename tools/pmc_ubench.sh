@@ -12,4 +12,4 @@ for pass in a b; do
   mkdir -p $O
   (timeout 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O -o p -- $ROOT/tools/ubench/tower_base $B $NB 3 $V > $O/log.txt 2>&1) < /dev/null
 done
-python3 $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/pmcu_${V}_a $ROOT/gpurun_out/pmcu_${V}_b $B $NB
+python3 $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/pmcu_${V}_a $ROOT/gpurun_out/pmcu_${V}_b $B $NB $ROOT/gpurun_out/pmc_sq_${V}.json

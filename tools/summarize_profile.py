@@ -77,6 +77,31 @@ def main():
     json.dump(tj, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     md += ["", "HBM PMC (separate passes): FETCH_SIZE %.0f KiB raw, WRITE_SIZE %.0f KiB per launch -> traffic %.3e B "
            "(algorithmic %.3e B); see pmc_traffic.json." % (fetch, write, tj["traffic_bytes_per_launch"], alg)]
+    # the HBM-bound tree / rules kernels of the same runs: counter traffic per launch and the GB/s that implies
+    dur = {r["Name"]: float(r["AverageNs"]) for r in rows}
+    tree = {}
+    fpath = find(os.path.join(src, "pmc_f"), "*counter_collection.csv")
+    wpath = find(os.path.join(src, "pmc_w"), "*counter_collection.csv")
+    for key, sub in (("k_select", "k_select"), ("k_expand_backup", "k_expand_backup"), ("k_value_fc", "k_value_fc")):
+        f_, n1 = pmc_mean(fpath, "FETCH_SIZE", sub)
+        w_, n2 = pmc_mean(wpath, "WRITE_SIZE", sub)
+        ns = [v for k, v in dur.items() if sub in k]
+        if f_ is None or w_ is None or not ns:
+            continue
+        t_ns = ns[0]
+        tree[key] = {"FETCH_SIZE_KiB_raw": f_, "WRITE_SIZE_KiB_raw": w_, "fetch_bytes_x1": f_ * 1024, "fetch_bytes_x2": f_ * 2048,
+                     "write_bytes": w_ * 1024, "avg_us": t_ns / 1e3, "launches": [n1, n2],
+                     "GBps_x1": (f_ * 1024 + w_ * 1024) / t_ns, "GBps_x2": (f_ * 2048 + w_ * 1024) / t_ns}
+    if tree:
+        tj2 = {"config": tj["config"], "kernels": tree,
+               "method": "same two rocprofv3 --pmc passes as pmc_traffic.json; avg_us from the --kernel-trace --stats pass; FETCH_SIZE is given "
+                         "raw (x1) and with the gfx950 x2 correction for wide coalesced reads (these kernels mix narrow gathers and wide "
+                         "loads: the truth lies between)"}
+        json.dump(tj2, open(os.path.join(prof, "pmc_tree_traffic.json"), "w"), indent=1)
+        md += ["", "Tree / rules kernels (HBM-bound; counter traffic per launch, x1 .. x2 FETCH correction):", "",
+               "| kernel | avg us | fetch KiB raw | write KiB | GB/s (x1 .. x2) |", "|---|---|---|---|---|"]
+        for k, v in tree.items():
+            md.append("| `%s` | %.1f | %.0f | %.0f | %.0f .. %.0f |" % (k, v["avg_us"], v["FETCH_SIZE_KiB_raw"], v["WRITE_SIZE_KiB_raw"], v["GBps_x1"], v["GBps_x2"]))
     open(os.path.join(prof, rnd + "_summary.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 
