@@ -87,79 +87,42 @@ def synth_positions(rules, G, seed, max_ply=80):
 
 
 # ---- CPU baseline: the C oracle's search + a torch-CPU (oneDNN) fp32 net on this host's cores -----------------------------
-def _cpu_worker(args):
-    """One worker process: `games` trees searched in lock-step by the C oracle (oracle/, the pinned restatement of the
-    reference's search), leaves evaluated in one batch by the fp32 torch module on `threads` CPU threads."""
-    idx, games, threads, blocks, seconds, first_core = args
-    os.environ["HIP_VISIBLE_DEVICES"] = ""
-    os.environ["CUDA_VISIBLE_DEVICES"] = ""
-    # pin the worker (and the OpenMP threads it creates later) to its own cores: without it every worker's OpenMP pool
-    # ends up on the same cores (measured: 16 workers x 16 threads gave 2.2x ONE core)
-    try:
-        avail = sorted(os.sched_getaffinity(0))
-        mine = avail[first_core:first_core + int(threads)] or avail[:int(threads)]
-        os.sched_setaffinity(0, mine)
-    except Exception:
-        pass
-    import torch as T
-    T.set_num_threads(int(threads))
-    from oracle import oracle as O
-    from cchess_zero_amd.net import PolicyValueModule
-    rng = np.random.default_rng(idx)
-    boards = np.tile(START, (games, 1))
-    side = np.zeros(games, np.uint8)
-    for g in range(games):  # short random playouts with the oracle
-        b, s = boards[g].copy(), 0
-        for _ in range(int(rng.integers(0, 60))):
-            mv = O.legal_moves(b, s)
-            if len(mv) == 0:
-                break
-            nb, cap, term = O.apply_move(b, int(mv[rng.integers(len(mv))]))
-            if term:
-                break
-            b, s = nb, s ^ 1
-        boards[g], side[g] = b, s
-    m = PolicyValueModule(blocks, seed=0).eval()
-    srch = O.Search(games, 40000)
-    srch.reset(boards, side, None)
-    t0 = time.perf_counter()
-    sims, step = 0, 0
-    with T.no_grad():
-        while True:
-            planes, need = srch.select(0 if step == 0 else 1)
-            lg, v = m(T.from_numpy(planes).permute(0, 3, 1, 2))
-            srch.expand_backup(lg.numpy(), v.numpy())
-            if step > 0:
-                sims += games
-            step += 1
-            if time.perf_counter() - t0 > seconds and step > 2:
-                break
-    return sims, time.perf_counter() - t0, step - 1
+def _cpu_workers(specs):
+    """Runs oracle/cpu_baseline_worker.py once per spec (idx, games, threads, blocks, seconds, first_core), concurrently,
+    as separate processes (their thread affinity has to be in place before torch / OpenMP load)."""
+    worker = os.path.join(ROOT, "oracle", "cpu_baseline_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker] + [str(x) for x in sp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for sp in specs]
+    out = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError("cpu_baseline worker failed: " + se[-400:])
+        out.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    return out
 
 
 def cpu_baseline(blocks, seconds_target=12.0):
     """The CPU port timed on this host, single core and all cores: C oracle search + fp32 torch-CPU
     net, a bounded sample of the same workload family.  Test infrastructure used as the *baseline being measured*, never
     as the product path.  `value` is the all-core figure."""
-    import multiprocessing as mp
     cores = os.cpu_count() or 1
-    ctx = mp.get_context("spawn")
     out = {"unit": "sims/s", "kind": "port", "reference_python": REFERENCE_PYTHON}
     try:
-        with ctx.Pool(1) as pool:
-            s, dt, steps = pool.map(_cpu_worker, [(0, 8, 1, blocks, seconds_target * 0.5, 0)])[0]
-        out["single_core"] = {"value": s / dt, "cores": 1,
-                              "sample": "8 games x %d lock-step simulations, 1 thread, %.1f s" % (steps, dt)}
-        tpw = 16 if cores >= 32 else max(1, cores // 2)     # threads per worker process
+        r = _cpu_workers([(0, 8, 1, blocks, seconds_target * 0.4, 0)])[0]
+        out["single_core"] = {"value": r["sims"] / r["seconds"], "cores": 1,
+                              "sample": "8 games x %d lock-step simulations, 1 thread pinned to one core, %.1f s (%.0f %% in the net)" %
+                                        (r["steps"], r["seconds"], 100.0 * r["net_seconds"] / r["seconds"])}
+        tpw = 8 if cores >= 16 else max(1, cores // 2)     # threads per worker process
         workers = max(1, cores // tpw)
-        games = 256
-        with ctx.Pool(workers) as pool:
-            res = pool.map(_cpu_worker, [(i + 1, games, tpw, blocks, seconds_target, i * tpw) for i in range(workers)])
-        out["value"] = float(sum(s / dt for s, dt, _ in res))
+        games = 128
+        res = _cpu_workers([(i + 1, games, tpw, blocks, seconds_target, i * tpw) for i in range(workers)])
+        out["value"] = float(sum(r["sims"] / r["seconds"] for r in res))
         out["cores"] = workers * tpw
-        out["sample"] = ("%d worker processes x %d threads, each %d games x ~%d lock-step simulations: C oracle search + fp32 "
-                         "torch-CPU (oneDNN) %d-block net, %.1f s" % (workers, tpw, games, int(np.mean([st for _, _, st in res])), blocks,
-                                                                       float(np.mean([dt for _, dt, _ in res]))))
+        out["sample"] = ("%d worker processes x %d pinned threads, each %d games x ~%d lock-step simulations: C oracle search + fp32 "
+                         "torch-CPU (oneDNN) %d-block net, %.1f s (%.0f %% in the net)" %
+                         (workers, tpw, games, int(np.mean([r["steps"] for r in res])), blocks, float(np.mean([r["seconds"] for r in res])),
+                          100.0 * float(np.mean([r["net_seconds"] / r["seconds"] for r in res]))))
     except Exception as e:   # the GPU number must survive a failing baseline leg
         out.setdefault("value", None)
         out.setdefault("cores", cores)

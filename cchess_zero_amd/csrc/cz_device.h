@@ -256,16 +256,21 @@ __device__ __forceinline__ int czd_group_movegen(const uint8_t *b, SideFn side_o
         }
     }
     __syncthreads();
-    // (src, dst) -> label (label2i, main.py:217); every entry is read and rewritten by the same lane
-    if (live)
-        for (int i = s; i < base; i += 16) {
-            const int sd = o[i];
-            const int l = lut[(sd & 0xFF) * CZD_NSQ + (sd >> 8)];
-            if (l < 0) err = true; else o[i] = (uint16_t)l;
-        }
+    // (src, dst) -> label (label2i, main.py:217); every entry is read and rewritten by the same lane.  With one position
+    // per wave all 64 lanes share the list (one or two LUT round trips instead of up to eight)
+    {
+        const int step = NP == 1 ? 64 : 16, first = NP == 1 ? lane : s;
+        const int lim = NP == 1 ? __shfl(base, 0, 64) : base;
+        if (live || NP == 1)
+            for (int i = first; i < lim; i += step) {
+                const int sd = o[i];
+                const int l = lut[(sd & 0xFF) * CZD_NSQ + (sd >> 8)];
+                if (l < 0) err = true; else o[i] = (uint16_t)l;
+            }
+    }
     // an error anywhere in the group spoils the group
     const unsigned long long em = __ballot(err);
-    const bool gerr = ((em >> (lane & 48)) & 0xFFFFull) != 0ull;
+    const bool gerr = NP == 1 ? em != 0ull : ((em >> (lane & 48)) & 0xFFFFull) != 0ull;
     __syncthreads();
     return live ? (gerr ? -1 : base) : 0;
 }

@@ -1,0 +1,12 @@
+#!/bin/bash
+TAG=${1:-r02d}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
+( timeout 900 python -m pytest tests/test_hip_search.py tests/test_bench_path.py tests/test_scale_properties.py tests/test_width.py tests/test_selfplay_golden.py tests/test_selfplay_device.py -m gpu -q -p no:cacheprovider --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log )
+tail -4 $OUT/pytest_gpu.log | cut -c1-200
+cd /tmp; (timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/stats -o s -- python $OLDPWD/bench.py --no-cpu-baseline --steps 100 --warmup 8 > $OLDPWD/$OUT/bench_under_rocprof.json 2> $OLDPWD/$OUT/stats.err) < /dev/null; cd $OLDPWD
+find $OUT -name '*_kernel_trace.csv' -size +20M -delete
+head -7 $(find $OUT/stats -name "*kernel_stats.csv" | head -1) | cut -c1-100,180-330
+bash tools/pmc_tree.sh $OUT/pmc_tree > $OUT/pmc_tree.log 2>&1; tail -12 $OUT/pmc_tree.log | cut -c1-400
