@@ -108,6 +108,27 @@ def cpu_baseline(blocks, seconds_target=12.0):
     as the product path.  `value` is the all-core figure."""
     cores = os.cpu_count() or 1
     out = {"unit": "sims/s", "kind": "port", "reference_python": REFERENCE_PYTHON}
+    # a container may see every host CPU and still be throttled to a few of them by its cgroup CPU quota: report it, and do
+    # not oversubscribe it (measured on the GPU box: 256 visible CPUs, all-core throughput of ~4 cores)
+    quota = None
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            quota = float(q[0]) / float(q[1])
+    except Exception:
+        try:
+            qq = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if qq > 0:
+                quota = qq / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception:
+            pass
+    out["visible_cpus"], out["cgroup_cpu_quota"] = cores, quota
+    try:
+        out["loadavg"] = os.getloadavg()[0]
+    except Exception:
+        pass
+    if quota:
+        cores = max(1, min(cores, int(quota)))
     try:
         r = _cpu_workers([(0, 8, 1, blocks, seconds_target * 0.4, 0)])[0]
         out["single_core"] = {"value": r["sims"] / r["seconds"], "cores": 1,
@@ -116,6 +137,9 @@ def cpu_baseline(blocks, seconds_target=12.0):
         tpw = 8 if cores >= 16 else max(1, cores // 2)     # threads per worker process
         workers = max(1, cores // tpw)
         games = 128
+        r1 = _cpu_workers([(99, games, tpw, blocks, seconds_target * 0.4, 0)])[0]   # one worker alone: the scaling reference
+        out["one_worker"] = {"value": r1["sims"] / r1["seconds"], "cores": tpw,
+                             "sample": "1 worker x %d pinned threads, %d games x %d simulations, %.1f s" % (tpw, games, r1["steps"], r1["seconds"])}
         res = _cpu_workers([(i + 1, games, tpw, blocks, seconds_target, i * tpw) for i in range(workers)])
         out["value"] = float(sum(r["sims"] / r["seconds"] for r in res))
         out["cores"] = workers * tpw

@@ -189,16 +189,16 @@ __device__ __forceinline__ int czd_row_excl_scan16(int v, int *total, int lane) 
     return x - v;
 }
 
-// b: LDS boards, position p at b + p * CZD_BOARD_LDS; side_of(p) its side to move; NP positions (1..4).
+// b: LDS boards, position p at b + p * STRIDE; side_of(p) its side to move; NP positions (1..4).
 // out: LDS [NP][128] u16 (labels on return); stage: LDS [64 * 18] u16; G: LDS scratch.
 // Returns, in every lane of group q, the move count of position q (-1 on overflow / unlabeled move; 0 for q >= NP).
-template <int NP, typename SideFn>
+template <int NP, int STRIDE, typename SideFn>
 __device__ __forceinline__ int czd_group_movegen(const uint8_t *b, SideFn side_of, const int16_t *lut, CzdGroupLds &G,
                                                  uint16_t *stage, uint16_t *out, int lane) {
-    // ---- stage A
-#pragma unroll
+    // ---- stage A (not unrolled: four copies of it only cost registers, i.e. occupancy)
+#pragma unroll 1
     for (int p = 0; p < NP; ++p) {
-        const uint8_t *bp = b + p * CZD_BOARD_LDS;
+        const uint8_t *bp = b + p * STRIDE;
         const int side = side_of(p);
         const CzdBoardSets S = czd_board_sets(bp, side, lane);
         const int c0 = bp[lane], c1 = (lane + 64 < CZD_NSQ) ? bp[lane + 64] : 0;
@@ -279,7 +279,7 @@ __device__ __forceinline__ int czd_group_movegen(const uint8_t *b, SideFn side_o
 //   b LDS board [96]; stage LDS [64*18] u16; out LDS [128] u16.  Returns the move count (wave-uniform) or -1.
 __device__ __forceinline__ int czd_wave_movegen(const uint8_t *b, int side, const int16_t *lut, CzdGroupLds &G,
                                                 uint16_t *stage, uint16_t *out, int lane) {
-    const int n = czd_group_movegen<1>(b, [side](int) { return side; }, lut, G, stage, out, lane);
+    const int n = czd_group_movegen<1, CZD_BOARD_LDS>(b, [side](int) { return side; }, lut, G, stage, out, lane);
     return __shfl(n, 0, 64);
 }
 

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void k_movegen(CzTables tab, const uint8_t *__r
                                                 const uint8_t *__restrict__ side, int G,
                                                 uint16_t *__restrict__ moves, uint16_t *__restrict__ count,
                                                 uint32_t *__restrict__ mask) {
-    __shared__ __attribute__((aligned(16))) uint8_t b[4 * CZD_BOARD_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t b[4 * CZ_NSQ + 8];   // four boards, packed (stride 90)
     __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
     __shared__ __attribute__((aligned(16))) uint16_t out[4 * CZD_MAXMOVES];
     __shared__ CzdGroupLds GL;
@@ -31,21 +31,23 @@ __global__ __launch_bounds__(64) void k_movegen(CzTables tab, const uint8_t *__r
     __shared__ uint8_t sd[4];
     const int lane = threadIdx.x, q = lane >> 4, s = lane & 15;
     const int ngroups = (G + 3) >> 2;
+    const bool aligned4 = (reinterpret_cast<uintptr_t>(boards) & 3u) == 0;   // 4 boards = 360 bytes = 90 dwords
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int g0 = grp * 4;
         const int np = min(4, G - g0);
-        for (int j = lane; j < 4 * (CZD_BOARD_LDS / 2); j += 64) {
-            const int p = j / (CZD_BOARD_LDS / 2), w = j - p * (CZD_BOARD_LDS / 2);
-            uint16_t v = 0;
-            if (p < np && w < CZ_NSQ / 2) {
-                const uint8_t *src = boards + (size_t)(g0 + p) * CZ_NSQ + 2 * w;
-                v = (uint16_t)(src[0] | (src[1] << 8));
+        if (aligned4 && np == 4) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(boards + (size_t)g0 * CZ_NSQ);
+            reinterpret_cast<uint32_t *>(b)[lane] = src[lane];
+            if (lane < 26) reinterpret_cast<uint32_t *>(b)[lane + 64] = src[lane + 64];
+        } else {
+            for (int j = lane; j < 4 * CZ_NSQ; j += 64) {
+                const int p = j / CZ_NSQ;
+                b[j] = p < np ? boards[(size_t)g0 * CZ_NSQ + j] : (uint8_t)0;
             }
-            reinterpret_cast<uint16_t *>(b)[j] = v;
         }
         if (lane < 4) sd[lane] = (lane < np && side[g0 + lane]) ? 1 : 0;
         __syncthreads();
-        const int n = czd_group_movegen<4>(b, [&](int p) { return (int)sd[p]; }, tab.lut, GL, stage, out, lane);
+        const int n = czd_group_movegen<4, CZ_NSQ>(b, [&](int p) { return (int)sd[p]; }, tab.lut, GL, stage, out, lane);
         const int nn = n < 0 ? 0 : n;
         if (s == 0 && q < np) count[g0 + q] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
         if (moves) {
