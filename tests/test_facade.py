@@ -122,3 +122,12 @@ def test_cchess_main_selfplay_and_update(tmp_path, monkeypatch):
     from policy_value_network_gpus import policy_value_network_gpus
     n2 = policy_value_network_gpus(1, 2)
     assert n2.global_step == cm.global_step
+    # one iteration of the training loop itself (main.py:1206-1248): continuous self-play on 8 slots until 8 games have
+    # finished, records -> buffer (resized to hold two batches, shuffled), policy updates proportional to the new samples
+    cm.games = 8
+    step1 = cm.global_step
+    cm.run(max_batches=1)
+    st = cm.last_selfplay_stats
+    assert st["games"] >= 8 and st["stalled"] == 0 and st["dropped"] == 0
+    assert len(cm.data_buffer) >= st["plies"] > 0 and cm.data_buffer.maxlen >= 2 * st["plies"]
+    assert cm.global_step > step1 and st["sims"] == st["plies_played"] * 8 * cm.playout_counts
