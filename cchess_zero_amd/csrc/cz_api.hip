@@ -330,7 +330,6 @@ int cz_selfplay_begin(cz_ctx *c, int max_plies, const uint8_t *boards, const uin
             sp.ply = k.take<int32_t>(G);
             sp.stalled = k.take<uint8_t>(G);
             sp.active = k.take<uint8_t>(G);
-            sp.fin_winner = k.take<int8_t>(G);
             sp.start_board = k.take<uint8_t>(G * CZD_BOARD_LDS);
             sp.start_side = k.take<uint8_t>(G);
             sp.start_rr = k.take<int32_t>(G);

@@ -55,7 +55,6 @@ struct CzSelfplay {
     int32_t *ply;                // [max_games] plies recorded for the game in progress
     uint8_t *stalled;            // [max_games] the last choose found no root child (node pool exhausted at the root)
     uint8_t *active;             // [max_games] 0 = parked (finished, not re-seeded)
-    int8_t *fin_winner;          // [max_games] scratch between adjudicate and flush
     uint8_t *start_board;        // [max_games][96] position every new game of the slot starts from
     uint8_t *start_side;         // [max_games]
     int32_t *start_rr;           // [max_games]

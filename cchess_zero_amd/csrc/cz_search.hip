@@ -195,13 +195,15 @@ template <> __device__ __forceinline__ float to_f32<uint16_t>(uint16_t x) { retu
 //               s[l] = ((p[12l] + p[12l+1]) + ...) + p[12l+11] for l = 0..15 (s[15] = 0);
 //               s[l] += s[15-l]; s[l] += s[(l & 8) | (7 - (l & 7))]; s[l] += s[(l & 12) | (3 - (l & 3))]; s[l] += s[l ^ 1]
 //               (each step on all 16 values at once); logit = s[0] + bias.
+// register caps: 8192 trees are 32 waves per CU, which only fit at <= 64 VGPRs and <= 80 SGPRs per wave (see k_select)
 template <typename T, bool FC>
-__global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, int G, const T *__restrict__ logits,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64))) void k_expand_backup(CzTrees t, CzTables tab, int G, const T *__restrict__ logits,
                                                       const T *__restrict__ value, const float *__restrict__ fcw,
                                                       const float *__restrict__ fcb, int compact_parity) {
     __shared__ float pr[CZD_MAXMOVES];
     __shared__ float tot_s;
-    __shared__ __attribute__((aligned(16))) float xin[FC ? 180 : 4];
+    __shared__ __attribute__((aligned(16))) float xin[FC ? 192 : 4];
+    __shared__ uint16_t ridx[FC ? CZD_MAXMOVES : 2];
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     // compact batches (compact_parity >= 0): tree g's leaf sits in row slot_of[g] of z / value; tree 0 also books the
@@ -232,10 +234,13 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
                     if (ch < 2) xin[cell * 2 + ch] = zv;
                 }
                 if (lane < 12) xin[180 + lane] = 0.f;
+                // the weight row of every move, resolved for all moves at once (label -> flip_policy's unflip for black):
+                // two dependent round trips for the whole node instead of two per group of four moves
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int i = lane + 64 * r;
                     lab[r] = i < n ? t.pend_moves[(size_t)g * CZD_MAXMOVES + i] : (uint16_t)0;
+                    if (i < n) ridx[i] = (uint16_t)(sd ? tab.unflip[lab[r]] : lab[r]);
                 }
                 __syncthreads();
                 // four moves per pass, 16 lanes per move: lane l of a group owns inputs k = 12 l .. 12 l + 11 (three
@@ -247,25 +252,24 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
                 float xr[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) xr[k] = xin[l16 * 12 + k];
-                // two groups of four moves per iteration: the weight rows of both are requested before either is reduced
-                // (each row fetch is a dependent chain label -> unflip -> 3 x 16 bytes of the row)
+                // THREE passes (12 moves) per iteration: all their weight rows are requested before any is reduced, so a
+                // 40-move node waits for four gathers instead of ten (four passes would need 76 registers: 6 waves per SIMD)
+                constexpr int NH = 3;
 #pragma unroll 1
-                for (int base = 0; base < n; base += 8) {
-                    int idx[2] = {0, 0};
-                    float sum[2] = {0.f, 0.f};
-                    float4 wa[2], wb[2], wc4[2];
-                    bool on[2];
+                for (int base = 0; base < n; base += 4 * NH) {
+                    int idx[NH];
+                    float sum[NH];
+                    float4 wa[NH], wb[NH], wc4[NH];
+                    bool on[NH];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NH; ++h) {
                         const int i = base + 4 * h + grp;
                         on[h] = i < n;
-                        if (on[h]) {
-                            const int l = t.pend_moves[(size_t)g * CZD_MAXMOVES + i];
-                            idx[h] = sd ? tab.unflip[l] : l;
-                        }
+                        idx[h] = on[h] ? (int)ridx[i] : 0;
+                        sum[h] = 0.f;
                     }
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NH; ++h) {
                         wa[h] = wb[h] = wc4[h] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (on[h] && l16 < 15) {
                             const float4 *w4 = reinterpret_cast<const float4 *>(fcw + (size_t)idx[h] * 180 + l16 * 12);
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
                         }
                     }
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NH; ++h) {
                         if (on[h] && l16 < 15) {
                             const float4 a = wa[h], bq = wb[h], cq = wc4[h];
                             float sm = a.x * xr[0];
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(CzTrees t, CzTables tab, i
                         }
                     }
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NH; ++h) {
                         float sm = sum[h];
                         sm = sm + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sm), 0x140, 0xF, 0xF, false));  // row_mirror
                         sm = sm + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sm), 0x141, 0xF, 0xF, false));  // row_half_mirror

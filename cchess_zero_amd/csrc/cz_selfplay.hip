@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_sp_seed(CzTrees t, CzSelfplay sp, int G,
     if (lane == 0) {
         sp.start_side[g] = boards ? (side[g] ? 1 : 0) : t.root_side[g];
         sp.start_rr[g] = boards ? (rr ? rr[g] : 0) : t.root_rr[g];
-        sp.ply[g] = 0; sp.stalled[g] = 0; sp.active[g] = 1; sp.fin_winner[g] = 0;
+        sp.ply[g] = 0; sp.stalled[g] = 0; sp.active[g] = 1;
         if (g == 0)
             for (int k = 0; k < CZ_SP_NSTATS; ++k) sp.stats[k] = 0;
     }

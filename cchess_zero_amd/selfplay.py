@@ -199,7 +199,10 @@ class SelfPlay:
             self.step_ply(forward)
 
     def play(self, forward=None, max_plies=None):
-        """continuous=False: play until every game has ended (or max_plies plies); returns the drained records."""
+        """continuous=False: play until every game has ended (or max_plies plies); returns the drained records.
+        continuous=True needs max_plies (the loop never runs out of games)."""
+        if self.continuous and max_plies is None:
+            raise ValueError("a continuous self-play loop has no natural end: pass max_plies (or drive step_ply / drain yourself)")
         n = 0
         out = []
         while max_plies is None or n < max_plies:
