@@ -162,6 +162,107 @@ __device__ __forceinline__ int czd_gen_piece(int c, int sq, int side, const CzdB
     return n;
 }
 
+// ---- the same generator without divergent control flow ------------------------------------------------------------
+// czd_gen_piece above is the readable statement of the rules (and what round 1 ran).  Its if-per-candidate structure
+// costs more scalar instructions (exec-mask save / restore / branch) than vector ones: the SQ counters of k_select
+// showed 894 SALU + 210 branch instructions per wave against 1 264 VALU, ~90 % of the scalar ones from the generator,
+// and the scalar unit is shared by the 32 waves of a CU.  Here every candidate is evaluated by every lane: a move is
+// written to st[valid ? n : 17] (slot 17 is a dump: a piece has at most 17 moves) and n += valid.  Only the
+// slider / leaper split is a real branch.  Emission order is the reference's, candidate by candidate.
+//   leapers: 8 candidates per (piece kind, side) from a table: (dy, dx) of the destination, (by, bx) of the square that
+//            must be empty (horse leg / elephant eye), flags; destination inside the kind's rectangle (board, own half,
+//            palace), not an own piece;  pawn rows differ by side (forward direction, sideways only past the river).
+//   sliders: per direction the first occupied square by find-first-set on the 9 / 10 line bits, the run of empty
+//            squares in front of it, then the capture (rook: that square if enemy; cannon: the next occupied one).
+// entry: bits 0-2 dy+2, 3-5 dx+2, 6-7 by+1, 8-9 bx+1, 10 has-block, 11 needs the source past the river, 12 valid
+#define CZD_LE(dy, dx, by, bx, blk, src) (uint32_t)(((dy) + 2) | (((dx) + 2) << 3) | (((by) + 1) << 6) | (((bx) + 1) << 8) | ((blk) << 10) | ((src) << 11) | (1u << 12))
+__constant__ uint32_t c_czd_leap[8][8] = {
+    // row 0: black pawn (p): forward = y-1; sideways below rank 5 (main.py:1063-1078)
+    {CZD_LE(-1, 0, 0, 0, 0, 0), CZD_LE(0, 1, 0, 0, 0, 1), CZD_LE(0, -1, 0, 0, 0, 1), 0, 0, 0, 0, 0},
+    // row 1: K/k (main.py:919-946): (0,-1) (0,+1) (-1,0) (+1,0)
+    {CZD_LE(0, -1, 0, 0, 0, 0), CZD_LE(0, 1, 0, 0, 0, 0), CZD_LE(-1, 0, 0, 0, 0, 0), CZD_LE(1, 0, 0, 0, 0, 0), 0, 0, 0, 0},
+    // row 2: A/a (main.py:889-918): (i,i), (i,-i) for i = -1, +1
+    {CZD_LE(-1, -1, 0, 0, 0, 0), CZD_LE(-1, 1, 0, 0, 0, 0), CZD_LE(1, 1, 0, 0, 0, 0), CZD_LE(1, -1, 0, 0, 0, 0), 0, 0, 0, 0},
+    // row 3: rook (slider, unused)
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    // row 4: B/b (main.py:857-888): (i,i) eye (i/2,i/2), (i,-i) eye (i/2,-i/2) for i = -2, +2
+    {CZD_LE(-2, -2, -1, -1, 1, 0), CZD_LE(-2, 2, -1, 1, 1, 0), CZD_LE(2, 2, 1, 1, 1, 0), CZD_LE(2, -2, 1, -1, 1, 0), 0, 0, 0, 0},
+    // row 5: N/n (main.py:835-856): for i, j in (-1,+1)^2: (2i, j) leg (i, 0), then (i, 2j) leg (0, j)
+    {CZD_LE(-2, -1, -1, 0, 1, 0), CZD_LE(-1, -2, 0, -1, 1, 0), CZD_LE(-2, 1, -1, 0, 1, 0), CZD_LE(-1, 2, 0, 1, 1, 0),
+     CZD_LE(2, -1, 1, 0, 1, 0), CZD_LE(1, -2, 0, -1, 1, 0), CZD_LE(2, 1, 1, 0, 1, 0), CZD_LE(1, 2, 0, 1, 1, 0)},
+    // row 6: red pawn (P): forward = y+1; sideways above rank 4 (main.py:1079-1095)
+    {CZD_LE(1, 0, 0, 0, 0, 0), CZD_LE(0, 1, 0, 0, 0, 1), CZD_LE(0, -1, 0, 0, 0, 1), 0, 0, 0, 0, 0},
+    // row 7: cannon (slider, unused)
+    {0, 0, 0, 0, 0, 0, 0, 0},
+};
+
+__device__ __forceinline__ int czd_gen_piece_bf(int c, int sq, int side, const CzdBoardSets &S, const uint32_t *leap, uint16_t *st) {
+    const int t = c > 7 ? c - 7 : c;     // the caller only passes pieces of the side to move
+    const int y = sq / 9, x = sq - y * 9;
+    int n = 0;
+    if (t == 3 || t == 7) {
+        const bool cannon = t == 7;
+        const unsigned row = czd_bits(S.occ, y * 9) & 0x1FFu, rowE = czd_bits(S.enemy, y * 9) & 0x1FFu;
+        const unsigned col = czd_bits(S.occT, x * 10) & 0x3FFu, colE = czd_bits(S.enemyT, x * 10) & 0x3FFu;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {   // -x, +x, -y, +y (main.py:757-833 / 947-1062)
+            const bool along_x = d < 2, neg = (d & 1) == 0;
+            const unsigned o = along_x ? row : col, e = along_x ? rowE : colE;
+            const int p = along_x ? x : y, len = along_x ? 9 : 10;
+            int hit, tgt;
+            if (neg) {
+                const unsigned m = o & ((1u << p) - 1u);
+                hit = m ? 31 - __clz(m) : -1;
+                const unsigned m2 = hit >= 0 ? o & ((1u << hit) - 1u) : 0u;
+                tgt = cannon ? (m2 ? 31 - __clz(m2) : -1) : hit;
+            } else {
+                const unsigned m = o >> (p + 1);
+                hit = m ? p + __ffs(m) : len;
+                const unsigned m2 = hit < len ? o >> (hit + 1) : 0u;
+                tgt = cannon ? (m2 ? hit + __ffs(m2) : len) : hit;
+            }
+            const int run = neg ? p - hit - 1 : hit - p - 1;
+            const bool cap = tgt >= 0 && tgt < len && ((e >> (tgt & 31)) & 1u);
+            const int step = neg ? -1 : 1;
+            // dst square of line index q: along x  y*9 + q ; along y  q*9 + x
+            const int mul = along_x ? 1 : 9, add = along_x ? y * 9 : x;
+            // at most len - 1 squares; the loop leaves (wave-uniform branch) once no lane of the wave has squares left
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (i >= len - 1 || __ballot(i < run) == 0ull) break;
+                const int q = p + step * (i + 1);
+                st[i < run ? n + i : 17] = (uint16_t)(sq | ((q * mul + add) << 8));
+            }
+            n += run;
+            st[cap ? n : 17] = (uint16_t)(sq | ((tgt * mul + add) << 8));
+            n += cap ? 1 : 0;
+        }
+        return n;
+    }
+    // leapers: the kind's rectangle
+    const bool palace = t <= 2, half = t == 4;
+    const int ylo = palace ? (side ? 7 : 0) : (half ? (side ? 5 : 0) : 0);
+    const int yhi = palace ? (side ? 9 : 2) : (half ? (side ? 9 : 4) : 9);
+    const int xlo = palace ? 3 : 0, xhi = palace ? 5 : 8;
+    const bool past_river = side ? y < 5 : y > 4;
+    const uint32_t *row = leap + ((t == 6 && side) ? 0 : t) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t e = row[k];
+        const int ty = y + (int)(e & 7u) - 2, tx = x + (int)((e >> 3) & 7u) - 2;
+        const int q = ty * 9 + tx;
+        const int bq = (y + (int)((e >> 6) & 3u) - 1) * 9 + x + (int)((e >> 8) & 3u) - 1;
+        bool ok = ((e >> 12) & 1u) && ty >= ylo && ty <= yhi && tx >= xlo && tx <= xhi;
+        const int qs = ok ? q : sq, bqs = ok ? bq : sq;   // keep the bit tests in range (a valid destination has its leg / eye on the board)
+        ok = ok && (!czd_tst(S.occ, qs) || czd_tst(S.enemy, qs));                 // validate_move, main.py:727
+        ok = ok && !(((e >> 10) & 1u) && czd_tst(S.occ, bqs));                    // leg / eye must be empty
+        ok = ok && (!((e >> 11) & 1u) || past_river);
+        st[ok ? n : 17] = (uint16_t)(sq | (q << 8));
+        n += ok ? 1 : 0;
+    }
+    return n;
+}
+
 // ---- ordered pseudo-legal move lists (GameBoard.get_legal_moves, main.py:743-1109), lane = piece ----------------------
 // A position has at most 16 pieces of the side to move, so a wave64 generates for up to FOUR positions at once: lanes
 // 16 q .. 16 q + 15 own position q, lane 16 q + s the s-th piece of the mover in scan order (ascending square = y outer,
@@ -177,6 +278,7 @@ struct CzdGroupLds {
     uint16_t pl[4][16];              // mover's pieces: sq | code << 8
     int16_t kings[4][2];             // square of 'K', 'k' (or -1)
     int16_t npc[4];
+    uint32_t leap[64];               // c_czd_leap, staged once per call
 };
 
 __device__ __forceinline__ int czd_row_excl_scan16(int v, int *total, int lane) {
@@ -195,6 +297,7 @@ __device__ __forceinline__ int czd_row_excl_scan16(int v, int *total, int lane) 
 template <int NP, int STRIDE, typename SideFn>
 __device__ __forceinline__ int czd_group_movegen(const uint8_t *b, SideFn side_of, const int16_t *lut, CzdGroupLds &G,
                                                  uint16_t *stage, uint16_t *out, int lane) {
+    G.leap[lane] = (&c_czd_leap[0][0])[lane];
     // ---- stage A (not unrolled: four copies of it only cost registers, i.e. occupancy)
 #pragma unroll 1
     for (int p = 0; p < NP; ++p) {
@@ -233,7 +336,7 @@ __device__ __forceinline__ int czd_group_movegen(const uint8_t *b, SideFn side_o
     int n = 0;
     if (live && s < npc) {
         const int pc = G.pl[qq][s];
-        n = czd_gen_piece(pc >> 8, pc & 0xFF, side, S, st);
+        n = czd_gen_piece_bf(pc >> 8, pc & 0xFF, side, S, G.leap, st);
     }
     // ---- stage C
     int total;

@@ -101,9 +101,11 @@ class Trainer:
         self.global_step = int(d.get("global_step", 0))
 
 
-def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multiplier, kl_targ, seed=0, log=print):
+def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multiplier, kl_targ, seed=0, log=print, temperature=1.0):
     """cchess_main.policy_update (main.py:1157-1204).  net: forward(list of planes) -> (logits, value) ndarrays,
     train_step(...) -> (accuracy, loss, global_step), save(step), global_step.  Returns (lr_multiplier, info dict).
+
+    data_buffer items: dense (planes, pi, z) tuples like the reference's, or packed 608-byte self-play records.
 
     Rank-consistent by construction: the mini-batch indices come from random.Random(seed, global step) — identical on
     every rank because every rank holds the same gathered buffer —, rank r trains on elements r::world of it, and the
@@ -112,9 +114,16 @@ def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multip
     rank = dist.get_rank() if _dist_on() else 0
     rng = random.Random((int(seed) << 32) ^ int(net.global_step))
     mini_batch = rng.sample(list(data_buffer), batch_size)[rank::world]   # main.py:1159 (random.sample)
-    state_batch = [d[0] for d in mini_batch]
-    mcts_probs_batch = [d[1] for d in mini_batch]
-    winner_batch = np.expand_dims([d[2] for d in mini_batch], 1)
+    if isinstance(mini_batch[0], np.ndarray) and mini_batch[0].dtype == np.uint8 and mini_batch[0].ndim == 1:
+        # the buffer holds PACKED records (608 bytes each instead of 22 KB of dense planes + pi): only the mini-batch is
+        # expanded to the reference's (state planes, pi[2086], z) tuples, pi with the reference's exact float64 expression
+        from .selfplay import to_dense
+        planes, pi, z = to_dense(np.stack(mini_batch), temperature, exact=True)
+        state_batch, mcts_probs_batch, winner_batch = list(planes), list(pi), np.expand_dims(z, 1)
+    else:
+        state_batch = [d[0] for d in mini_batch]
+        mcts_probs_batch = [d[1] for d in mini_batch]
+        winner_batch = np.expand_dims([d[2] for d in mini_batch], 1)
     start_time = time.time()
     old_probs, old_v = net.forward(state_batch)
     kl, loss, accuracy, new_v, steps = 0.0, 0.0, 0.0, old_v, 0

@@ -517,7 +517,8 @@ class cchess_main(object):
     def policy_update(self):
         from cchess_zero_amd.train import policy_update
         self.lr_multiplier, info = policy_update(self.policy_value_netowrk, self.data_buffer, self.batch_size, self.epochs,
-                                                 self.learning_rate, self.lr_multiplier, self.kl_targ, seed=self.update_seed)
+                                                 self.learning_rate, self.lr_multiplier, self.kl_targ, seed=self.update_seed,
+                                                 temperature=self.temperature)
         self.global_step = self.policy_value_netowrk.global_step
         msg = "kl:{:.5f},lr_multiplier:{:.3f},loss:{},accuracy:{},explained_var_old:{:.3f},explained_var_new:{:.3f}".format(
             info["kl"], self.lr_multiplier, info["loss"], info["accuracy"], info["explained_var_old"], info["explained_var_new"])
@@ -533,24 +534,25 @@ class cchess_main(object):
         shuffled before they enter it (so that a bounded buffer is not biased towards the last ranks' games), and the
         number of policy updates per batch grows with the number of new samples (the reference: one update of
         `batch_size` samples x `epochs` per ~100 new samples; here one per `batch_size` new samples, at most 64)."""
-        from cchess_zero_amd.selfplay import to_dense
         batch_iter = 0
         try:
             while max_batches is None or batch_iter < max_batches:
                 batch_iter += 1
                 t0 = time.time()
                 rec = self.selfplay_batch()
-                planes, pi, z = to_dense(rec, self.temperature, exact=False)
                 dt = time.time() - t0
                 st = self.last_selfplay_stats
+                n = len(rec)
                 print("batch i:{}, game slots:{}, games finished:{}, samples:{}, sims/s:{:.0f}".format(
-                    batch_iter, self.games, st["games"], len(z), self.last_selfplay_sims / max(dt, 1e-9)))
-                if self.data_buffer.maxlen < 2 * len(z):
-                    self.data_buffer = deque(self.data_buffer, maxlen=2 * len(z))
-                order = np.random.RandomState(self.update_seed + batch_iter).permutation(len(z))   # same on every rank
-                self.data_buffer.extend((planes[i], pi[i], z[i]) for i in order)
+                    batch_iter, self.games, st["games"], n, self.last_selfplay_sims / max(dt, 1e-9)))
+                if self.data_buffer.maxlen < 2 * n:
+                    self.data_buffer = deque(self.data_buffer, maxlen=2 * n)
+                # the buffer keeps the PACKED records (608 B each; the reference's dense tuple is 22 KB): policy_update
+                # expands the mini-batch it draws (cchess_zero_amd/train.py)
+                order = np.random.RandomState(self.update_seed + batch_iter).permutation(n)   # same on every rank
+                self.data_buffer.extend(rec[i] for i in order)
                 if len(self.data_buffer) > self.batch_size:
-                    for _ in range(max(1, min(64, len(z) // self.batch_size))):
+                    for _ in range(max(1, min(64, n // self.batch_size))):
                         self.policy_update()
         except KeyboardInterrupt:
             self.log_file.close()

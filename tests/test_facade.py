@@ -126,7 +126,9 @@ def test_cchess_main_selfplay_and_update(tmp_path, monkeypatch):
     # finished, records -> buffer (resized to hold two batches, shuffled), policy updates proportional to the new samples
     cm.games = 8
     step1 = cm.global_step
+    cm.data_buffer.clear()          # run() keeps PACKED records in the buffer (the dense tuples above are the reference's form)
     cm.run(max_batches=1)
+    assert all(isinstance(r, np.ndarray) and r.dtype == np.uint8 and r.shape == (608,) for r in list(cm.data_buffer)[:5])
     st = cm.last_selfplay_stats
     assert st["games"] >= 8 and st["stalled"] == 0 and st["dropped"] == 0
     assert len(cm.data_buffer) >= st["plies"] > 0 and cm.data_buffer.maxlen >= 2 * st["plies"]
