@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcchess_hip.so")
+# CCHESS_HIP_LIB: another build of the SAME library (same-box A/B of kernel changes, tools/ab_lib.sh); default: in-tree
+LIB_PATH = os.environ.get("CCHESS_HIP_LIB") or os.path.join(_HERE, "libcchess_hip.so")
 
 NLABELS = 2086
 MAXMOVES = 128

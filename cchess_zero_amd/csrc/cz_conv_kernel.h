@@ -891,22 +891,30 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         float *hw = reinterpret_cast<float *>(smem + Geo::W_OFF);
         for (int i = tid; i < 3 * 128; i += Geo::THREADS) hw[i] = head_w[i];
         __syncthreads();
-        for (int idx = tid; idx < nrows * 3; idx += Geo::THREADS) {
-            const int r = idx / 3, c3 = idx - r * 3;
+        // one thread per board cell, all three head channels: the cell's 256-byte row is read and unpacked once (the first
+        // version gave every (cell, channel) pair its own thread: three reads and unpacks of every row, 5 us per workgroup).
+        // The summation order per (cell, channel) is unchanged — chunks in a fixed order, eight products left to right —
+        // so the outputs are bit-identical to the earlier kernel and do not depend on the row's position in the batch.
+        for (int r = tid; r < nrows; r += Geo::THREADS) {
             const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
-            const float *w = hw + c3 * 128;
-            float acc = 0.f;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
 #pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int c = it;                   // fixed summation order: the result of a position does not depend on its row
+            for (int c = 0; c < 16; ++c) {
                 const int p = c ^ key;
                 const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
-                const float *wc8 = w + c * 8;
                 const f32x2 e0 = unpack_pair<F16>(v.x), e1 = unpack_pair<F16>(v.y), e2 = unpack_pair<F16>(v.z), e3 = unpack_pair<F16>(v.w);
-                acc += e0[0] * wc8[0] + e0[1] * wc8[1] + e1[0] * wc8[2] + e1[1] * wc8[3]
-                     + e2[0] * wc8[4] + e2[1] * wc8[5] + e3[0] * wc8[6] + e3[1] * wc8[7];
+                const float *w0 = hw + c * 8, *w1 = hw + 128 + c * 8, *w2 = hw + 256 + c * 8;
+                acc0 += e0[0] * w0[0] + e0[1] * w0[1] + e1[0] * w0[2] + e1[1] * w0[3]
+                      + e2[0] * w0[4] + e2[1] * w0[5] + e3[0] * w0[6] + e3[1] * w0[7];
+                acc1 += e0[0] * w1[0] + e0[1] * w1[1] + e1[0] * w1[2] + e1[1] * w1[3]
+                      + e2[0] * w1[4] + e2[1] * w1[5] + e3[0] * w1[6] + e3[1] * w1[7];
+                acc2 += e0[0] * w2[0] + e0[1] * w2[1] + e1[0] * w2[2] + e1[1] * w2[3]
+                      + e2[0] * w2[4] + e2[1] * w2[5] + e3[0] * w2[6] + e3[1] * w2[7];
             }
-            head_out[((size_t)pos0 * 90 + r) * 3 + c3] = fmaxf(acc + head_b[c3], 0.f);
+            float *o = head_out + ((size_t)pos0 * 90 + r) * 3;
+            o[0] = fmaxf(acc0 + head_b[0], 0.f);
+            o[1] = fmaxf(acc1 + head_b[1], 0.f);
+            o[2] = fmaxf(acc2 + head_b[2], 0.f);
         }
     }
 }
