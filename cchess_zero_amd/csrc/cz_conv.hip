@@ -24,6 +24,7 @@ static constexpr int kDefaultVariant = 1;
 static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
                         const float *head_b, float *head_out, int B, int nblocks, const void *planes = nullptr,
                         const void *w0 = nullptr, const float *b0 = nullptr, bool f16 = false) {
+    if (head_w && (reinterpret_cast<uintptr_t>(head_w) & 15u)) { cz_set_error("cz_net_trunk: head_w must be 16-byte aligned"); return CZ_EINVAL; }
     using namespace czconv;
     if (B == 0) return CZ_OK;
     if (!c->tower_attr_set) {

@@ -599,10 +599,12 @@ template <int P> struct T8Geo {
     static constexpr int W_OFF = ZERO_OFF + CV_ROWB;
     static constexpr int LDS_BYTES = W_OFF + TW_NBUF * SLAB_BYTES;            // 157,952 / 79,104
     static constexpr int PLANES_OFF = W_OFF + 3 * SLAB_BYTES;  // the input planes (32 B per cell) borrow ring buffer 3
+    static constexpr int HEADW_OFF = LDS_BYTES;                // head 1x1 conv weights [3][128] f32, staged at the prologue
+    static constexpr int LDS_TOTAL = LDS_BYTES + 3 * 128 * 4;  // 159,488 / 80,640 of the CU's 163,840
 };
-constexpr int T8_P = 4, T8_THREADS = T8Geo<4>::THREADS, T8_LDS_BYTES = T8Geo<4>::LDS_BYTES;
+constexpr int T8_P = 4, T8_THREADS = T8Geo<4>::THREADS, T8_LDS_BYTES = T8Geo<4>::LDS_TOTAL;
 constexpr int T8_ROWS = T8Geo<4>::ROWS, T8_ZERO_OFF = T8Geo<4>::ZERO_OFF, T8_W_OFF = T8Geo<4>::W_OFF, T8_PLANES_OFF = T8Geo<4>::PLANES_OFF;
-constexpr int T2_P = 2, T2_THREADS = T8Geo<2>::THREADS, T2_LDS_BYTES = T8Geo<2>::LDS_BYTES;
+constexpr int T2_P = 2, T2_THREADS = T8Geo<2>::THREADS, T2_LDS_BYTES = T8Geo<2>::LDS_TOTAL;
 
 // Element type of activations and weights: bf16 (F16 = false) or IEEE fp16 (F16 = true, the reference's
 // "19-block fp16" configuration); accumulation is fp32 either way and only the MFMA opcode, the pack / unpack
@@ -679,6 +681,19 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         }
     }
     if (tid < 16) *reinterpret_cast<uint4 *>(smem + Geo::ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    // the head conv weights are fetched here, behind the loads the prologue waits for anyway (the first version fetched
+    // them after the last layer: one more exposed round trip and barrier per workgroup)
+    if (head_out && tid < 3 * 128 / 4)
+        reinterpret_cast<float4 *>(smem + Geo::HEADW_OFF)[tid] = reinterpret_cast<const float4 *>(head_w)[tid];
+    // first-layer weights: requested before the wait below so that their latency overlaps the planes / ring prologue
+    bf16x8 wf[9][CV_CT];
+    if (planes != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + (lane >> 5)) * 128 + (wave & 1) * 64 + j * 32 + (lane & 31)) << 3));
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -770,12 +785,6 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     };
 
     if (planes != nullptr) {   // first layer: conv3x3(14 -> 128) + BN + ReLU, one k-step per tap
-        bf16x8 wf[9][CV_CT];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < CV_CT; ++j)
-                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + khalf) * 128 + wc * 64 + j * 32 + l31) << 3));
         f32x16 acc[CV_RT][CV_CT];
         init_acc(acc, b0, false);
 #pragma unroll
@@ -887,10 +896,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         }
     }
     if (head_out) {
-        __syncthreads();
-        float *hw = reinterpret_cast<float *>(smem + Geo::W_OFF);
-        for (int i = tid; i < 3 * 128; i += Geo::THREADS) hw[i] = head_w[i];
-        __syncthreads();
+        const float *hw = reinterpret_cast<const float *>(smem + Geo::HEADW_OFF);   // staged at the prologue
         // one thread per board cell, all three head channels: the cell's 256-byte row is read and unpacked once (the first
         // version gave every (cell, channel) pair its own thread: three reads and unpacks of every row, 5 us per workgroup).
         // The summation order per (cell, channel) is unchanged — chunks in a fixed order, eight products left to right —
