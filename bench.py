@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 128)")
     ap.add_argument("--selfplay", action="store_true", help="time the device-resident self-play loop; a step = one ply of every game")
     ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records after every ply, inside the timed region")
+    ap.add_argument("--force-dist", action="store_true", help="testing only: initialise the process group and run every collective even with a world of 1 (RCCL API check on one GPU)")
     ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
     args = ap.parse_args()
 
@@ -197,11 +198,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist
     dist = None
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.all_on_device0:
             local_rank = 0

@@ -21,6 +21,7 @@ $B --selfplay --start-position --playout 100 --steps 300 --warmup 10 --no-cpu-ba
 $B --selfplay --steps 6 --warmup 1 --no-cpu-baseline > $OUT/bench_selfplay_p1600.json 2> $OUT/bench_selfplay_p1600.err
 $B --gpus 2 --all-on-device0 --dist-backend gloo --games 1024 --selfplay --timed-gather --playout 40 --steps 120 --warmup 4 > $OUT/bench_2ranks_selfplay_gather.json 2> $OUT/bench_2ranks_selfplay_gather.err
 $B --gpus 2 --all-on-device0 --dist-backend gloo --games 2048 --steps 100 --warmup 8 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err
+$B --force-dist --dist-backend nccl --games 1024 --selfplay --timed-gather --playout 40 --steps 40 --warmup 2 --no-cpu-baseline > $OUT/bench_rccl_world1_selfplay_gather.json 2> $OUT/bench_rccl_world1.err
 for f in $OUT/bench_*.json; do echo "== $f"; python tools/jline.py $f 2>&1 | head -12; done
 bash tools/profile_round.sh $TAG/prof > $OUT/profile_round.log 2>&1
 bash tools/pmc_ubench.sh 8 > $OUT/pmc_ubench8.log 2>&1; cp gpurun_out/pmc_sq_8.json $OUT/ 2>/dev/null; tail -7 $OUT/pmc_ubench8.log | cut -c1-300
