@@ -3,16 +3,20 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it through
 torch.distributed.run, one rank per GPU; run from a bare shell (`python bench.py --gpus 2`, WORLD_SIZE unset) it
-launches the N ranks itself.  One "step" = one lock-step simulation of EVERY game tree on the rank (G simulations);
-after every `--playout` simulations the trees advance one ply (root-visit argmax -> cz_search_advance, the update_tree of
-the reference) so long runs stay in the self-play regime.  Rank 0 prints ONE JSON line.  Metric/config follow
+launches the N ranks itself.  One "step" = one lock-step of EVERY game tree on the rank: select -> one net row per tree
+-> expand/backup.  A simulation that ends on a king capture or on the 60-ply rule needs no net row (the reference returns
+before its net queue, main.py:409-416): it completes inside the select launch (--terminal-extra, default 4 per tree and
+step), so a step completes G / (1 - f) simulations, f = the share of such simulations; simulations are COUNTED from the
+per-tree device counters.  A tree that has had `--playout` simulations advances one ply (root-visit argmax ->
+cz_search_advance, the update_tree of the reference) at the next check (every 8 steps), each tree at its own pace, so long
+runs stay in the self-play regime.  Rank 0 prints ONE JSON line.  Metric/config follow
 BASELINE.json: "MCTS simulations/sec (whole node), playout=1600, 7-block net", 8192 games per GPU (configs[2]).
 
 Opt-in modes:
   --selfplay       the timed region is the whole device-resident self-play loop (cchess_zero_amd/selfplay.py: search,
                    visit-count policy, Dirichlet-noise sampling, records, re-rooting, adjudication, re-seeding of finished
-                   games); a step is then one PLY of every game (playout + 1 search steps) and sims/s counts completed
-                   simulations from the device counters.
+                   games) with asynchronous plies: a step is the same lock-step, every 8 steps the games whose search is
+                   complete move; sims/s counts completed simulations from the device counters.
   --timed-gather   (with --selfplay, N > 1) after every ply each rank drains the records of the games that finished and
                    all ranks all-gather them over RCCL inside the timed region — the exchange step of configs[3].
 
@@ -186,7 +190,9 @@ def main():
     ap.add_argument("--compact", action="store_true", help="compact evaluation batches: no net row for terminal / drawn leaves (no gain at 8192 trees: the trunk runs in rounds of 1024 rows)")
     ap.add_argument("--full-policy-fc", action="store_true", help="compute all 2086 logits per leaf (k_policy_fc) instead of folding the policy FC into the expansion")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 128)")
-    ap.add_argument("--selfplay", action="store_true", help="time the device-resident self-play loop; a step = one ply of every game")
+    ap.add_argument("--selfplay", action="store_true", help="time the device-resident self-play loop (asynchronous plies)")
+    ap.add_argument("--terminal-extra", type=int, default=4, help="terminal / drawn simulations a tree may complete inside one select launch (0: one simulation per tree and step, round-1 behaviour)")
+    ap.add_argument("--advance-every", type=int, default=8, help="steps between checks for trees that have had their playouts")
     ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records after every ply, inside the timed region")
     ap.add_argument("--force-dist", action="store_true", help="testing only: initialise the process group and run every collective even with a world of 1 (RCCL API check on one GPU)")
     ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
@@ -266,35 +272,44 @@ def main():
         ev.append(e)
 
     gather_ok = None   # N > 1: result of the (untimed) record all-gather
-    banked = [0]   # simulations completed in plies that were closed inside the timed region (k > 1 accounting)
+    banked = torch.zeros(1, dtype=torch.int64, device=dev)   # simulations of the searches closed by an advance
+    reloaded = torch.zeros(1, dtype=torch.int64, device=dev)  # games that ended and started afresh
+    start_boards = torch.from_numpy(np.tile(START, (G, 1))).to(dev)
+    start_side, start_rr = torch.zeros(G, dtype=torch.uint8, device=dev), torch.zeros(G, dtype=torch.int32, device=dev)
+    TE = max(0, args.terminal_extra) if K == 1 else 0
 
-    def advance_ply():
-        banked[0] += int(eng.status()[2].sum().item())   # one sync per ply (every `playout` steps)
-        st = eng.root_stats()
-        n = st["N"].clone()
-        cnt = (st["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
+    def advance_ready():
+        """update_tree for every tree whose search has had its playouts (or whose node pool is full): most visited child."""
+        st, _, sims, _ = eng.status()
+        ready = (sims >= playout) | ((st & 1) != 0)
+        banked.add_((sims.to(torch.int64) * ready).sum())
+        rs = eng.root_stats()
+        n = rs["N"].clone()
+        cnt = (rs["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
         n[torch.arange(128, device=dev).unsqueeze(0) >= cnt] = -1
         best = n.argmax(dim=1, keepdim=True)
-        played = st["label"].gather(1, best).squeeze(1)
-        eng.advance(played)
-        one_step(0, False)  # expand roots that were never visited
+        played = rs["label"].gather(1, best).squeeze(1)
+        eng.advance(torch.where(ready & (cnt.squeeze(1) > 0), played, torch.full_like(played, -1)))
+        # the game is over where a king has been captured or the 60-ply rule has struck (main.py:1523-1552): such a tree
+        # starts a new game from the START position, like the reference's reload (main.py:255-258,604-608) — it neither
+        # goes on "searching" a finished game nor returns to a synthetic position that loses its king in one move
+        b, _, r = eng.root_state()
+        over = ready & (~(b == 1).any(dim=1) | ~(b == 8).any(dim=1) | (r >= 60) | (cnt.squeeze(1) == 0))
+        eng.reload(over, start_boards, start_side, start_rr)
+        reloaded.add_(over.sum())
 
-    sims_in_ply = 0
     graph = [None]   # the steady-state step (4 launches, static arguments) captured as one HIP graph
 
     def run(nsteps, timed):
-        nonlocal sims_in_ply
-        for _ in range(nsteps):
-            if sims_in_ply >= playout:
-                advance_ply()
-                sims_in_ply = 0
+        for i in range(nsteps):
             # every 8th timed step runs eagerly so that HIP events can bracket the launches on their stream
             if graph[0] is not None and not (timed and step_no[0] % 8 == 0):
                 step_no[0] += 1
                 graph[0].replay()
             else:
-                one_step(1, timed)
-            sims_in_ply += K
+                one_step(1, timed)   # mode 1 also expands the roots of trees that have just advanced
+            if (i + 1) % args.advance_every == 0:
+                advance_ready()
 
     sp = None
     gather_stats = {"gathers": 0, "records": 0, "seconds": 0.0}
@@ -305,9 +320,12 @@ def main():
         sp.start(boards, side, rr)
         eng.compact = compact
 
-        def run_plies(n, timed):
-            for i in range(n):
-                sp.step_ply()
+        def run_plies(n, timed):   # n lock-steps of the asynchronous loop, in chunks so that records leave the device
+            done = 0
+            while done < n:
+                m = min(64, n - done)
+                sp.run_async(m, every=args.advance_every, terminal_extra=TE)
+                done += m
                 if timed and args.timed_gather and dist_on:
                     rec = sp.drain_device()                       # device rows of the games that just finished (syncs on the cursor)
                     t1 = time.perf_counter()
@@ -315,11 +333,13 @@ def main():
                     gather_stats["gathers"] += 1
                     gather_stats["records"] += int(counts.sum().item())   # the host looks at the result: the collective is done
                     gather_stats["seconds"] += time.perf_counter() - t1
-                elif i % 4 == 3:   # the consumer of the records: every 4 plies the finished games leave the device
+                else:   # the consumer of the records: the finished games leave the device
                     gather_stats["records"] += len(sp.drain())
         run_plies(args.warmup, False)
     else:
         eng.reset(boards, side, rr)
+        eng.set_terminal_extra(TE)
+        eng.set_sim_target(playout)
         one_step(0, False)          # MCTS_tree.main root expansion (not a simulation)
         run(args.warmup, False)
     torch.cuda.synchronize()
@@ -338,9 +358,9 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    sims0 = int(sp.sims_t.item()) if sp else int(eng.status()[2].sum().item())
+    count_sims = (lambda: sp.stats()["sims"]) if sp else (lambda: int(banked.item()) + int(eng.status()[2].sum().item()))
+    sims0 = count_sims()
     rows0, csteps0 = eng.eval_totals() if compact else (0, 0)
-    banked[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if sp:
@@ -368,8 +388,10 @@ def main():
         except Exception as e:   # the throughput number above must survive a failure of this (untimed) exchange
             gather_ok = "failed: %r" % (e,)
 
-    my_sims = (int(sp.sims_t.item()) - sims0) if sp else (banked[0] + int(eng.status()[2].sum().item()) - sims0)
-    if sp:   # the self-play loop launches through SelfPlay.step_ply: sample the kernels' durations on 16 extra, uncounted steps
+    my_sims = count_sims() - sims0
+    if sp:   # the self-play loop launches through SelfPlay.run_async: sample the kernels' durations on 16 extra, uncounted steps
+        eng.set_terminal_extra(TE)
+        eng.set_sim_target(playout)
         for _ in range(16):
             step_no[0] = 0
             one_step(1, True)
@@ -468,18 +490,20 @@ def main():
         cfg_name = "BASELINE.json configs[1]"
     else:
         cfg_name = "custom configuration"
-    cfg = {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)%s" % (G, playout, args.blocks, args.dtype, cfg_name, "; device-resident self-play loop, step = one ply" if sp else ""),
+    cfg = {"workload": "%d parallel games per GPU, playout=%d, %d-block net %s (%s)%s" % (G, playout, args.blocks, args.dtype, cfg_name, "; device-resident self-play loop, asynchronous plies" if sp else ""),
            "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits",
            "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "hip_graph": graph[0] is not None, "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
            "positions": "seeded random playouts from the start position, ply~U[0,80]",
            "nodes_per_tree": cap, "node_pool_GB": G * cap * 28 / 1e9,
            "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "per_rank_sims_per_s": per_rank,
-           "simulations_counted": total_sims, "simulations_nominal": float(G) * args.steps * world * K * ((playout) if sp else 1),
+           "simulations_counted": total_sims, "net_rows_nominal": float(G) * args.steps * world * K,
+           "simulations_per_net_row": total_sims / (float(G) * args.steps * world * K), "terminal_extra": TE, "advance_every": args.advance_every,
+           "net_rows_per_s": float(G) * args.steps * world * K / dt, "games_reloaded_rank0": int(reloaded.item()),
            "mean_leaf_depth": mean_depth, "mean_nodes_per_tree": float(nodes.float().mean().item()),
            "trees_with_error_status": bad, "status_bits": st_bits}
     if sp:
         s = sp.stats()
-        cfg["selfplay"] = {"plies_timed": args.steps, "games_finished": s["games"], "red_wins": s["red_wins"], "black_wins": s["black_wins"],
+        cfg["selfplay"] = {"steps_timed": args.steps, "games_finished": s["games"], "red_wins": s["red_wins"], "black_wins": s["black_wins"],
                            "draws": s["draws"], "records": s["plies"], "stalled_games": s["stalled"], "dropped_records": s["dropped"],
                            "game_generations": s["games"] / float(G), "timed_gather": bool(args.timed_gather and dist_on),
                            "gathers": gather_stats["gathers"], "gathered_records": gather_stats["records"],

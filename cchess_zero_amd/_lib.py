@@ -18,7 +18,7 @@ MASK_WORDS = 66
 F32, BF16, F16 = 0, 1, 2
 # one packed self-play record (include/cchess_hip.h: CZ_REC_*)
 REC_BYTES, REC_SIDE, REC_COUNT, REC_Z, REC_FLAGS, REC_PLY, REC_LABELS, REC_VISITS = 608, 90, 91, 92, 93, 94, 96, 352
-SP_STATS = ("games", "red_wins", "black_wins", "draws", "plies", "stalled", "dropped", "reserved")
+SP_STATS = ("games", "red_wins", "black_wins", "draws", "plies", "stalled", "dropped", "sims")
 
 _u8p, _u16p, _i32p, _f32p, _vp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
 
@@ -40,6 +40,7 @@ _SIGS = {
     "cz_hash": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, _vp]),
     "cz_encode_planes": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "cz_search_reset": (C.c_int, [C.c_void_p, _u8p, _u8p, _i32p, C.c_int]),
+    "cz_search_reload": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, _i32p]),
     "cz_search_select": (C.c_int, [C.c_void_p, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup": (C.c_int, [C.c_void_p, _vp, _vp, C.c_int]),
     "cz_search_expand_backup_fc": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, C.c_int]),
@@ -48,6 +49,7 @@ _SIGS = {
     "cz_search_eval_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "cz_search_set_width": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_set_sim_target": (C.c_int, [C.c_void_p, C.c_int]),
+    "cz_search_set_terminal_extra": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_select_k": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup_k": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int]),
     "cz_search_root_stats": (C.c_int, [C.c_void_p, _u16p, _i32p, _f32p, _f32p, _f32p, _u16p]),
@@ -57,8 +59,8 @@ _SIGS = {
     "cz_search_tree_dump": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "cz_selfplay_begin": (C.c_int, [C.c_void_p, C.c_int, _u8p, _u8p, _i32p]),
     "cz_selfplay_active": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
-    "cz_selfplay_choose": (C.c_int, [C.c_void_p, _f32p, _f32p, _u16p, C.c_double, C.c_float, _u16p]),
-    "cz_selfplay_adjudicate": (C.c_int, [C.c_void_p, C.c_int, _i32p]),
+    "cz_selfplay_choose": (C.c_int, [C.c_void_p, _f32p, _f32p, _u16p, C.c_double, C.c_float, C.c_int, _u16p]),
+    "cz_selfplay_adjudicate": (C.c_int, [C.c_void_p, C.c_int, _u16p, _i32p]),
     "cz_selfplay_flush": (C.c_int, [C.c_void_p, _i32p, _vp, _u8p, C.c_longlong, _vp]),
     "cz_selfplay_stats": (C.c_int, [C.c_void_p, _vp]),
     "cz_conv3x3_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),

@@ -237,6 +237,12 @@ int cz_search_set_sim_target(cz_ctx *c, int target) {
     return CZ_OK;
 }
 
+int cz_search_set_terminal_extra(cz_ctx *c, int n) {
+    CZ_REQUIRE(c && n >= 0 && n <= 64, "cz_search_set_terminal_extra: 0 <= n <= 64 required");
+    c->terminal_extra = n;
+    return CZ_OK;
+}
+
 int cz_search_select_k(cz_ctx *c, int mode, int k, const uint8_t *active, void *planes, int dtype, int channels, uint8_t *needs_eval) {
     CZ_REQUIRE(c && c->G > 0, "cz_search_select_k: call cz_search_reset first");
     CZ_REQUIRE(mode == 0 || mode == 1, "cz_search_select_k: mode must be 0 or 1");
@@ -256,7 +262,12 @@ int cz_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const
     CZ_REQUIRE(c && boards && side, "cz_search_reset: null argument");
     if (G <= 0 || G > c->max_games) { cz_set_error("cz_search_reset: G=%d outside 1..%d", G, c->max_games); return CZ_EINVAL; }
     c->G = G;
-    return czk_search_reset(c, boards, side, rr, G);
+    return czk_search_reset(c, boards, side, rr, G, nullptr);
+}
+int cz_search_reload(cz_ctx *c, const uint8_t *which, const uint8_t *boards, const uint8_t *side, const int32_t *rr) {
+    CZ_REQUIRE(c && c->G > 0, "cz_search_reload: call cz_search_reset first");
+    CZ_REQUIRE(which && boards && side, "cz_search_reload: null argument");
+    return czk_search_reset(c, boards, side, rr, c->G, which);
 }
 int cz_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int channels, uint8_t *needs_eval) {
     CZ_REQUIRE(c && c->G > 0, "cz_search_select: call cz_search_reset first");
@@ -350,15 +361,16 @@ int cz_selfplay_active(cz_ctx *c, const uint8_t **active) {
     *active = c->sp.active;
     return CZ_OK;
 }
-int cz_selfplay_choose(cz_ctx *c, const float *gamma, const float *u, const uint16_t *forced, double temperature, float eps, uint16_t *played) {
+int cz_selfplay_choose(cz_ctx *c, const float *gamma, const float *u, const uint16_t *forced, double temperature, float eps, int min_sims, uint16_t *played) {
     CZ_REQUIRE(c && c->sp_block && c->G > 0, "cz_selfplay_choose: call cz_selfplay_begin first");
     CZ_REQUIRE(u && played, "cz_selfplay_choose: u and played required");
     CZ_REQUIRE(temperature > 0.0 && eps >= 0.f && eps <= 1.f, "cz_selfplay_choose: temperature > 0 and 0 <= noise_eps <= 1 required");
-    return czk_selfplay_choose(c, gamma, u, forced, temperature, eps, played);
+    CZ_REQUIRE(min_sims >= 0, "cz_selfplay_choose: min_sims >= 0 required");
+    return czk_selfplay_choose(c, gamma, u, forced, temperature, eps, min_sims, played);
 }
-int cz_selfplay_adjudicate(cz_ctx *c, int reseed, int32_t *fin_n) {
+int cz_selfplay_adjudicate(cz_ctx *c, int reseed, const uint16_t *played, int32_t *fin_n) {
     CZ_REQUIRE(c && c->sp_block && c->G > 0 && fin_n, "cz_selfplay_adjudicate: call cz_selfplay_begin first / null fin_n");
-    return czk_selfplay_adjudicate(c, reseed, fin_n);
+    return czk_selfplay_adjudicate(c, reseed, played, fin_n);
 }
 int cz_selfplay_flush(cz_ctx *c, const int32_t *fin_n, const long long *offset, uint8_t *ring, long long ring_records, const long long *read_cursor) {
     CZ_REQUIRE(c && c->sp_block && c->G > 0, "cz_selfplay_flush: call cz_selfplay_begin first");

@@ -98,6 +98,7 @@ struct cz_ctx {
     bool conv_attr_set, tower_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1
+    int terminal_extra;   // cz_search_set_terminal_extra: terminal simulations a tree may complete inside one select launch
     int sim_target;    // cz_search_set_sim_target: completed simulations per tree a k > 1 search stops at (0: no limit)
     int step_parity;   // which evcnt entry the current compact step uses
     const int32_t *batch_count;  // cz_set_batch_count: device row count bounding the net launches, or NULL
@@ -133,7 +134,7 @@ int czk_movegen(cz_ctx *, const uint8_t *, const uint8_t *, int, uint16_t *, uin
 int czk_apply_move(cz_ctx *, uint8_t *, uint8_t *, const uint16_t *, int, uint64_t *, uint8_t *, int8_t *);
 int czk_hash(cz_ctx *, const uint8_t *, const uint8_t *, int, uint64_t *);
 int czk_encode_planes(cz_ctx *, const uint8_t *, const uint8_t *, int, void *, int, int, int);
-int czk_search_reset(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *, int);
+int czk_search_reset(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *, int, const uint8_t *which);
 int czk_search_select(cz_ctx *, int, const uint8_t *, void *, int, int, uint8_t *, bool compact = false);
 int czk_search_expand_backup(cz_ctx *, const void *, const void *, int);
 int czk_search_expand_backup_fc(cz_ctx *, const float *, const float *, const float *, const float *, bool compact);
@@ -142,6 +143,6 @@ int czk_search_advance(cz_ctx *, const uint16_t *);
 int czk_search_select_k(cz_ctx *, int, int, const uint8_t *, void *, int, int, uint8_t *);
 int czk_search_expand_backup_k(cz_ctx *, int, const void *, const void *, int);
 int czk_selfplay_seed(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *);
-int czk_selfplay_choose(cz_ctx *, const float *, const float *, const uint16_t *, double, float, uint16_t *);
-int czk_selfplay_adjudicate(cz_ctx *, int, int32_t *);
+int czk_selfplay_choose(cz_ctx *, const float *, const float *, const uint16_t *, double, float, int, uint16_t *);
+int czk_selfplay_adjudicate(cz_ctx *, int, const uint16_t *, int32_t *);
 int czk_selfplay_flush(cz_ctx *, const int32_t *, const long long *, uint8_t *, long long, const long long *);

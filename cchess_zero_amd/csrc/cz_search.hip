@@ -18,9 +18,10 @@ namespace {
 
 // ---- reset: MCTS_tree.__init__ / reload, main.py:235-259 ---------------------------------------
 __global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restrict__ boards,
-                                              const uint8_t *__restrict__ side, const int32_t *__restrict__ rr, int G) {
+                                              const uint8_t *__restrict__ side, const int32_t *__restrict__ rr, int G,
+                                              const uint8_t *__restrict__ which) {
     const int g = blockIdx.x, lane = threadIdx.x;
-    if (g >= G) return;
+    if (g >= G || (which && !which[g])) return;   // cz_search_reload: only the trees whose game is over start afresh
     for (int i = lane; i < CZD_BOARD_LDS; i += 64)
         t.root_board[(size_t)g * CZD_BOARD_LDS + i] = i < CZ_NSQ ? boards[(size_t)g * CZ_NSQ + i] : 0;
     if (lane == 0) {
@@ -44,108 +45,149 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
 // atomic counter (t.evcnt[parity]); t.slot_of[g] records the row (or -1), the other counter is zeroed for the next
 // step.  Terminal / drawn / parked trees then cost the net nothing (they are 9 % of the simulations on the bench
 // workload), and which row a tree gets does not matter: every row of the net is computed independently.
-// amdgpu_num_sgpr(80): 8192 trees are exactly 32 waves per CU; at 82 SGPRs (what hipcc picked) only 7 waves fit a SIMD
-// (MI355X_MICROARCH.md: floor(800 / (ceil(sgpr / 16) * 16 + 16))), and the 4 left-over waves per CU cost a second pass.
+// Terminal simulations complete INSIDE the selection kernel (`extra` > 0).  A simulation that ends on a king capture or
+// on the 60-ply rule (main.py:409-416) needs no net evaluation — the reference returns before push_queue — so there is no
+// reason to spend one of the net batch's rows (and a whole lock-step) on it: the wave backs the value up along the path
+// it has just walked (same float32 arithmetic as k_expand_backup), counts the simulation and starts the next descent, up
+// to `extra` times per launch, until it stands on a leaf that does need the net.  Simulations of one tree are still
+// strictly sequential, so the tree after N simulations is bit-identical to the one-simulation-per-step schedule; what
+// changes is that a step now completes 1 / (1 - f) simulations per net row (f = share of terminal simulations, 8.5 % on
+// the bench workload).  sim_target > 0 stops a tree at that many completed simulations (cz_search_set_sim_target).
 template <typename T, bool COMPACT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_select(CzTrees t, CzTables tab, int G, int mode,
-                                               const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
-                                               T one, uint8_t *__restrict__ needs_eval, int parity) {
+__device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &tab, int G, int mode,
+                                            const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                            T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
     __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t b0[CZD_BOARD_LDS];   // the root board, to restart a descent from
     __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
     __shared__ uint16_t mv[CZD_MAXMOVES];
+    __shared__ int path_s[CZ_PATH_MAX];
     __shared__ CzdGroupLds GL;
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     T *pl = planes ? planes + (size_t)g * 90 * C : nullptr;
     const bool parked = (active && !active[g]) || (t.status[g] & ~CZ_ST_BAD_ADVANCE) != 0;
-    int kind = 0, leaf = 0, depth = 0;
+    int kind = 0, leaf = 0, depth = 0, done_here = 0;
     float pend = 0.f;
     int side = t.root_side[g];
     if (!parked) {
-        for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64)
-            ((uint32_t *)b)[i] = ((const uint32_t *)(t.root_board + (size_t)g * CZD_BOARD_LDS))[i];
+        for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64) {
+            const uint32_t w = ((const uint32_t *)(t.root_board + (size_t)g * CZD_BOARD_LDS))[i];
+            ((uint32_t *)b)[i] = w;
+            ((uint32_t *)b0)[i] = w;
+        }
         __syncthreads();
         const TreeView v = view_of(t, g);
         const int root = t.root_node[g];
-        int rr = t.root_rr[g];
-        int node = root;
+        const int root_rr = t.root_rr[g], root_side = side, s0 = t.sims[g];
         // kings present on the root board ('K' = 1, 'k' = 8)
         const int c0 = b[lane], c1 = (lane + 64 < CZ_NSQ) ? b[lane + 64] : 0;
-        bool Kmiss = (__ballot(c0 == 1) | __ballot(c1 == 1)) == 0ull;
-        bool kmiss = (__ballot(c0 == 8) | __ballot(c1 == 8)) == 0ull;
-        if (v.child_begin[root] < 0) {
+        const bool Kmiss0 = (__ballot(c0 == 1) | __ballot(c1 == 1)) == 0ull;
+        const bool kmiss0 = (__ballot(c0 == 8) | __ballot(c1 == 8)) == 0ull;
+        const int rcb = v.child_begin[root];
+        if (rcb < 0) {
             kind = 3; leaf = root;  // MCTS_tree.main root expansion, main.py:475-487
         } else if (mode != 0) {
-            // One dependent HBM round trip per tree level: every lane fetches, together with the statistics of the
-            // child it scores, that child's move label and expansion record (child_begin, child_count); the
-            // winner's are then taken from its lane, so the next level starts without touching memory again.
-            int cb = v.child_begin[node], cc = v.child_count[node], nN = v.N[node];
-            for (;;) {
-                if (cb < 0) { kind = 1; leaf = node; break; }  // not in `expanded`, main.py:357
-                if (cc == 0) { if (lane == 0) t.status[g] |= CZ_ST_NO_MOVES; break; }  // max() of empty, quirk Q7
-                // select_new / get_Q_plus_U_new, main.py:108-116,158-159.  Non-root nodes on the path
-                // carry their virtual loss (N += 3, main.py:403) while their children are scored.
-                const double sq = sqrt((double)(nN + (node != root ? 3 : 0)));
-                Cand best; best.s = -INFINITY; best.i = 0x7FFFFFFF;
-                bool first_nan = false;
-                int cN[2] = {0, 0}, cBeg[2] = {-1, -1}, cCnt[2] = {0, 0}, cSd[2] = {0, 0};
-                float cP[2] = {0.f, 0.f}, cQ[2] = {0.f, 0.f};
+            // the root's own record does not change while simulations complete (the root is never backed up, quirk Q2)
+            const int rcc = v.child_count[root], rN = v.N[root];
+            int extra_left = extra;
+            for (;;) {   // one descent per iteration
+                if (sim_target > 0 && s0 + done_here >= sim_target) { kind = 0; break; }   // this tree has had its playouts
+                int rr = root_rr, node = root;
+                bool Kmiss = Kmiss0, kmiss = kmiss0;
+                side = root_side; depth = 0; kind = 0;
+                // One dependent HBM round trip per tree level: every lane fetches, together with the statistics of the
+                // child it scores, that child's move label and expansion record (child_begin, child_count); the
+                // winner's are then taken from its lane, so the next level starts without touching memory again.
+                int cb = rcb, cc = rcc, nN = rN;
+                for (;;) {
+                    if (cb < 0) { kind = 1; leaf = node; break; }  // not in `expanded`, main.py:357
+                    if (cc == 0) { if (lane == 0) t.status[g] |= CZ_ST_NO_MOVES; break; }  // max() of empty, quirk Q7
+                    // select_new / get_Q_plus_U_new, main.py:108-116,158-159.  Non-root nodes on the path
+                    // carry their virtual loss (N += 3, main.py:403) while their children are scored.
+                    const double sq = sqrt((double)(nN + (node != root ? 3 : 0)));
+                    Cand best; best.s = -INFINITY; best.i = 0x7FFFFFFF;
+                    bool first_nan = false;
+                    int cN[2] = {0, 0}, cBeg[2] = {-1, -1}, cCnt[2] = {0, 0}, cSd[2] = {0, 0};
+                    float cP[2] = {0.f, 0.f}, cQ[2] = {0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int i = lane + 64 * r;
-                    if (i < cc) {
-                        cP[r] = v.P[cb + i]; cN[r] = v.N[cb + i]; cQ[r] = v.Q[cb + i];
-                        cBeg[r] = v.child_begin[cb + i]; cCnt[r] = v.child_count[cb + i];
-                        cSd[r] = tab.srcdst[v.move[cb + i]];
+                    for (int r = 0; r < 2; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < cc) {
+                            cP[r] = v.P[cb + i]; cN[r] = v.N[cb + i]; cQ[r] = v.Q[cb + i];
+                            cBeg[r] = v.child_begin[cb + i]; cCnt[r] = v.child_count[cb + i];
+                            cSd[r] = tab.srcdst[v.move[cb + i]];
+                        }
                     }
-                }
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int i = lane + 64 * r;
-                    if (i < cc) {
-                        const float cp = 5.0f * cP[r];
-                        const double u = (double)cp * sq / (double)(1 + cN[r]);
-                        double s = (double)cQ[r] + u;
-                        if (s != s) { if (i == 0) first_nan = true; s = -INFINITY; }
-                        Cand c; c.s = s; c.i = i;
-                        best = better(best, c);
+                    for (int r = 0; r < 2; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < cc) {
+                            const float cp = 5.0f * cP[r];
+                            const double u = (double)cp * sq / (double)(1 + cN[r]);
+                            double s = (double)cQ[r] + u;
+                            if (s != s) { if (i == 0) first_nan = true; s = -INFINITY; }
+                            Cand c; c.s = s; c.i = i;
+                            best = better(best, c);
+                        }
                     }
-                }
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    Cand o; o.s = __shfl_xor(best.s, d, 64); o.i = __shfl_xor(best.i, d, 64);
-                    best = better(best, o);
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        Cand o; o.s = __shfl_xor(best.s, d, 64); o.i = __shfl_xor(best.i, d, 64);
+                        best = better(best, o);
+                    }
+                    int bi = best.i;
+                    if (__shfl((int)first_nan, 0, 64)) bi = 0;  // a NaN first element is never displaced by `>`
+                    const int c = cb + bi;
+                    const int wl = bi & 63, wr = bi >> 6;   // the winner sits in lane wl, round wr
+                    const int sd = __shfl(wr ? cSd[1] : cSd[0], wl, 64);
+                    const int nbeg = __shfl(wr ? cBeg[1] : cBeg[0], wl, 64);
+                    const int ncnt = __shfl(wr ? cCnt[1] : cCnt[0], wl, 64);
+                    const int nn = __shfl(wr ? cN[1] : cN[0], wl, 64);
+                    const int src = sd & 0xFF, dst = sd >> 8;
+                    const int cap = b[dst];
+                    __syncthreads();
+                    if (lane == 0) {
+                        b[dst] = b[src]; b[src] = 0;   // sim_do_action, main.py:671-672
+                        if (depth < CZ_PATH_MAX) { path_s[depth] = c; t.pend_path[(size_t)g * CZ_PATH_MAX + depth] = c; }
+                    }
+                    __syncthreads();
+                    side ^= 1;                  // main.py:392
+                    rr = cap ? 0 : rr + 1;      // main.py:393-396
+                    ++depth;
+                    if (cap == 1) Kmiss = true;
+                    if (cap == 8) kmiss = true;
+                    if (Kmiss || kmiss) {
+                        // main.py:409-414; `side` is the player to move at the child
+                        float value = 0.f;
+                        if (Kmiss) value = side ? 1.0f : -1.0f;
+                        if (kmiss) value = side ? -1.0f : 1.0f;
+                        kind = 2; leaf = c; pend = value * -1.0f; break;
+                    } else if (rr >= 60) {      // main.py:415-416
+                        kind = 2; leaf = c; pend = 0.f; break;
+                    }
+                    node = c; cb = nbeg; cc = ncnt; nN = nn;
                 }
-                int bi = best.i;
-                if (__shfl((int)first_nan, 0, 64)) bi = 0;  // a NaN first element is never displaced by `>`
-                const int c = cb + bi;
-                const int wl = bi & 63, wr = bi >> 6;   // the winner sits in lane wl, round wr
-                const int sd = __shfl(wr ? cSd[1] : cSd[0], wl, 64);
-                const int nbeg = __shfl(wr ? cBeg[1] : cBeg[0], wl, 64);
-                const int ncnt = __shfl(wr ? cCnt[1] : cCnt[0], wl, 64);
-                const int nn = __shfl(wr ? cN[1] : cN[0], wl, 64);
-                const int src = sd & 0xFF, dst = sd >> 8;
-                const int cap = b[dst];
-                __syncthreads();
-                if (lane == 0) { b[dst] = b[src]; b[src] = 0; }  // sim_do_action, main.py:671-672
-                __syncthreads();
-                side ^= 1;                  // main.py:392
-                rr = cap ? 0 : rr + 1;      // main.py:393-396
-                if (lane == 0 && depth < CZ_PATH_MAX) t.pend_path[(size_t)g * CZ_PATH_MAX + depth] = c;
-                ++depth;
-                if (cap == 1) Kmiss = true;
-                if (cap == 8) kmiss = true;
-                if (Kmiss || kmiss) {
-                    // main.py:409-414; `side` is the player to move at the child
-                    float value = 0.f;
-                    if (Kmiss) value = side ? 1.0f : -1.0f;
-                    if (kmiss) value = side ? -1.0f : 1.0f;
-                    kind = 2; leaf = c; pend = value * -1.0f; break;
-                } else if (rr >= 60) {      // main.py:415-416
-                    kind = 2; leaf = c; pend = 0.f; break;
+                if (!(kind == 2 && extra_left > 0 && depth <= CZ_PATH_MAX)) break;
+                // back_up_value along the path (main.py:189-194,426-435), exactly as k_expand_backup does it: lane d owns
+                // the node of level d; (W + -3) + 3 reproduces the float32 rounding of the virtual loss
+                if (lane < depth) {
+                    const int n = path_s[lane];
+                    const float x = ((depth - 1 - lane) & 1) ? pend * -1.0f : pend;
+                    float w = v.W[n];
+                    w = w + -3.0f;
+                    w = w + 3.0f;
+                    const int cnt = v.N[n] + 1;
+                    w = w + x;
+                    v.N[n] = cnt; v.W[n] = w; v.Q[n] = w / (float)cnt;
                 }
-                node = c; cb = nbeg; cc = ncnt; nN = nn;
+                ++done_here; --extra_left;
+                __threadfence_block();
+                __syncthreads();
+                for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64) ((uint32_t *)b)[i] = ((const uint32_t *)b0)[i];
+                __syncthreads();
             }
+            if (lane == 0 && done_here) t.sims[g] = s0 + done_here;
         }
     }
     int nmoves = 0;
@@ -178,6 +220,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_sel
         if (!parked) t.last_depth[g] = depth;
         if (needs_eval) needs_eval[g] = (kind == 1 || kind == 3) ? 1 : 0;
     }
+}
+
+// The two kernels around select_body.  The product step (no compaction) is capped at 80 SGPRs: 8192 trees are exactly 32
+// waves per CU, and at the 82+ SGPRs hipcc picks only 7 waves fit a SIMD (MI355X_MICROARCH.md: floor(800 / (ceil(sgpr / 16)
+// * 16 + 16))), so the 4 left-over waves per CU cost a second pass.  The compact variant (parking mode of self-play: the
+// batch is not full anyway) keeps hipcc's own allocation — under the cap it would spill to scratch.
+template <typename T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_select(CzTrees t, CzTables tab, int G, int mode,
+                                               const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                               T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
+    select_body<T, false>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
+}
+template <typename T>
+__global__ __launch_bounds__(64) void k_select_compact(CzTrees t, CzTables tab, int G, int mode,
+                                                       const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                                       T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
+    select_body<T, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
 }
 
 // ---- K5 + K6: expansion and value backup ---------------------------------------------------------
@@ -784,8 +843,8 @@ __global__ void k_root_state(CzTrees t, int G, uint8_t *__restrict__ boards, uin
 
 }  // namespace
 
-int czk_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const int32_t *rr, int G) {
-    hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, c->stream, c->t, boards, side, rr, G);
+int czk_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const int32_t *rr, int G, const uint8_t *which) {
+    hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, c->stream, c->t, boards, side, rr, G, which);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
@@ -793,10 +852,10 @@ int czk_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, cons
 int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, int dtype, int C, uint8_t *needs_eval, bool compact) {
     const uint16_t one16 = (uint16_t)(dtype == CZ_F16 ? 0x3C00 : 0x3F80);
     const int par = c->step_parity;
-#define CZ_LAUNCH_SELECT(TT, CMP, ONE)                                                                                  \
-    hipLaunchKernelGGL((k_select<TT, CMP>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (TT *)planes, C, ONE, needs_eval, par)
-    if (dtype == CZ_F32) { if (compact) CZ_LAUNCH_SELECT(float, true, 1.0f); else CZ_LAUNCH_SELECT(float, false, 1.0f); }
-    else { if (compact) CZ_LAUNCH_SELECT(uint16_t, true, one16); else CZ_LAUNCH_SELECT(uint16_t, false, one16); }
+#define CZ_LAUNCH_SELECT(KERNEL, TT, ONE)                                                                               \
+    hipLaunchKernelGGL((KERNEL<TT>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (TT *)planes, C, ONE, needs_eval, par, c->sim_target, c->terminal_extra)
+    if (dtype == CZ_F32) { if (compact) CZ_LAUNCH_SELECT(k_select_compact, float, 1.0f); else CZ_LAUNCH_SELECT(k_select, float, 1.0f); }
+    else { if (compact) CZ_LAUNCH_SELECT(k_select_compact, uint16_t, one16); else CZ_LAUNCH_SELECT(k_select, uint16_t, one16); }
 #undef CZ_LAUNCH_SELECT
     CZ_HIP(hipGetLastError());
     return CZ_OK;

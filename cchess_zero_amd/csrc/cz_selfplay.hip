@@ -70,10 +70,17 @@ __global__ __launch_bounds__(64) void k_sp_seed(CzTrees t, CzSelfplay sp, int G,
 // get_action (main.py:1337-1351) + the record append of selfplay (:1504-1518) for every active game.
 __global__ __launch_bounds__(64) void k_sp_choose(CzTrees t, CzSelfplay sp, int G, const float *__restrict__ gamma,
                                                   const float *__restrict__ u, const uint16_t *__restrict__ forced,
-                                                  double inv_temp, float eps, uint16_t *__restrict__ played) {
+                                                  double inv_temp, float eps, int min_sims, uint16_t *__restrict__ played) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     if (!sp.active[g]) { if (lane == 0) played[g] = 0xFFFF; return; }
+    // asynchronous plies (min_sims > 0): only the games whose search has had its playouts move now — or cannot go on
+    // (node pool full: the move is chosen from the visits it has; rules overflow: dropped below)
+    if (min_sims > 0 && t.sims[g] < min_sims && (t.status[g] & (CZ_ST_POOL_EXHAUSTED | CZ_ST_NO_MOVES | CZ_ST_MOVE_OVERFLOW)) == 0) {
+        if (lane == 0) played[g] = 0xFFFF;
+        return;
+    }
+    if (lane == 0) atomicAdd((unsigned long long *)&sp.stats[CZ_SP_SIMS], (unsigned long long)t.sims[g]);
     const TreeView v = view_of(t, g);
     const int root = t.root_node[g];
     const int cb = v.child_begin[root];
@@ -160,10 +167,13 @@ __global__ __launch_bounds__(64) void k_sp_choose(CzTrees t, CzSelfplay sp, int 
 // The game-end tests of selfplay (main.py:1532-1545) on the position after the move, z for every recorded ply, and —
 // reseed != 0 — MCTS_tree.reload / GameBoard.reload for the next game of the slot (:1549-1551, :1494).
 // fin_n[g] = number of records the finished game hands to the ring (0: not finished, or dropped).
-__global__ __launch_bounds__(64) void k_sp_adjudicate(CzTrees t, CzSelfplay sp, int G, int reseed, int32_t *__restrict__ fin_n) {
+__global__ __launch_bounds__(64) void k_sp_adjudicate(CzTrees t, CzSelfplay sp, int G, int reseed, const uint16_t *__restrict__ played,
+                                                      int32_t *__restrict__ fin_n) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     if (!sp.active[g]) { if (lane == 0) fin_n[g] = 0; return; }
+    // asynchronous plies: only the slots that just moved (or stalled) can have ended their game
+    if (played && played[g] == 0xFFFF && !sp.stalled[g]) { if (lane == 0) fin_n[g] = 0; return; }
     const uint8_t *rb = t.root_board + (size_t)g * CZD_BOARD_LDS;
     const int c0 = rb[lane], c1 = (lane + 64 < CZ_NSQ) ? rb[lane + 64] : 0;
     const bool Kmiss = (__ballot(c0 == 1) | __ballot(c1 == 1)) == 0ull;
@@ -224,14 +234,14 @@ int czk_selfplay_seed(cz_ctx *c, const uint8_t *boards, const uint8_t *side, con
 }
 
 int czk_selfplay_choose(cz_ctx *c, const float *gamma, const float *u, const uint16_t *forced, double temperature, float eps,
-                        uint16_t *played) {
-    hipLaunchKernelGGL(k_sp_choose, dim3(c->G), dim3(64), 0, c->stream, c->t, c->sp, c->G, gamma, u, forced, 1.0 / temperature, eps, played);
+                        int min_sims, uint16_t *played) {
+    hipLaunchKernelGGL(k_sp_choose, dim3(c->G), dim3(64), 0, c->stream, c->t, c->sp, c->G, gamma, u, forced, 1.0 / temperature, eps, min_sims, played);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
 
-int czk_selfplay_adjudicate(cz_ctx *c, int reseed, int32_t *fin_n) {
-    hipLaunchKernelGGL(k_sp_adjudicate, dim3(c->G), dim3(64), 0, c->stream, c->t, c->sp, c->G, reseed, fin_n);
+int czk_selfplay_adjudicate(cz_ctx *c, int reseed, const uint16_t *played, int32_t *fin_n) {
+    hipLaunchKernelGGL(k_sp_adjudicate, dim3(c->G), dim3(64), 0, c->stream, c->t, c->sp, c->G, reseed, played, fin_n);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

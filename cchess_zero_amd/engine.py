@@ -79,6 +79,19 @@ class SearchEngine:
         self.compact = False
         self.planes = None
         self.need = None
+        self.terminal_extra = 0
+
+    def set_terminal_extra(self, n):
+        """Terminal simulations (king captured / 60-ply rule: no net evaluation needed, main.py:409-416) a tree may complete
+        inside one select launch before it presents a leaf that does need the net (cz_search_set_terminal_extra).  Trees
+        stay bit-identical; a lock-step then completes more than one simulation per net row.  Width 1 only."""
+        assert self.width == 1 or int(n) == 0, "terminal_extra applies to the one-simulation-per-tree select"
+        check(lib().cz_search_set_terminal_extra(self.ctx.h, int(n)), "cz_search_set_terminal_extra")
+        self.terminal_extra = int(n)
+
+    def set_sim_target(self, target):
+        """Trees stop at `target` completed simulations since their last reset / advance (0: no limit)."""
+        check(lib().cz_search_set_sim_target(self.ctx.h, int(target)), "cz_search_set_sim_target")
 
     # -- tree lifecycle ------------------------------------------------------------------------
     def reset(self, boards, side, rr=None):
@@ -95,6 +108,24 @@ class SearchEngine:
             self.planes = torch.zeros((G * self.width, 9, 10, self.channels), dtype=self.plane_dtype, device=self.dev)
             self.need = torch.zeros(G * self.width, dtype=torch.uint8, device=self.dev)
         self._keep = (boards, side, rr_t)
+
+    def reload(self, which, boards, side, rr=None):
+        """MCTS_tree.reload / GameBoard.reload for the games that are over (main.py:255-258,604-608): trees with
+        which[g] != 0 start afresh from boards[g] / side[g] / rr[g] ([G] arrays), the others are untouched."""
+        self.ctx.bind_stream()
+        which = self._dev_u8(which)
+        boards = self._dev_u8(boards).reshape(-1, NSQ)
+        side = self._dev_u8(side)
+        assert which.numel() == self.G and boards.shape[0] == self.G and side.numel() == self.G
+        rr_t = None
+        if rr is not None:
+            rr_t = torch.as_tensor(np.ascontiguousarray(rr, np.int32) if not torch.is_tensor(rr) else rr).to(self.dev).to(torch.int32).contiguous()
+        check(lib().cz_search_reload(self.ctx.h, _ptr(which), _ptr(boards), _ptr(side), _ptr(rr_t)), "cz_search_reload")
+
+    def _dev_u8(self, x):
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(np.ascontiguousarray(x).astype(np.uint8))
+        return x.to(self.dev).to(torch.uint8).contiguous()
 
     def select(self, mode=1, active=None, k=None):
         """-> (leaf planes [G*k,9,10,C] device tensor, needs_eval [G*k] u8 device tensor); k <= width descents per
@@ -258,10 +289,41 @@ class SearchEngine:
         per-tree budget (cz_search_set_sim_target) and a few extra steps make up for it.  Returns the number of steps."""
         playouts = int(playouts)
         self.step(forward, mode=0, active=active)
-        if self.width == 1:
+        if self.width == 1 and self.terminal_extra == 0:
             for _ in range(playouts):
                 self.step(forward, mode=1, active=active)
             return playouts
+        if self.width == 1:
+            # terminal simulations complete inside the select launches: a tree needs one lock-step per simulation that
+            # needs the net, so the search is over when every tree has counted `playouts` (checked every 32 steps)
+            base = self.status()[2]
+            if not bool((base == base[0]).all().item()):   # stacked searches on unequal counters: the plain schedule
+                extra = self.terminal_extra
+                self.set_terminal_extra(0)
+                try:
+                    for _ in range(playouts):
+                        self.step(forward, mode=1, active=active)
+                finally:
+                    self.set_terminal_extra(extra)
+                return playouts
+            target = int(base[0].item()) + playouts
+            act = None if active is None or isinstance(active, C.c_void_p) else torch.as_tensor(active).to(self.dev).bool()
+            steps = 0
+            self.set_sim_target(target)
+            try:
+                while steps < playouts:
+                    for _ in range(min(32, playouts - steps)):
+                        self.step(forward, mode=1, active=active)
+                        steps += 1
+                    st, _, sims, _ = self.status()
+                    live = (st & ~8) == 0
+                    if act is not None:
+                        live = live & act
+                    if not bool(((sims < target) & live).any().item()):
+                        break
+            finally:
+                self.set_sim_target(0)
+            return steps
         base = self.status()[2].clone()      # searches may be stacked on one root: the target is relative
         check(lib().cz_search_set_sim_target(self.ctx.h, 0), "cz_search_set_sim_target")
         # per-tree targets differ only if `base` does; the kernel takes one number, so stacked searches on trees with

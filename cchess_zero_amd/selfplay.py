@@ -159,7 +159,6 @@ class SelfPlay:
         self.cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)       # records ever handed to the ring
         self.read_cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)  # records the host has drained
         self._read = 0
-        self.sims_t = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.played = torch.empty(G, dtype=torch.int16, device=self.dev)
         self.fin_n = torch.zeros(G, dtype=torch.int32, device=self.dev)
         self._alpha = torch.full((G, MAXMOVES), 0.3, dtype=torch.float32, device=self.dev)
@@ -170,10 +169,16 @@ class SelfPlay:
     def step_ply(self, forward=None, forced=None):
         """Search, choose, record, advance, adjudicate, flush — all enqueued, nothing synchronised.
         forced: int16/uint16 [G] labels overriding the sampled moves (0xFFFF = sample), for replaying recorded games."""
-        eng, h = self.eng, self.eng.ctx.h
+        eng = self.eng
         fwd = forward or self.net.forward_device
         eng.search(fwd, self.playouts, active=None if self.continuous else self._active_ptr)
-        self.sims_t += eng.status()[2].sum()            # completed simulations of this ply (device counter)
+        self._transition(0, forced)
+        self.plies += 1
+
+    def _transition(self, min_sims, forced=None):
+        """choose / advance / adjudicate / flush for every game (min_sims = 0) or for the games whose search has completed
+        min_sims simulations (asynchronous plies)."""
+        eng, h = self.eng, self.eng.ctx.h
         gamma = None
         if self.exploration:   # np.random.dirichlet(0.3 * ones(k)) = normalised Gamma(0.3) variates, main.py:1346
             gamma = torch._standard_gamma(self._alpha, generator=self.gen)
@@ -184,19 +189,40 @@ class SelfPlay:
         vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         eng.ctx.bind_stream()
         check(lib().cz_selfplay_choose(h, vp(gamma), vp(u), vp(f), self.temperature, 0.25 if self.exploration else 0.0,
-                                       vp(self.played)), "cz_selfplay_choose")
+                                       int(min_sims), vp(self.played)), "cz_selfplay_choose")
         eng.advance(self.played)
-        check(lib().cz_selfplay_adjudicate(h, 1 if self.continuous else 0, vp(self.fin_n)), "cz_selfplay_adjudicate")
+        check(lib().cz_selfplay_adjudicate(h, 1 if self.continuous else 0, vp(self.played) if min_sims > 0 else None,
+                                           vp(self.fin_n)), "cz_selfplay_adjudicate")
         csum = torch.cumsum(self.fin_n, 0, dtype=torch.int64)
         offset = csum - self.fin_n + self.cursor
         check(lib().cz_selfplay_flush(h, vp(self.fin_n), vp(offset), vp(self.ring), self.ring.shape[0], vp(self.read_cursor)),
               "cz_selfplay_flush")
         self.cursor += csum[-1:]
-        self.plies += 1
 
     def run(self, plies, forward=None):
         for _ in range(int(plies)):
             self.step_ply(forward)
+
+    def run_async(self, steps, forward=None, every=8, terminal_extra=4):
+        """ASYNCHRONOUS plies (continuous mode): `steps` lock-steps of the net, every game at its own pace.  Each step is
+        one select / net / expand for all slots; every `every` steps the games whose search has completed its `playouts`
+        simulations choose, move, are adjudicated and — if finished — re-seeded.  With terminal_extra > 0 simulations
+        that end on terminal / drawn leaves complete inside the select launch without a net row, so a game finishes its
+        search in fewer steps than it has playouts and the net batch is never spent on leaves that need no evaluation.
+        Per tree the simulations are the same sequence as in lock-step plies (trees bit-identical for the same evaluations)."""
+        assert self.continuous, "asynchronous plies re-seed finished slots at once"
+        eng = self.eng
+        fwd = forward or self.net.forward_device
+        eng.set_terminal_extra(terminal_extra)
+        eng.set_sim_target(self.playouts)
+        try:
+            for i in range(int(steps)):
+                eng.step(fwd, mode=1)            # an unexpanded root (fresh game, new ply) is expanded by this step
+                if (i + 1) % every == 0:
+                    self._transition(self.playouts)
+        finally:
+            eng.set_sim_target(0)
+            eng.set_terminal_extra(0)
 
     def play(self, forward=None, max_plies=None):
         """continuous=False: play until every game has ended (or max_plies plies); returns the drained records.
@@ -246,7 +272,7 @@ class SelfPlay:
         self.eng.ctx.bind_stream()
         check(lib().cz_selfplay_stats(self.eng.ctx.h, C.c_void_p(self._stats.data_ptr())), "cz_selfplay_stats")
         s = self._stats.cpu().numpy()
-        d = {k: int(v) for k, v in zip(SP_STATS, s) if k != "reserved"}
-        d["sims"] = int(self.sims_t.item())
+        d = {k: int(v) for k, v in zip(SP_STATS, s)}
+        d["sims"] += int(self.eng.status()[2].sum().item())   # + the simulations of the searches in progress
         d["plies_played"] = self.plies
         return d

@@ -80,6 +80,7 @@ extern "C" {
 #define CZ_SP_PLIES 4      /* records handed to the ring */
 #define CZ_SP_STALLED 5    /* games dropped because the root had no child to play (node pool exhausted) */
 #define CZ_SP_DROPPED 6    /* records dropped because the ring was full */
+#define CZ_SP_SIMS 7       /* simulations of the searches behind the moves played so far */
 
 typedef struct cz_ctx cz_ctx;
 
@@ -130,6 +131,11 @@ int cz_encode_planes(cz_ctx *, const uint8_t *boards, const uint8_t *side, int G
  * replaces: MCTS_tree.__init__/reload (main.py:235-259): fresh, unexpanded roots. */
 int cz_search_reset(cz_ctx *, const uint8_t *root_boards, const uint8_t *root_side,
                     const int32_t *restrict_round /* may be NULL = 0 */, int G);
+/* replaces: MCTS_tree.reload / GameBoard.reload when a game is over (main.py:255-258,604-608,1494,1552): the trees g with
+ *   which[g] != 0 start afresh (unexpanded root, no simulations) from root_boards[g] / root_side[g] / restrict_round[g]
+ *   ([G] arrays like cz_search_reset's; restrict_round may be NULL = 0); every other tree is left untouched. */
+int cz_search_reload(cz_ctx *, const uint8_t *which, const uint8_t *root_boards, const uint8_t *root_side,
+                     const int32_t *restrict_round);
 /* K4 (+K1,K2,K3 on the leaf)  replaces one start_tree_search descent, main.py:350-418
  *   (select_new :158, get_Q_plus_U_new :108-116, kill-move/restrict_round :393-396, terminal
  *   tests :409-416, generate_inputs :362, get_legal_moves :374) with search_threads = 1.
@@ -178,6 +184,13 @@ int cz_search_set_width(cz_ctx *, int width);
  * ceil(playouts / k) + a few steps ends with EXACTLY `playouts` simulations per tree like MCTS_tree.main (main.py:489-493:
  * `playouts` coroutines, at most search_threads of them in flight).  0 = no limit (default). */
 int cz_search_set_sim_target(cz_ctx *, int target);
+/* cz_search_set_terminal_extra: a simulation that ends on a king capture or on the 60-ply rule needs no net evaluation
+ * (main.py:409-416 returns before push_queue).  With n > 0, cz_search_select[_compact] completes up to n such simulations
+ * per tree inside the launch (value backed up along the path, simulation counted) and goes on to the next descent, so that
+ * every tree presents a leaf that DOES need the net: a lock-step then completes 1 / (1 - f) simulations per net row.
+ * Simulations of one tree stay strictly sequential: the tree after N simulations is bit-identical to the n = 0 schedule.
+ * Use cz_search_set_sim_target (also honoured by cz_search_select) to stop every tree at exactly N.  Default 0. */
+int cz_search_set_terminal_extra(cz_ctx *, int n);
 int cz_search_select_k(cz_ctx *, int mode, int k, const uint8_t *active, void *leaf_planes, int dtype,
                        int channels, uint8_t *needs_eval);
 int cz_search_expand_backup_k(cz_ctx *, int k, const void *logits, const void *value, int dtype);
@@ -211,10 +224,13 @@ int cz_search_tree_dump(cz_ctx *, int g, int32_t *host_out, int max_records);
  *   60-ply no-capture rule).
  * cz_selfplay_choose: gamma [G][128] f32 Gamma(0.3, 1) variates (normalised per game = Dirichlet(0.3), main.py:1346) or
  *   NULL, u [G] f32 uniforms in [0, 1), forced [G] labels overriding the sampled move (0xFFFF = none; NULL) for replaying
- *   recorded games; temperature as in get_action; noise_eps = 0.25 when exploring, 0 otherwise.  played [G] out
- *   (0xFFFF for parked games and for games whose root has no child).
+ *   recorded games; temperature as in get_action; noise_eps = 0.25 when exploring, 0 otherwise.  min_sims = 0: every
+ *   active game moves (lock-step plies); min_sims > 0: only the games whose current search has completed that many
+ *   simulations (or whose tree cannot go on) move — asynchronous plies, every game at its own pace.  played [G] out
+ *   (0xFFFF for parked games, for games that do not move now and for games whose root has no child).
  * cz_selfplay_adjudicate: reseed != 0: a finished slot starts a new game at once; 0: it is parked (cz_selfplay_active
- *   turns 0).  fin_n [G] out: records the finished game contributes (0 otherwise).
+ *   turns 0).  played: the array cz_selfplay_choose filled (slots that did not move are skipped) or NULL (all slots).
+ *   fin_n [G] out: records the finished game contributes (0 otherwise).
  * cz_selfplay_flush: offset [G] int64 = first ring index (before the modulo) of each finished game, i.e. an exclusive
  *   prefix sum of fin_n on top of the running cursor, computed by the caller; ring [ring_records][CZ_REC_BYTES];
  *   read_cursor: device int64 the caller advances after draining (records that would overwrite undrained ones are
@@ -224,8 +240,8 @@ int cz_selfplay_begin(cz_ctx *, int max_plies, const uint8_t *start_boards, cons
                       const int32_t *start_rr);
 int cz_selfplay_active(cz_ctx *, const uint8_t **active_dev /* [G] */);
 int cz_selfplay_choose(cz_ctx *, const float *gamma, const float *u, const uint16_t *forced, double temperature,
-                       float noise_eps, uint16_t *played);
-int cz_selfplay_adjudicate(cz_ctx *, int reseed, int32_t *fin_n);
+                       float noise_eps, int min_sims, uint16_t *played);
+int cz_selfplay_adjudicate(cz_ctx *, int reseed, const uint16_t *played, int32_t *fin_n);
 int cz_selfplay_flush(cz_ctx *, const int32_t *fin_n, const long long *offset, uint8_t *ring, long long ring_records,
                       const long long *read_cursor);
 int cz_selfplay_stats(cz_ctx *, long long *stats_dev);

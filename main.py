@@ -500,15 +500,19 @@ class cchess_main(object):
                       seed=base_seed + 7919 * rank, continuous=True)
         b0 = np.tile(state_to_board(START_STATE), (G, 1))
         sp.start(b0, np.zeros(G, np.uint8), np.zeros(G, np.int32))
+        # asynchronous plies: every game moves when ITS search has had its playouts (simulations that end on a king capture
+        # or the 60-ply rule complete inside the select launch and use no net row, so searches differ in length)
         chunks, plies = [], 0
+        steps_per_ply = self.playout_counts + 1
+        every = max(1, min(8, self.playout_counts // 16))
         while True:
-            sp.step_ply()
-            plies += 1
-            if plies % 8 == 0 or (max_plies is not None and plies >= max_plies):
-                chunks.append(sp.drain_device().clone())
-                st = sp.stats()
-                if st["games"] >= target or (max_plies is not None and plies >= max_plies):
-                    break
+            n = 8 if max_plies is None else max(1, min(8, max_plies - plies))
+            sp.run_async(n * steps_per_ply, every=every, terminal_extra=4)
+            plies += n
+            chunks.append(sp.drain_device().clone())
+            st = sp.stats()
+            if st["games"] >= target or (max_plies is not None and plies >= max_plies):
+                break
         self.last_selfplay_stats = sp.stats()
         self.last_selfplay_sims = self.last_selfplay_stats["sims"]
         rec = torch.cat(chunks, 0) if chunks else sp.ring[:0]

@@ -194,3 +194,163 @@ def test_compact_batches_give_identical_trees(rules_golden):
     rows, steps = engs[1].eval_totals()
     assert steps == 41 and 0 < rows < 41 * G      # fewer rows than trees x steps: some leaves needed no evaluation
     print("compact batches: %d rows for %d tree-steps (%.1f %%)" % (rows, 41 * G, 100.0 * rows / (41 * G)))
+
+
+def _run_to_target(eng, fwds, playouts, extra):
+    """Lock-steps with per-row fake nets until every tree has counted `playouts` simulations; returns the step count."""
+    G = eng.e.G
+    eng.e.set_terminal_extra(extra)
+    eng.e.set_sim_target(playouts)
+    steps = 0
+    try:
+        # root expansion first (MCTS_tree.main, main.py:475-487), like SearchEngine.search
+        for mode in [0] + [1] * (playouts + 2):
+            if mode == 1 and np.all(eng.e.status()[2].cpu().numpy() >= playouts):
+                break
+            planes, need = eng.select(mode)
+            logits = np.zeros((G, 2086), np.float32)
+            value = np.zeros((G, 1), np.float32)
+            for g in range(G):
+                if need[g]:
+                    lg, v = fwds[g](planes[g])
+                    logits[g], value[g] = lg[0], v[0]
+            eng.expand_backup(logits, value)
+            steps += mode
+    finally:
+        eng.e.set_sim_target(0)
+        eng.e.set_terminal_extra(0)
+    return steps
+
+
+@pytest.mark.parametrize("extra", [1, 3])
+def test_terminal_simulations_complete_inside_select_golden(mcts_golden, extra):
+    """cz_search_set_terminal_extra: simulations that end on a king capture / the 60-ply rule are backed up inside the select
+    launch and the tree goes on to its next descent.  The trees must still be the UNMODIFIED reference's (golden root
+    children, whole-tree digests, number and order of net evaluations) — with fewer lock-steps than playouts wherever such
+    simulations occur."""
+    cases = mcts_golden["cases"]
+    by_playouts = {}
+    for c in cases:
+        by_playouts.setdefault(c["plies"][0]["playouts"], []).append(c)
+    saved = 0
+    for playouts, group in sorted(by_playouts.items()):
+        G = len(group)
+        logs = [[] for _ in range(G)]
+        fwds = [fakenet.make_forward(c["mode"], c["salt"], logs[i]) for i, c in enumerate(group)]
+        boards = np.stack([searchdrive.fen_to_board(c["plies"][0]["state"]) for c in group])
+        side = np.array([1 if c["plies"][0]["player"] == "b" else 0 for c in group], np.uint8)
+        rr = np.array([c["plies"][0]["rr"] for c in group], np.int32)
+        eng = _HipEngine(G)
+        eng.reset(boards, side, rr)
+        steps = _run_to_target(eng, fwds, playouts, extra)
+        assert steps <= playouts
+        saved += playouts - steps
+        st = eng.root_stats()
+        sims = eng.e.status()[2].cpu().numpy()
+        assert np.all(sims == playouts)
+        for g, c in enumerate(group):
+            gp = c["plies"][0]
+            n = int(st["count"][g])
+            root = [(int(st["label"][g, i]), int(st["N"][g, i]), int(st["W"][g, i].view(np.uint32)),
+                     int(st["Q"][g, i].view(np.uint32)), int(st["P"][g, i].view(np.uint32))) for i in range(n)]
+            assert root == [tuple(x) for x in gp["root"]], c["name"]
+            rec = eng.tree_dump(g)
+            assert len(rec) == gp["tree_records"] and searchdrive.tree_digest(rec) == gp["tree_sha256"], c["name"]
+            assert len(logs[g]) == gp["evals"], c["name"]
+            assert ["%016x" % k for k in logs[g]] == c["eval_keys"][:gp["evals"]], c["name"]
+    print("terminal_extra=%d: %d lock-steps saved over the golden cases" % (extra, saved))
+    assert saved > 0
+
+
+def test_terminal_extra_vs_oracle_batch(rules_golden):
+    """256 trees, many of them near the 60-ply limit (every non-capturing leaf a draw): the device search with terminal
+    simulations completing inside select against the oracle's plain one-simulation-per-step schedule — identical trees
+    after the same number of simulations, in fewer lock-steps."""
+    from oracle import oracle as O
+    g = rules_golden
+    ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
+    idx = np.nonzero(ok)[0][::11][:256]
+    G, playouts = len(idx), 60
+    boards, side = g["boards"][idx], g["side"][idx]
+    rr = (np.arange(G) * 7 % 61).astype(np.int32)
+    rr[::3] = 58
+    hip = _HipEngine(G, 20000)
+    orc = O.Search(G, 20000)
+    hip.reset(boards, side, rr)
+    orc.reset(boards, side, rr)
+    fwd = fakenet.make_forward("signed", 31)
+    for step in range(playouts + 1):
+        op, on = orc.select(0 if step == 0 else 1)
+        lg, v = fwd(op)
+        orc.expand_backup(lg, v)
+    hip.e.set_terminal_extra(2)
+    hip.e.set_sim_target(playouts)
+    busy_steps = 0   # lock-steps x trees still searching: G * playouts with one simulation per tree and step
+    for mode in [0] + [1] * playouts:
+        busy = (hip.e.status()[2].cpu().numpy() < playouts) & (hip.status() & ~8 == 0)
+        if mode == 1 and not busy.any():
+            break
+        hp, hn = hip.select(mode)
+        lg, v = fwd(hp)
+        hip.expand_backup(lg, v)
+        busy_steps += mode * int(busy.sum())
+    hip.e.set_sim_target(0)
+    hip.e.set_terminal_extra(0)
+    assert busy_steps < 0.9 * G * playouts
+    hs, os_ = hip.root_stats(), orc.root_stats()
+    for k in ("label", "N", "count"):
+        assert np.array_equal(hs[k], os_[k]), k
+    for k in ("Q", "P", "W"):
+        assert np.array_equal(hs[k].view(np.uint32), os_[k].view(np.uint32)), k
+    assert np.array_equal(hip.status(), orc.status()[0])
+    assert np.array_equal(hip.e.status()[2].cpu().numpy(), orc.status()[2])
+    for t in range(0, G, 9):
+        assert np.array_equal(hip.tree_dump(t), orc.tree_dump(t)), t
+    print("terminal_extra=2 on %d trees: %d tree-steps instead of %d" % (G, busy_steps, G * playouts))
+
+
+def test_reload_restarts_only_the_chosen_trees(rules_golden):
+    """cz_search_reload (MCTS_tree.reload for the games that are over): the chosen trees become fresh roots at the given
+    positions — their next search equals a fresh oracle search — and every other tree keeps every node."""
+    from oracle import oracle as O
+    g = rules_golden
+    ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
+    idx = np.nonzero(ok)[0][::37][:24]
+    G = len(idx)
+    boards, side = g["boards"][idx], g["side"][idx]
+    rr = (np.arange(G) * 5 % 50).astype(np.int32)
+    fwd = fakenet.make_forward("pos", 7)
+
+    def search(e, n):
+        for step in range(n + 1):
+            p, _ = e.select(0 if step == 0 else 1)
+            lg, v = fwd(p)
+            e.expand_backup(lg, v)
+
+    hip = _HipEngine(G, 8000)
+    hip.reset(boards, side, rr)
+    search(hip, 20)
+    before = [hip.tree_dump(t) for t in range(G)]
+    which = np.zeros(G, np.uint8)
+    which[[1, 4, 5, 17]] = 1
+    nb, ns, nr = np.roll(boards, 3, axis=0), np.roll(side, 3), np.roll(rr, 3)
+    hip.e.reload(which, nb, ns, nr)
+    sims = hip.e.status()[2].cpu().numpy()
+    assert np.array_equal(sims, np.where(which, 0, 20))
+    for t in range(G):
+        if not which[t]:
+            assert np.array_equal(hip.tree_dump(t), before[t]), t
+    rb, rs, rrr = (x.cpu().numpy() for x in hip.e.root_state())
+    assert np.array_equal(rb, np.where(which[:, None] != 0, nb, boards)) and np.array_equal(rs, np.where(which, ns, side))
+    assert np.array_equal(rrr, np.where(which, nr, rr))
+    # the reloaded trees search like fresh ones; the others go on from where they were (30 simulations with the oracle)
+    mask = which.astype(bool)
+    for step in range(13):
+        p, _ = hip.select(0 if step == 0 else 1, mask=mask)
+        lg, v = fwd(p)
+        hip.expand_backup(lg, v)
+    orc = O.Search(G, 8000)
+    orc.reset(nb, ns, nr)
+    search(orc, 12)
+    for t in np.nonzero(which)[0]:
+        assert np.array_equal(hip.tree_dump(int(t)), orc.tree_dump(int(t))), t

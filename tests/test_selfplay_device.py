@@ -117,3 +117,27 @@ def test_full_node_pool_recovers_at_the_advance():
         from cchess_zero_amd.selfplay import unpack_records
         u = unpack_records(rec)
         assert np.all(u["counts"] > 0) and np.all(u["visits"].astype(np.int64).sum(axis=1) > 0)
+
+
+def test_asynchronous_plies_keep_records_well_formed():
+    """SelfPlay.run_async: every game moves at its own pace (when its search has completed `playouts` simulations), terminal
+    simulations complete inside the select launches.  The records must be the same kind of tuples as with lock-step plies:
+    every root searched with exactly `playouts` simulations on top of the kept subtree."""
+    G, playouts = 96, 6
+    net, eng, sp = _setup(G, 4096, playouts)
+    recs = []
+    for chunk in range(12):
+        sp.run_async(150, every=4, terminal_extra=2)
+        recs.append(sp.drain())
+    st = sp.stats()
+    rec = np.concatenate(recs, axis=0)
+    print("asynchronous plies: 1800 steps x %d slots: %d games finished, %d records, %d sims (%.3f per net row)" %
+          (G, st["games"], st["plies"], st["sims"], st["sims"] / (1800.0 * G)))
+    assert st["stalled"] == 0 and st["dropped"] == 0 and st["games"] >= G // 2
+    assert st["games"] == st["red_wins"] + st["black_wins"] + st["draws"] and st["plies"] == len(rec)
+    assert not bool(eng.status()[0].any())
+    assert _check_records(rec, playouts) == st["games"]
+    # simulations: every move played had its full search; a lock-step completes at least one simulation per tree that is
+    # not waiting for its move, and more than one where terminal simulations completed inside select
+    assert st["sims"] >= st["plies"] * playouts
+    assert int(eng.status()[2].max().item()) <= playouts
