@@ -17,7 +17,7 @@ Opt-in modes:
                    visit-count policy, Dirichlet-noise sampling, records, re-rooting, adjudication, re-seeding of finished
                    games) with asynchronous plies: a step is the same lock-step, every 8 steps the games whose search is
                    complete move; sims/s counts completed simulations from the device counters.
-  --timed-gather   (with --selfplay, N > 1) after every ply each rank drains the records of the games that finished and
+  --timed-gather   (with --selfplay, N > 1) every 64 lock-steps each rank drains the records of the games that finished and
                    all ranks all-gather them over RCCL inside the timed region — the exchange step of configs[3].
 
 Inputs are synthetic: seeded random-playout positions generated on the GPU with the rules kernels,
@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--selfplay", action="store_true", help="time the device-resident self-play loop (asynchronous plies)")
     ap.add_argument("--terminal-extra", type=int, default=4, help="terminal / drawn simulations a tree may complete inside one select launch (0: one simulation per tree and step, round-1 behaviour)")
     ap.add_argument("--advance-every", type=int, default=8, help="steps between checks for trees that have had their playouts")
-    ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records after every ply, inside the timed region")
+    ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records every 64 lock-steps, inside the timed region")
     ap.add_argument("--force-dist", action="store_true", help="testing only: initialise the process group and run every collective even with a world of 1 (RCCL API check on one GPU)")
     ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
     args = ap.parse_args()
@@ -298,6 +298,7 @@ def main():
         eng.reload(over, start_boards, start_side, start_rr)
         reloaded.add_(over.sum())
 
+    steps_since_reset = [0]
     graph = [None]   # the steady-state step (4 launches, static arguments) captured as one HIP graph
 
     def run(nsteps, timed):
@@ -308,7 +309,9 @@ def main():
                 graph[0].replay()
             else:
                 one_step(1, timed)   # mode 1 also expands the roots of trees that have just advanced
-            if (i + 1) % args.advance_every == 0:
+            steps_since_reset[0] += 1
+            # no tree can have had its playouts before playout / (K * (TE + 1)) steps have passed since the common start
+            if (i + 1) % args.advance_every == 0 and steps_since_reset[0] * K * (TE + 1) >= playout:
                 advance_ready()
 
     sp = None

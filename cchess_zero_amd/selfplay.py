@@ -140,6 +140,7 @@ class SelfPlay:
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
         self.ring_records = ring_records
         self.plies = 0
+        self.lock_steps = 0
         if engine.width != 1:
             raise ValueError("SelfPlay drives one simulation in flight per tree (thousands of trees fill the net batch)")
 
@@ -164,6 +165,7 @@ class SelfPlay:
         self._alpha = torch.full((G, MAXMOVES), 0.3, dtype=torch.float32, device=self.dev)
         self._stats = torch.zeros(len(SP_STATS), dtype=torch.int64, device=self.dev)
         self.plies = 0
+        self.lock_steps = 0
 
     # -- one ply of every game ------------------------------------------------------------------------
     def step_ply(self, forward=None, forced=None):
@@ -218,6 +220,7 @@ class SelfPlay:
         try:
             for i in range(int(steps)):
                 eng.step(fwd, mode=1)            # an unexpanded root (fresh game, new ply) is expanded by this step
+                self.lock_steps += 1
                 if (i + 1) % every == 0:
                     self._transition(self.playouts)
         finally:
@@ -274,5 +277,6 @@ class SelfPlay:
         s = self._stats.cpu().numpy()
         d = {k: int(v) for k, v in zip(SP_STATS, s)}
         d["sims"] += int(self.eng.status()[2].sum().item())   # + the simulations of the searches in progress
-        d["plies_played"] = self.plies
+        d["plies_played"] = self.plies          # lock-step plies (step_ply)
+        d["lock_steps"] = self.lock_steps       # select / net / expand steps of the asynchronous loop (run_async)
         return d

@@ -35,6 +35,7 @@ class policy_value_network(object):
         self.c_l2 = 0.0001
         self.momentum = 0.9
         self.global_norm = 100
+        self.max_to_keep = 5
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.net = PolicyValueNet(res_block_nums, self.device, dtype, seed=seed)
         self.module = self.net.module
@@ -111,6 +112,15 @@ class policy_value_network(object):
         d["global_step"] = int(in_global_step)
         torch.save(d, path)
         print("Model saved in file: {}".format(path))
+        # tf.train.Saver() keeps the five most recent checkpoints (max_to_keep=5, policy_value_network.py:148); with one
+        # save per policy update (main.py:1188) anything else fills the disk
+        self._saved = [f for f in getattr(self, "_saved", []) if f != path] + [path]
+        while len(self._saved) > self.max_to_keep:
+            old = self._saved.pop(0)
+            try:
+                os.remove(old)
+            except OSError:
+                pass
         return path
 
     def export_tf_variables(self, file=None):

@@ -203,3 +203,21 @@ def test_policy_update_is_rank_consistent_gloo_world2(tmp_path):
     assert g0 == g1 == sum(st for st, _, _ in i0)
     assert len(s0) == 3 and s1 == []                # only rank 0 writes checkpoints
     assert any(st < 5 for st, _, _ in i0), "the large-learning-rate update should stop early: %r" % (i0,)
+
+
+@pytest.mark.gpu
+def test_saver_keeps_the_five_most_recent_checkpoints(tmp_path, monkeypatch):
+    """tf.train.Saver() default max_to_keep=5 (policy_value_network.py:148): one save per policy update must not fill the disk."""
+    import glob
+    import os
+    import sys
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import policy_value_network as pv
+    net = pv.policy_value_network(res_block_nums=1)
+    for step in range(1, 9):
+        net.save(step)
+    left = sorted(glob.glob(os.path.join(net.save_dir, "best_model.ckpt-*.pt")))
+    assert sorted(os.path.basename(f) for f in left) == sorted("best_model.ckpt-%d.pt" % i for i in range(4, 9))
+    # a restart restores the newest one
+    assert pv.policy_value_network(res_block_nums=1).global_step == 8

@@ -15,13 +15,15 @@ $B > $OUT/bench_default.json 2> $OUT/bench_default.err
 $B --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_shape.json 2> $OUT/bench_driver_shape.err
 $B --games 4096 --playout 400 --steps 1200 --no-cpu-baseline > $OUT/bench_cfg1_4096x400.json 2> $OUT/bench_cfg1.err
 $B --blocks 19 --dtype fp16 --steps 300 --no-cpu-baseline > $OUT/bench_19blk_fp16.json 2> $OUT/bench_19blk.err
-$B --selfplay --playout 100 --steps 300 --warmup 10 --no-cpu-baseline > $OUT/bench_selfplay_p100.json 2> $OUT/bench_selfplay_p100.err
-$B --playout 100 --steps 3000 --warmup 16 --no-cpu-baseline > $OUT/bench_search_p100.json 2> $OUT/bench_search_p100.err
-$B --selfplay --start-position --playout 100 --steps 300 --warmup 10 --no-cpu-baseline > $OUT/bench_selfplay_p100_startpos.json 2> $OUT/bench_selfplay_p100_startpos.err
-$B --selfplay --steps 6 --warmup 1 --no-cpu-baseline > $OUT/bench_selfplay_p1600.json 2> $OUT/bench_selfplay_p1600.err
-$B --gpus 2 --all-on-device0 --dist-backend gloo --games 1024 --selfplay --timed-gather --playout 40 --steps 120 --warmup 4 > $OUT/bench_2ranks_selfplay_gather.json 2> $OUT/bench_2ranks_selfplay_gather.err
+$B --terminal-extra 0 --no-cpu-baseline > $OUT/bench_default_te0.json 2> $OUT/bench_default_te0.err
+$B --selfplay --playout 100 --steps 20000 --warmup 64 --advance-every 4 --no-cpu-baseline > $OUT/bench_selfplay_p100.json 2> $OUT/bench_selfplay_p100.err
+$B --playout 100 --steps 20000 --warmup 64 --advance-every 4 --no-cpu-baseline > $OUT/bench_search_p100.json 2> $OUT/bench_search_p100.err
+$B --selfplay --start-position --playout 100 --steps 20000 --warmup 64 --advance-every 4 --no-cpu-baseline > $OUT/bench_selfplay_p100_startpos.json 2> $OUT/bench_selfplay_p100_startpos.err
+$B --selfplay --steps 6400 --warmup 16 --no-cpu-baseline > $OUT/bench_selfplay_p1600.json 2> $OUT/bench_selfplay_p1600.err
+$B --gpus 2 --all-on-device0 --dist-backend gloo --games 1024 --selfplay --timed-gather --playout 40 --steps 4800 --warmup 64 --advance-every 4 > $OUT/bench_2ranks_selfplay_gather.json 2> $OUT/bench_2ranks_selfplay_gather.err
 $B --gpus 2 --all-on-device0 --dist-backend gloo --games 2048 --steps 100 --warmup 8 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err
-$B --force-dist --dist-backend nccl --games 1024 --selfplay --timed-gather --playout 40 --steps 40 --warmup 2 --no-cpu-baseline > $OUT/bench_rccl_world1_selfplay_gather.json 2> $OUT/bench_rccl_world1.err
+$B --force-dist --dist-backend nccl --games 1024 --selfplay --timed-gather --playout 40 --steps 1600 --warmup 64 --advance-every 4 --no-cpu-baseline > $OUT/bench_rccl_world1_selfplay_gather.json 2> $OUT/bench_rccl_world1.err
+ROOT=$(pwd); mkdir -p $OUT/train && cd $OUT/train && ( SECONDS=0; timeout 900 python $ROOT/main.py --mode train --games 2048 --train_playout 100 --batch_size 512 --res_block_nums 7 --processor gpu --max_batches 2 > train.log 2> train.err; echo "wall seconds: $SECONDS" >> train.log ); cd $ROOT; rm -rf $OUT/train/gpu_models $OUT/train/models* 2>/dev/null; tail -n 4 $OUT/train/train.log | cut -c1-200
 for f in $OUT/bench_*.json; do echo "== $f"; python tools/jline.py $f 2>&1 | head -12; done
 bash tools/profile_round.sh $TAG/prof > $OUT/profile_round.log 2>&1
 bash tools/pmc_ubench.sh 8 > $OUT/pmc_ubench8.log 2>&1; cp gpurun_out/pmc_sq_8.json $OUT/ 2>/dev/null; tail -7 $OUT/pmc_ubench8.log | cut -c1-300
