@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 128)")
     ap.add_argument("--selfplay", action="store_true", help="time the device-resident self-play loop (asynchronous plies)")
     ap.add_argument("--terminal-extra", type=int, default=4, help="terminal / drawn simulations a tree may complete inside one select launch (0: one simulation per tree and step, round-1 behaviour)")
+    ap.add_argument("--eval-cache", action="store_true", help="evaluation cache (cz_search_set_eval_cache): a leaf whose position the tree has evaluated before is expanded from the remembered node inside the select launch, without a net row; trees are bit-identical with it on or off.  Off in the default (headline) run")
     ap.add_argument("--advance-every", type=int, default=8, help="steps between checks for trees that have had their playouts")
     ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records every 64 lock-steps, inside the timed region")
     ap.add_argument("--force-dist", action="store_true", help="testing only: initialise the process group and run every collective even with a world of 1 (RCCL API check on one GPU)")
@@ -320,6 +321,8 @@ def main():
         from cchess_zero_amd import parallel
         from cchess_zero_amd.selfplay import SelfPlay
         sp = SelfPlay(eng, net, playout, exploration=True, temperature=1.0, seed=77 + rank, continuous=True)
+        if args.eval_cache:
+            eng.set_eval_cache(True)
         sp.start(boards, side, rr)
         eng.compact = compact
 
@@ -340,6 +343,8 @@ def main():
                     gather_stats["records"] += len(sp.drain())
         run_plies(args.warmup, False)
     else:
+        if args.eval_cache:
+            eng.set_eval_cache(True)
         eng.reset(boards, side, rr)
         eng.set_terminal_extra(TE)
         eng.set_sim_target(playout)
@@ -501,7 +506,8 @@ def main():
            "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "per_rank_sims_per_s": per_rank,
            "simulations_counted": total_sims, "net_rows_nominal": float(G) * args.steps * world * K,
            "simulations_per_net_row": total_sims / (float(G) * args.steps * world * K), "terminal_extra": TE, "advance_every": args.advance_every,
-           "net_rows_per_s": float(G) * args.steps * world * K / dt, "games_reloaded_rank0": int(reloaded.item()),
+           "net_rows_per_s": float(G) * args.steps * world * K / dt,
+           "eval_cache": (dict(zip(("hits", "lookups"), eng.eval_cache_stats())) if args.eval_cache else None), "games_reloaded_rank0": int(reloaded.item()),
            "mean_leaf_depth": mean_depth, "mean_nodes_per_tree": float(nodes.float().mean().item()),
            "trees_with_error_status": bad, "status_bits": st_bits}
     if sp:

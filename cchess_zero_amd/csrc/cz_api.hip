@@ -145,6 +145,7 @@ void cz_destroy(cz_ctx *c) {
     if (c->tree_block) (void)hipFree(c->tree_block);
     if (c->pool_block) (void)hipFree(c->pool_block);
     if (c->sp_block) (void)hipFree(c->sp_block);
+    if (c->ec_block) (void)hipFree(c->ec_block);
     delete c;
 }
 
@@ -215,6 +216,7 @@ int cz_search_set_width(cz_ctx *c, int width) {
     CZ_REQUIRE(c, "null ctx");
     if (width < 1 || width > 64) { cz_set_error("cz_search_set_width: width %d outside 1..64", width); return CZ_EINVAL; }
     if (width <= c->width) return CZ_OK;
+    if (c->t.ec_key) { cz_set_error("cz_search_set_width: the evaluation cache needs width 1 (cz_search_set_eval_cache(ctx, 0) first)"); return CZ_EINVAL; }
     CZ_HIP(hipStreamSynchronize(c->stream));
     const size_t n = (size_t)c->max_games * (size_t)width;
     Carver m{nullptr};
@@ -237,6 +239,40 @@ int cz_search_set_sim_target(cz_ctx *c, int target) {
     return CZ_OK;
 }
 
+int cz_search_set_eval_cache(cz_ctx *c, int on) {
+    CZ_REQUIRE(c, "cz_search_set_eval_cache: null ctx");
+    if (on && c->width != 1) { cz_set_error("cz_search_set_eval_cache: needs width 1 (one simulation in flight per tree)"); return CZ_EINVAL; }
+    if (on && !c->ec_block) {
+        const size_t per = (size_t)c->max_games * CZ_EC_ENTRIES;
+        const size_t bytes = per * (8 + 4 + 4) + (size_t)c->max_games * 8 + (size_t)c->max_games * 8;
+        CZ_HIP(hipSetDevice(c->device));
+        if (hipMalloc(&c->ec_block, bytes) != hipSuccess) { c->ec_block = nullptr; cz_set_error("cz_search_set_eval_cache: hipMalloc(%zu B) failed", bytes); return CZ_ENOMEM; }
+    }
+    if (on) {
+        const size_t per = (size_t)c->max_games * CZ_EC_ENTRIES;
+        char *b = (char *)c->ec_block;
+        c->t.ec_key = (unsigned long long *)b;
+        c->t.pend_key = (unsigned long long *)(b + per * 8);
+        c->t.ec_stats = (uint32_t *)(b + per * 8 + (size_t)c->max_games * 8);
+        c->t.ec_node = (int32_t *)(b + per * 8 + (size_t)c->max_games * 16);
+        c->t.ec_val = (float *)(b + per * 8 + (size_t)c->max_games * 16 + per * 4);
+        // an empty cache: entries of an earlier use would point into trees that no longer exist
+        CZ_HIP(hipMemsetAsync(c->ec_block, 0, per * 8 + (size_t)c->max_games * 16, c->stream));
+    } else {
+        c->t.ec_key = nullptr; c->t.ec_node = nullptr; c->t.ec_val = nullptr; c->t.pend_key = nullptr; c->t.ec_stats = nullptr;
+    }
+    return CZ_OK;
+}
+int cz_search_eval_cache_stats(cz_ctx *c, unsigned long long *hits, unsigned long long *lookups) {
+    CZ_REQUIRE(c && hits && lookups, "cz_search_eval_cache_stats: null argument");
+    *hits = 0; *lookups = 0;
+    if (!c->t.ec_stats || c->G <= 0) return CZ_OK;
+    std::vector<uint32_t> h((size_t)c->G * 2);
+    CZ_HIP(hipMemcpyAsync(h.data(), c->t.ec_stats, h.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    for (int g = 0; g < c->G; ++g) { *hits += h[2 * (size_t)g]; *lookups += h[2 * (size_t)g + 1]; }
+    return CZ_OK;
+}
 int cz_search_set_terminal_extra(cz_ctx *c, int n) {
     CZ_REQUIRE(c && n >= 0 && n <= 64, "cz_search_set_terminal_extra: 0 <= n <= 64 required");
     c->terminal_extra = n;

@@ -61,6 +61,9 @@ struct CzSelfplay {
     long long *stats;            // [CZ_SP_NSTATS]
 };
 
+#define CZ_EC_BUCKETS 128
+#define CZ_EC_ENTRIES (CZ_EC_BUCKETS * 64)
+
 struct CzTrees {
     CzPool pool;         // [max_games * cap]
     int cap;
@@ -80,6 +83,13 @@ struct CzTrees {
     // updates all levels in parallel instead of chasing parent pointers (one dependent round trip per level)
     int32_t *pend_depth;              // [max_games]
     int32_t *pend_path;               // [max_games][CZ_PATH_MAX]
+    // evaluation cache (cz_search_set_eval_cache): per tree CZ_EC_BUCKETS buckets of 64 entries {Zobrist key of an expanded
+    // node's position, its node index, the value its evaluation backed up}.  The priors are the node's children's P.
+    unsigned long long *ec_key;       // [max_games][CZ_EC_ENTRIES]  0 = empty      (NULL: cache off)
+    int32_t *ec_node;                 // [max_games][CZ_EC_ENTRIES]
+    float *ec_val;                    // [max_games][CZ_EC_ENTRIES]
+    unsigned long long *pend_key;     // [max_games] key of the pending leaf (select -> expand_backup)
+    uint32_t *ec_stats;               // [max_games][2] hits, lookups of the tree (summed by cz_search_eval_cache_stats)
     // compact evaluation batches (cz_search_select_compact): row of the step's leaf in planes / z / value, or -1
     int32_t *slot_of;                 // [max_games]
     int32_t *evcnt;                   // [2] rows handed out this step / next step (ping-pong, zeroed one step ahead)
@@ -104,6 +114,7 @@ struct cz_ctx {
     const int32_t *batch_count;  // cz_set_batch_count: device row count bounding the net launches, or NULL
     CzSelfplay sp;     // cz_selfplay_begin
     void *sp_block;
+    void *ec_block;    // cz_search_set_eval_cache
 };
 
 // ---- device helpers shared by cz_search.hip / cz_selfplay.hip -----------------------------------
@@ -127,6 +138,13 @@ __device__ __forceinline__ void init_root(TreeView v, int idx) {
     v.P[idx] = 1.0f;  // p_ = 0.75 + 0.25 * dirichlet([0.3]) == 1 (quirk Q4), main.py:238
     v.W[idx] = 0.f; v.Q[idx] = 0.f; v.N[idx] = 0; v.parent[idx] = -1; v.child_begin[idx] = -1;
     v.child_count[idx] = 0; v.move[idx] = 0xFFFF;
+}
+
+// evaluation cache: forget everything tree g knows (fresh root: reset / reload / re-seed / failed advance)
+__device__ __forceinline__ void ec_clear_tree(const CzTrees &t, int g, int tid, int nthreads) {
+    if (!t.ec_key) return;
+    unsigned long long *k = t.ec_key + (size_t)g * CZ_EC_ENTRIES;
+    for (int i = tid; i < CZ_EC_ENTRIES; i += nthreads) k[i] = 0ull;
 }
 
 // kernels' launch wrappers (cz_rules.hip / cz_search.hip)

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restri
         t.pend_kind[g] = 0; t.pend_leaf[g] = 0; t.pend_value[g] = 0.f; t.pend_side[g] = 0; t.pend_nmoves[g] = 0;
         init_root(view_of(t, g), 0);
     }
+    ec_clear_tree(t, g, lane, 64);
 }
 
 // ---- K4: selection descent + leaf preparation ----------------------------------------------------
@@ -40,6 +41,19 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
     if (b.s > a.s || (b.s == a.s && b.i < a.i)) return b;
     return a;
 }
+
+// Zobrist key of the position in LDS (the same function as cz_hash; 0 is reserved for "empty" in the evaluation cache)
+__device__ __forceinline__ unsigned long long wave_position_key(const uint8_t *b, int side, const uint64_t *__restrict__ zob, int lane) {
+    unsigned long long h = 0ull;
+    const int c0 = b[lane];
+    if (c0) h = zob[c0 * CZ_NSQ + lane];
+    if (lane + 64 < CZ_NSQ) { const int c1 = b[lane + 64]; if (c1) h ^= zob[c1 * CZ_NSQ + lane + 64]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) h ^= __shfl_xor(h, d, 64);
+    if (side) h ^= zob[15 * CZ_NSQ];
+    return h ? h : 1ull;
+}
+__device__ __forceinline__ int ec_bucket(unsigned long long key) { return (int)((key >> 17) & (CZ_EC_BUCKETS - 1)); }
 
 // COMPACT: the leaf planes of the trees that need a net evaluation are written to consecutive rows handed out by an
 // atomic counter (t.evcnt[parity]); t.slot_of[g] records the row (or -1), the other counter is zeroed for the next
@@ -53,7 +67,7 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {
 // strictly sequential, so the tree after N simulations is bit-identical to the one-simulation-per-step schedule; what
 // changes is that a step now completes 1 / (1 - f) simulations per net row (f = share of terminal simulations, 8.5 % on
 // the bench workload).  sim_target > 0 stops a tree at that many completed simulations (cz_search_set_sim_target).
-template <typename T, bool COMPACT>
+template <typename T, bool COMPACT, bool CACHE>
 __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &tab, int G, int mode,
                                             const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                             T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
@@ -69,6 +83,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
     const bool parked = (active && !active[g]) || (t.status[g] & ~CZ_ST_BAD_ADVANCE) != 0;
     int kind = 0, leaf = 0, depth = 0, done_here = 0;
     float pend = 0.f;
+    unsigned long long key = 0ull;
     int side = t.root_side[g];
     if (!parked) {
         for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64) {
@@ -168,7 +183,51 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                     }
                     node = c; cb = nbeg; cc = ncnt; nN = nn;
                 }
-                if (!(kind == 2 && extra_left > 0 && depth <= CZ_PATH_MAX)) break;
+                const bool may = extra_left > 0 && depth <= CZ_PATH_MAX;
+                bool full = false;
+                if (CACHE && kind == 1) {
+                    // Evaluation cache.  The net is a pure function of (board, side to move) and every row of a batch is
+                    // computed independently of the others, so a position this tree has evaluated before would get the
+                    // same priors and value, bit for bit.  An expanded node with the same key lends its children's move
+                    // labels and priors and the value its evaluation backed up: the simulation completes here, without
+                    // a net row, and the tree is the one the net would have produced.
+                    key = wave_position_key(b, side, tab.zob, lane);
+                    bool hit = false;
+                    int src = 0;
+                    if (may) {
+                        const size_t eb = (size_t)g * CZ_EC_ENTRIES + (size_t)ec_bucket(key) * 64 + lane;
+                        const unsigned long long ek = t.ec_key[eb];
+                        const int en = t.ec_node[eb];
+                        const float ev = t.ec_val[eb];
+                        const unsigned long long m = __ballot(ek == key);
+                        if (m) {
+                            const int hl = __ffsll((long long)m) - 1;
+                            src = __shfl(en, hl, 64);
+                            pend = __shfl(ev, hl, 64);
+                            hit = true;
+                        }
+                        if (lane == 0) { t.ec_stats[2 * g] += hit ? 1u : 0u; t.ec_stats[2 * g + 1] += 1u; }
+                    }
+                    if (!hit) break;
+                    const int scb = v.child_begin[src], n = v.child_count[src];
+                    const int begin = t.n_nodes[g];
+                    if (begin + n <= t.cap) {   // leaf_node.expand with the lender's priors
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int i = lane + 64 * r;
+                            if (i < n) {
+                                const int c = begin + i;
+                                v.P[c] = v.P[scb + i]; v.move[c] = v.move[scb + i];
+                                v.W[c] = 0.f; v.Q[c] = 0.f; v.N[c] = 0; v.parent[c] = leaf; v.child_begin[c] = -1;
+                                v.child_count[c] = 0;
+                            }
+                        }
+                        if (lane == 0) { v.child_begin[leaf] = begin; v.child_count[leaf] = (uint16_t)n; t.n_nodes[g] = begin + n; }
+                    } else {
+                        if (lane == 0) t.status[g] |= CZ_ST_POOL_EXHAUSTED;
+                        full = true;   // this simulation is still backed up; the tree then stops, as it does after k_expand_backup
+                    }
+                } else if (!(kind == 2 && may)) break;
                 // back_up_value along the path (main.py:189-194,426-435), exactly as k_expand_backup does it: lane d owns
                 // the node of level d; (W + -3) + 3 reproduces the float32 rounding of the virtual loss
                 if (lane < depth) {
@@ -182,6 +241,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                     v.N[n] = cnt; v.W[n] = w; v.Q[n] = w / (float)cnt;
                 }
                 ++done_here; --extra_left;
+                if (full) { kind = 0; break; }
                 __threadfence_block();
                 __syncthreads();
                 for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64) ((uint32_t *)b)[i] = ((const uint32_t *)b0)[i];
@@ -213,6 +273,10 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
     } else if (pl && !COMPACT) {
         for (int e = lane; e < 90 * C; e += 64) pl[e] = (T)0;
     }
+    if (CACHE && (kind == 1 || kind == 3)) {
+        if (kind == 3) key = wave_position_key(b, side, tab.zob, lane);
+        if (lane == 0) t.pend_key[g] = key;
+    }
     if (lane == 0) {
         t.pend_kind[g] = kind; t.pend_leaf[g] = leaf; t.pend_value[g] = pend;
         t.pend_side[g] = (uint8_t)side; t.pend_nmoves[g] = (uint16_t)nmoves;
@@ -230,13 +294,27 @@ template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_select(CzTrees t, CzTables tab, int G, int mode,
                                                const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                                T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
-    select_body<T, false>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
+    select_body<T, false, false>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
 }
 template <typename T>
 __global__ __launch_bounds__(64) void k_select_compact(CzTrees t, CzTables tab, int G, int mode,
                                                        const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                                        T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
-    select_body<T, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
+    select_body<T, true, false>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
+}
+// With the evaluation cache (cz_search_set_eval_cache): the same descent, plus the lookup at the leaf and the expansion from
+// a lender node inside the launch.
+template <typename T>
+__global__ __launch_bounds__(64) void k_select_cache(CzTrees t, CzTables tab, int G, int mode,
+                                                     const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                                     T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
+    select_body<T, false, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
+}
+template <typename T>
+__global__ __launch_bounds__(64) void k_select_compact_cache(CzTrees t, CzTables tab, int G, int mode,
+                                                             const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                                             T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
+    select_body<T, true, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
 }
 
 // ---- K5 + K6: expansion and value backup ---------------------------------------------------------
@@ -398,8 +476,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
         } else if (lane == 0) {
             t.status[g] |= CZ_ST_POOL_EXHAUSTED;
         }
-        if (kind == 3) { if (lane == 0) t.pend_kind[g] = 0; return; }
         val = to_f32<T>(value[FC ? row : g]) * -1.0f;  // return value[0] * -1, main.py:384
+        if (t.ec_key && fits) {
+            // evaluation cache: this node now holds the priors of its position (its children's P), `val` is what its
+            // evaluation backs up.  First empty entry of the key's bucket; a full bucket replaces a pseudo-random entry.
+            const unsigned long long key = t.pend_key[g];
+            const size_t eb0 = (size_t)g * CZ_EC_ENTRIES + (size_t)ec_bucket(key) * 64;
+            const unsigned long long ek = t.ec_key[eb0 + lane];
+            if (__ballot(ek == key) == 0ull) {
+                const unsigned long long em = __ballot(ek == 0ull);
+                const int slot = em ? __ffsll((long long)em) - 1 : (int)((key >> 40) & 63);
+                if (lane == slot) { t.ec_key[eb0 + lane] = key; t.ec_node[eb0 + lane] = leaf; t.ec_val[eb0 + lane] = val; }
+            }
+        }
+        if (kind == 3) { if (lane == 0) t.pend_kind[g] = 0; return; }
     } else {
         val = t.pend_value[g];
     }
@@ -758,6 +848,7 @@ __global__ __launch_bounds__(256) void k_advance(CzTrees t, CzTables tab, int G,
             init_root(v, 0);
             t.root_node[g] = 0; t.n_nodes[g] = 1;
         }
+        ec_clear_tree(t, g, tid, 256);
         return;
     }
     // ---- pass 1: the kept-node bitmap.  Nothing below `found` can be in its subtree.
@@ -808,6 +899,17 @@ __global__ __launch_bounds__(256) void k_advance(CzTrees t, CzTables tab, int G,
         for (int w = lo; w < hi; ++w) { rank[w] = (uint32_t)acc; acc += __popcll(bits[w]); }
         __syncthreads();
     }
+    // ---- evaluation cache: entries of kept nodes follow them to their new indices, the others are forgotten
+    if (t.ec_key) {
+        unsigned long long *ek = t.ec_key + (size_t)g * CZ_EC_ENTRIES;
+        int32_t *en = t.ec_node + (size_t)g * CZ_EC_ENTRIES;
+        for (int e = tid; e < CZ_EC_ENTRIES; e += 256) {
+            if (ek[e] == 0ull) continue;
+            const int nd = en[e];
+            if (nd >= found && nd < n && mark_tst(bits, nd)) en[e] = (int)mark_rank_of(bits, rank, nd);
+            else ek[e] = 0ull;
+        }
+    }
     // ---- pass 2: move the kept nodes down, ascending (new index <= old index)
     for (int base = w0 << 6; base < n; base += 256) {
         const int i = base + tid;
@@ -854,8 +956,14 @@ int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, 
     const int par = c->step_parity;
 #define CZ_LAUNCH_SELECT(KERNEL, TT, ONE)                                                                               \
     hipLaunchKernelGGL((KERNEL<TT>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (TT *)planes, C, ONE, needs_eval, par, c->sim_target, c->terminal_extra)
-    if (dtype == CZ_F32) { if (compact) CZ_LAUNCH_SELECT(k_select_compact, float, 1.0f); else CZ_LAUNCH_SELECT(k_select, float, 1.0f); }
-    else { if (compact) CZ_LAUNCH_SELECT(k_select_compact, uint16_t, one16); else CZ_LAUNCH_SELECT(k_select, uint16_t, one16); }
+    const bool cache = c->t.ec_key != nullptr;
+    if (dtype == CZ_F32) {
+        if (cache) { if (compact) CZ_LAUNCH_SELECT(k_select_compact_cache, float, 1.0f); else CZ_LAUNCH_SELECT(k_select_cache, float, 1.0f); }
+        else { if (compact) CZ_LAUNCH_SELECT(k_select_compact, float, 1.0f); else CZ_LAUNCH_SELECT(k_select, float, 1.0f); }
+    } else {
+        if (cache) { if (compact) CZ_LAUNCH_SELECT(k_select_compact_cache, uint16_t, one16); else CZ_LAUNCH_SELECT(k_select_cache, uint16_t, one16); }
+        else { if (compact) CZ_LAUNCH_SELECT(k_select_compact, uint16_t, one16); else CZ_LAUNCH_SELECT(k_select, uint16_t, one16); }
+    }
 #undef CZ_LAUNCH_SELECT
     CZ_HIP(hipGetLastError());
     return CZ_OK;

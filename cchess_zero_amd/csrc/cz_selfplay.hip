@@ -48,6 +48,7 @@ __device__ __forceinline__ void seed_slot(const CzTrees &t, const CzSelfplay &sp
         init_root(view_of(t, g), 0);
         sp.ply[g] = 0; sp.stalled[g] = 0;
     }
+    ec_clear_tree(t, g, lane, 64);
 }
 
 __global__ __launch_bounds__(64) void k_sp_seed(CzTrees t, CzSelfplay sp, int G, const uint8_t *__restrict__ boards,

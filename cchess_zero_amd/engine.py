@@ -80,6 +80,7 @@ class SearchEngine:
         self.planes = None
         self.need = None
         self.terminal_extra = 0
+        self.eval_cache = False
 
     def set_terminal_extra(self, n):
         """Terminal simulations (king captured / 60-ply rule: no net evaluation needed, main.py:409-416) a tree may complete
@@ -88,6 +89,20 @@ class SearchEngine:
         assert self.width == 1 or int(n) == 0, "terminal_extra applies to the one-simulation-per-tree select"
         check(lib().cz_search_set_terminal_extra(self.ctx.h, int(n)), "cz_search_set_terminal_extra")
         self.terminal_extra = int(n)
+
+    def set_eval_cache(self, on):
+        """Evaluation cache (include/cchess_hip.h: cz_search_set_eval_cache): a leaf whose position the tree has
+        evaluated before is expanded from the remembered node inside the select launch, without a net row."""
+        assert self.width == 1 or not on, "the evaluation cache needs one simulation in flight per tree"
+        self.ctx.bind_stream()
+        check(lib().cz_search_set_eval_cache(self.ctx.h, 1 if on else 0), "cz_search_set_eval_cache")
+        self.eval_cache = bool(on)
+
+    def eval_cache_stats(self):
+        """-> (hits, lookups) summed over the trees since the cache was turned on."""
+        h, n = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(lib().cz_search_eval_cache_stats(self.ctx.h, C.byref(h), C.byref(n)), "cz_search_eval_cache_stats")
+        return int(h.value), int(n.value)
 
     def set_sim_target(self, target):
         """Trees stop at `target` completed simulations since their last reset / advance (0: no limit)."""

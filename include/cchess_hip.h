@@ -191,6 +191,17 @@ int cz_search_set_sim_target(cz_ctx *, int target);
  * Simulations of one tree stay strictly sequential: the tree after N simulations is bit-identical to the n = 0 schedule.
  * Use cz_search_set_sim_target (also honoured by cz_search_select) to stop every tree at exactly N.  Default 0. */
 int cz_search_set_terminal_extra(cz_ctx *, int n);
+/* Evaluation cache (off by default; width 1 only).  The net is a pure function of (board, side to move) and this library
+ *   computes every row of a batch independently of the others, so a position a tree has evaluated before would get the
+ *   same priors and value again, bit for bit (the reference re-evaluates it: transpositions are separate nodes,
+ *   main.py:357-384).  With the cache on, every expanded node is remembered under the 64-bit Zobrist key of its position
+ *   (cz_zobrist; per tree 128 buckets x 64 entries, 128 KB); a leaf whose key is found is expanded inside the select
+ *   launch from the remembered node's children (labels, priors) and backed up with the remembered value — no net row —
+ *   subject to the same per-launch budget as cz_search_set_terminal_extra.  Trees are identical with the cache on or
+ *   off; entries follow their nodes through cz_search_advance and are dropped with them.  Turning it on empties it.
+ *   cz_search_eval_cache_stats: hits / lookups summed over the trees since the cache was turned on (synchronises). */
+int cz_search_set_eval_cache(cz_ctx *, int on);
+int cz_search_eval_cache_stats(cz_ctx *, unsigned long long *hits, unsigned long long *lookups);
 int cz_search_select_k(cz_ctx *, int mode, int k, const uint8_t *active, void *leaf_planes, int dtype,
                        int channels, uint8_t *needs_eval);
 int cz_search_expand_backup_k(cz_ctx *, int k, const void *logits, const void *value, int dtype);

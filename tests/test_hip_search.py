@@ -354,3 +354,114 @@ def test_reload_restarts_only_the_chosen_trees(rules_golden):
     search(orc, 12)
     for t in np.nonzero(which)[0]:
         assert np.array_equal(hip.tree_dump(int(t)), orc.tree_dump(int(t))), t
+
+
+def _dedup(seq):
+    seen, out = set(), []
+    for k in seq:
+        if k not in seen:
+            seen.add(k)
+            out.append(k)
+    return out
+
+
+def test_eval_cache_keeps_the_golden_trees(mcts_golden):
+    """cz_search_set_eval_cache: a leaf whose position the tree has evaluated before is expanded from the remembered node
+    (children's labels and priors, backed-up value) inside the select launch.  The trees must still be the unmodified
+    reference's — root children, whole-tree digests — and the net must see the golden sequence of positions with the
+    repeats it was spared removed (a repeat may still reach the net when the launch's budget is used up)."""
+    cases = mcts_golden["cases"]
+    by_playouts = {}
+    for c in cases:
+        by_playouts.setdefault(c["plies"][0]["playouts"], []).append(c)
+    spared = 0
+    for playouts, group in sorted(by_playouts.items()):
+        G = len(group)
+        logs = [[] for _ in range(G)]
+        fwds = [fakenet.make_forward(c["mode"], c["salt"], logs[i]) for i, c in enumerate(group)]
+        boards = np.stack([searchdrive.fen_to_board(c["plies"][0]["state"]) for c in group])
+        side = np.array([1 if c["plies"][0]["player"] == "b" else 0 for c in group], np.uint8)
+        rr = np.array([c["plies"][0]["rr"] for c in group], np.int32)
+        eng = _HipEngine(G)
+        eng.e.set_eval_cache(True)
+        eng.reset(boards, side, rr)
+        _run_to_target(eng, fwds, playouts, 4)
+        st = eng.root_stats()
+        assert np.all(eng.e.status()[2].cpu().numpy() == playouts) and not np.any(eng.status() & ~8)
+        for g, c in enumerate(group):
+            gp = c["plies"][0]
+            n = int(st["count"][g])
+            root = [(int(st["label"][g, i]), int(st["N"][g, i]), int(st["W"][g, i].view(np.uint32)),
+                     int(st["Q"][g, i].view(np.uint32)), int(st["P"][g, i].view(np.uint32))) for i in range(n)]
+            assert root == [tuple(x) for x in gp["root"]], c["name"]
+            rec = eng.tree_dump(g)
+            assert len(rec) == gp["tree_records"] and searchdrive.tree_digest(rec) == gp["tree_sha256"], c["name"]
+            gold = c["eval_keys"][:gp["evals"]]
+            got = ["%016x" % k for k in logs[g]]
+            assert len(got) <= len(gold) and _dedup(got) == _dedup(gold), c["name"]
+            spared += len(gold) - len(got)
+        hits, lookups = eng.e.eval_cache_stats()
+        assert lookups >= hits >= 0
+        eng.e.set_eval_cache(False)
+    print("evaluation cache: %d net evaluations spared over the golden cases" % spared)
+    assert spared > 0
+
+
+def test_eval_cache_follows_the_tree_through_advances(rules_golden):
+    """48 trees, 3 plies x 500 playouts with re-rooting in between, evaluation cache + terminal simulations inside select,
+    against the oracle's plain schedule: identical root statistics and whole trees after every ply (the cache entries of
+    kept nodes are remapped by cz_search_advance, the others dropped), with fewer net rows."""
+    from oracle import oracle as O
+    g = rules_golden
+    ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
+    idx = np.nonzero(ok)[0][::61][:48]
+    G, playouts = len(idx), 500
+    boards, side = g["boards"][idx], g["side"][idx]
+    rr = (np.arange(G) * 3 % 40).astype(np.int32)
+    hip = _HipEngine(G, 80000)
+    orc = O.Search(G, 80000)
+    hip.e.set_eval_cache(True)
+    hip.reset(boards, side, rr)
+    orc.reset(boards, side, rr)
+    fwd = fakenet.make_forward("signed", 5)
+    rows_hip = rows_orc = 0
+    hits_by_ply = []
+    for ply in range(3):
+        for step in range(playouts + 1):
+            op, on = orc.select(0 if step == 0 else 1)
+            rows_orc += int(on.sum())
+            lg, v = fwd(op)
+            orc.expand_backup(lg, v)
+        hip.e.set_terminal_extra(4)
+        hip.e.set_sim_target(playouts)
+        for mode in [0] + [1] * playouts:
+            busy = (hip.e.status()[2].cpu().numpy() < playouts) & (hip.status() & ~8 == 0)
+            if mode == 1 and not busy.any():
+                break
+            hp, hn = hip.select(mode)
+            rows_hip += int(hn.sum())
+            lg, v = fwd(hp)
+            hip.expand_backup(lg, v)
+        hip.e.set_sim_target(0)
+        hip.e.set_terminal_extra(0)
+        hs, os_ = hip.root_stats(), orc.root_stats()
+        for k in ("label", "N", "count"):
+            assert np.array_equal(hs[k], os_[k]), (ply, k)
+        for k in ("Q", "P", "W"):
+            assert np.array_equal(hs[k].view(np.uint32), os_[k].view(np.uint32)), (ply, k)
+        assert np.array_equal(hip.status(), orc.status()[0]), ply
+        for t in range(0, G, 5):
+            assert np.array_equal(hip.tree_dump(t), orc.tree_dump(t)), (ply, t)
+        hits_by_ply.append(hip.e.eval_cache_stats()[0])
+        # play the most visited move (ties: first), like get_action with temperature -> 0
+        n = hs["N"].astype(np.int64).copy()
+        n[np.arange(128)[None, :] >= hs["count"].astype(np.int64)[:, None]] = -1
+        played = hs["label"][np.arange(G), n.argmax(axis=1)].astype(np.uint16)
+        played[hs["count"] == 0] = 0xFFFF
+        hip.advance(played)
+        orc.advance(played)
+    hits, lookups = hip.e.eval_cache_stats()
+    print("evaluation cache over 3 plies x %d playouts x %d trees: %d hits / %d lookups (by ply: %s), net rows %d instead of %d" %
+          (playouts, G, hits, lookups, np.diff([0] + hits_by_ply).tolist(), rows_hip, rows_orc))
+    assert hits > 0 and rows_hip < rows_orc and hits_by_ply[2] > hits_by_ply[1] > hits_by_ply[0]
+    hip.e.set_eval_cache(False)

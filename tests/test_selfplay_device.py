@@ -141,3 +141,32 @@ def test_asynchronous_plies_keep_records_well_formed():
     # not waiting for its move, and more than one where terminal simulations completed inside select
     assert st["sims"] >= st["plies"] * playouts
     assert int(eng.status()[2].max().item()) <= playouts
+
+
+def test_eval_cache_and_terminal_extra_leave_real_net_selfplay_unchanged():
+    """The claim behind the evaluation cache, checked with the REAL fused net: a position evaluated twice gets the same
+    priors and value bit for bit (every row of a batch is computed independently of the others), so whole self-play games
+    — visit counts, sampled moves, results — are byte-identical with the cache and in-select terminal simulations on or off."""
+    G, playouts, plies = 64, 24, 30
+
+    def run(cache):
+        net, eng, sp = _setup(G, 8192, playouts, seed=11)
+        if cache:
+            eng.set_eval_cache(True)
+            eng.set_terminal_extra(4)
+        sp.run(plies)
+        rec = sp.drain()
+        st = sp.stats()
+        hits = eng.eval_cache_stats() if cache else (0, 0)
+        if cache:
+            eng.set_terminal_extra(0)
+            eng.set_eval_cache(False)
+        return rec, st, hits
+
+    rec0, st0, _ = run(False)
+    rec1, st1, hits = run(True)
+    print("real net, %d games x %d plies x %d playouts: %d records; cache hits %d / %d lookups" %
+          (G, plies, playouts, len(rec0), hits[0], hits[1]))
+    assert len(rec0) > 0 and rec0.shape == rec1.shape and np.array_equal(rec0, rec1)
+    assert {k: st0[k] for k in ("games", "red_wins", "black_wins", "draws", "plies")} == {k: st1[k] for k in ("games", "red_wins", "black_wins", "draws", "plies")}
+    assert hits[0] > 0

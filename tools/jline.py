@@ -17,6 +17,6 @@ if c:
 sp = d["config"].get("selfplay")
 if sp:
     print("  selfplay:", sp)
-print("  sims per net row %s  terminal_extra %s" % (d["config"].get("simulations_per_net_row"), d["config"].get("terminal_extra")))
+print("  sims per net row %s  terminal_extra %s  eval_cache %s  net rows/s %s" % (d["config"].get("simulations_per_net_row"), d["config"].get("terminal_extra"), d["config"].get("eval_cache"), d["config"].get("net_rows_per_s")))
 print("  per rank:", d["config"].get("per_rank_sims_per_s"), "backend", d["config"].get("dist_backend"), "gather", d["config"].get("record_gather"),
       "status", d["config"].get("status_bits"))
