@@ -321,8 +321,7 @@ def main():
         from cchess_zero_amd import parallel
         from cchess_zero_amd.selfplay import SelfPlay
         sp = SelfPlay(eng, net, playout, exploration=True, temperature=1.0, seed=77 + rank, continuous=True)
-        if args.eval_cache:
-            eng.set_eval_cache(True)
+        sp.eval_cache = bool(args.eval_cache)
         sp.start(boards, side, rr)
         eng.compact = compact
 

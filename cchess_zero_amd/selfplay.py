@@ -129,13 +129,15 @@ class SelfPlay:
     """
 
     def __init__(self, engine, net, playouts, exploration=True, temperature=1.0, seed=0, max_plies=512, ring_records=None,
-                 continuous=True):
+                 continuous=True, eval_cache=False):
         self.eng, self.net = engine, net
         self.playouts = int(playouts)
         self.exploration = bool(exploration)
         self.temperature = float(temperature)
         self.max_plies = int(max_plies)
         self.continuous = bool(continuous)
+        # evaluation cache (engine.set_eval_cache): valid as long as the net's weights do not change — start() empties it
+        self.eval_cache = bool(eval_cache)
         self.dev = engine.dev
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
         self.ring_records = ring_records
@@ -148,6 +150,8 @@ class SelfPlay:
     def start(self, boards, side, rr=None):
         """Fresh trees on the given positions; every later game of a slot starts from the same position."""
         eng = self.eng
+        if self.eval_cache or eng.eval_cache:
+            eng.set_eval_cache(self.eval_cache)   # turning it on empties it: new weights, new cache
         eng.reset(boards, side, rr)
         eng.compact = not self.continuous   # parked games drop out of the net's batch; a full batch needs no compaction
         G = eng.G
