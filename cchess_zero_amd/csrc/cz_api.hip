@@ -39,16 +39,11 @@ void carve_trees(Carver &c, CzTrees &t, size_t G, size_t words) {
     t.mark_bits = c.take<unsigned long long>(G * words);
     t.mark_rank = c.take<uint32_t>(G * words);
     t.root_board = c.take<uint8_t>(G * CZD_BOARD_LDS);
-    t.root_side = c.take<uint8_t>(G);
-    t.root_rr = c.take<int32_t>(G); t.root_node = c.take<int32_t>(G); t.n_nodes = c.take<int32_t>(G);
-    t.status = c.take<int32_t>(G); t.sims = c.take<int32_t>(G); t.last_depth = c.take<int32_t>(G);
-    t.pend_kind = c.take<int32_t>(G); t.pend_leaf = c.take<int32_t>(G);
-    t.pend_value = c.take<float>(G);
-    t.pend_side = c.take<uint8_t>(G);
-    t.pend_nmoves = c.take<uint16_t>(G);
+    t.rec = c.take<CzTreeRec>(G);
     t.pend_moves = c.take<uint16_t>(G * CZD_MAXMOVES);
-    t.pend_depth = c.take<int32_t>(G);
     t.pend_path = c.take<int32_t>(G * CZ_PATH_MAX);
+    t.pk_kind = c.take<int32_t>(G); t.pk_leaf = c.take<int32_t>(G); t.pk_value = c.take<float>(G);
+    t.pk_side = c.take<uint8_t>(G); t.pk_nmoves = c.take<uint16_t>(G);
     t.slot_of = c.take<int32_t>(G);
     t.evcnt = c.take<int32_t>(2);
     t.evtotal = c.take<unsigned long long>(2);
@@ -225,8 +220,8 @@ int cz_search_set_width(cz_ctx *c, int width) {
     if (hipMalloc(&blk, m.off) != hipSuccess) { cz_set_error("cz_search_set_width: hipMalloc(%zu B) failed", m.off); return CZ_ENOMEM; }
     CZ_HIP(hipMemset(blk, 0, m.off));
     Carver k{(char *)blk};
-    c->t.pend_kind = k.take<int32_t>(n); c->t.pend_leaf = k.take<int32_t>(n); c->t.pend_value = k.take<float>(n);
-    c->t.pend_side = k.take<uint8_t>(n); c->t.pend_nmoves = k.take<uint16_t>(n); c->t.pend_moves = k.take<uint16_t>(n * CZD_MAXMOVES);
+    c->t.pk_kind = k.take<int32_t>(n); c->t.pk_leaf = k.take<int32_t>(n); c->t.pk_value = k.take<float>(n);
+    c->t.pk_side = k.take<uint8_t>(n); c->t.pk_nmoves = k.take<uint16_t>(n); c->t.pend_moves = k.take<uint16_t>(n * CZD_MAXMOVES);
     if (c->pend_block) (void)hipFree(c->pend_block);
     c->pend_block = blk;
     c->width = width;
@@ -242,35 +237,33 @@ int cz_search_set_sim_target(cz_ctx *c, int target) {
 int cz_search_set_eval_cache(cz_ctx *c, int on) {
     CZ_REQUIRE(c, "cz_search_set_eval_cache: null ctx");
     if (on && c->width != 1) { cz_set_error("cz_search_set_eval_cache: needs width 1 (one simulation in flight per tree)"); return CZ_EINVAL; }
+    const size_t per = (size_t)c->max_games * CZ_EC_ENTRIES;
     if (on && !c->ec_block) {
-        const size_t per = (size_t)c->max_games * CZ_EC_ENTRIES;
-        const size_t bytes = per * (8 + 4 + 4) + (size_t)c->max_games * 8 + (size_t)c->max_games * 8;
+        const size_t bytes = per * (8 + 4 + 4);
         CZ_HIP(hipSetDevice(c->device));
         if (hipMalloc(&c->ec_block, bytes) != hipSuccess) { c->ec_block = nullptr; cz_set_error("cz_search_set_eval_cache: hipMalloc(%zu B) failed", bytes); return CZ_ENOMEM; }
     }
     if (on) {
-        const size_t per = (size_t)c->max_games * CZ_EC_ENTRIES;
         char *b = (char *)c->ec_block;
         c->t.ec_key = (unsigned long long *)b;
-        c->t.pend_key = (unsigned long long *)(b + per * 8);
-        c->t.ec_stats = (uint32_t *)(b + per * 8 + (size_t)c->max_games * 8);
-        c->t.ec_node = (int32_t *)(b + per * 8 + (size_t)c->max_games * 16);
-        c->t.ec_val = (float *)(b + per * 8 + (size_t)c->max_games * 16 + per * 4);
+        c->t.ec_node = (int32_t *)(b + per * 8);
+        c->t.ec_val = (float *)(b + per * 12);
         // an empty cache: entries of an earlier use would point into trees that no longer exist
-        CZ_HIP(hipMemsetAsync(c->ec_block, 0, per * 8 + (size_t)c->max_games * 16, c->stream));
+        CZ_HIP(hipMemsetAsync(c->ec_block, 0, per * 8, c->stream));
+        czk_search_clear_cache_stats(c);
     } else {
-        c->t.ec_key = nullptr; c->t.ec_node = nullptr; c->t.ec_val = nullptr; c->t.pend_key = nullptr; c->t.ec_stats = nullptr;
+        c->t.ec_key = nullptr; c->t.ec_node = nullptr; c->t.ec_val = nullptr;
     }
     return CZ_OK;
 }
 int cz_search_eval_cache_stats(cz_ctx *c, unsigned long long *hits, unsigned long long *lookups) {
     CZ_REQUIRE(c && hits && lookups, "cz_search_eval_cache_stats: null argument");
     *hits = 0; *lookups = 0;
-    if (!c->t.ec_stats || c->G <= 0) return CZ_OK;
-    std::vector<uint32_t> h((size_t)c->G * 2);
-    CZ_HIP(hipMemcpyAsync(h.data(), c->t.ec_stats, h.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->G <= 0) return CZ_OK;
+    std::vector<CzTreeRec> h((size_t)c->G);
+    CZ_HIP(hipMemcpyAsync(h.data(), c->t.rec, h.size() * sizeof(CzTreeRec), hipMemcpyDeviceToHost, c->stream));
     CZ_HIP(hipStreamSynchronize(c->stream));
-    for (int g = 0; g < c->G; ++g) { *hits += h[2 * (size_t)g]; *lookups += h[2 * (size_t)g + 1]; }
+    for (int g = 0; g < c->G; ++g) { *hits += h[(size_t)g].ec_hits; *lookups += h[(size_t)g].ec_lookups; }
     return CZ_OK;
 }
 int cz_search_set_terminal_extra(cz_ctx *c, int n) {
@@ -356,12 +349,7 @@ int cz_search_advance(cz_ctx *c, const uint16_t *played) {
 }
 int cz_search_status(cz_ctx *c, int32_t *status, int32_t *nodes, int32_t *sims, int32_t *depth) {
     CZ_REQUIRE(c && c->G > 0, "cz_search_status: no search");
-    const size_t b = sizeof(int32_t) * (size_t)c->G;
-    if (status) CZ_HIP(hipMemcpyAsync(status, c->t.status, b, hipMemcpyDeviceToDevice, c->stream));
-    if (nodes) CZ_HIP(hipMemcpyAsync(nodes, c->t.n_nodes, b, hipMemcpyDeviceToDevice, c->stream));
-    if (sims) CZ_HIP(hipMemcpyAsync(sims, c->t.sims, b, hipMemcpyDeviceToDevice, c->stream));
-    if (depth) CZ_HIP(hipMemcpyAsync(depth, c->t.last_depth, b, hipMemcpyDeviceToDevice, c->stream));
-    return CZ_OK;
+    return czk_search_status(c, status, nodes, sims, depth);
 }
 
 int cz_selfplay_begin(cz_ctx *c, int max_plies, const uint8_t *boards, const uint8_t *side, const int32_t *rr) {
@@ -423,8 +411,8 @@ int cz_search_tree_dump(cz_ctx *c, int g, int32_t *out, int max_records) {
     CZ_REQUIRE(c && c->G > 0 && g >= 0 && g < c->G, "cz_search_tree_dump: bad tree index");
     CZ_HIP(hipStreamSynchronize(c->stream));
     int32_t root = 0, n = 0;
-    CZ_HIP(hipMemcpy(&root, c->t.root_node + g, 4, hipMemcpyDeviceToHost));
-    CZ_HIP(hipMemcpy(&n, c->t.n_nodes + g, 4, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(&root, &c->t.root_node[g], 4, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(&n, &c->t.n_nodes[g], 4, hipMemcpyDeviceToHost));
     const CzPool &p = c->t.pool;
     const size_t base = (size_t)g * (size_t)c->cap;
     std::vector<float> P(n), W(n), Q(n);

@@ -1,5 +1,6 @@
 // cz_internal.h — context layout and helpers shared by the libcchess_hip translation units.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -64,32 +65,60 @@ struct CzSelfplay {
 #define CZ_EC_BUCKETS 128
 #define CZ_EC_ENTRIES (CZ_EC_BUCKETS * 64)
 
+// Per-tree scalars: ONE 64-byte record per tree instead of sixteen arrays.  A wave owns a tree, so what it reads at entry
+// (root, counters, status) and leaves behind (the pending leaf) is one cache line, and the kernels hold one base pointer
+// instead of sixteen (the select kernels spilled 30-60 SGPRs keeping the array bases alive).  Kernel code keeps the array
+// syntax — t.status[g] — through CzRecField: every field of the union below IS the record pointer plus a constant offset.
+struct CzTreeRec {
+    int32_t root_rr, root_node, n_nodes, status;      //  0
+    int32_t sims, last_depth, pend_kind, pend_leaf;   // 16  pending leaf between select and expand_backup (width 1)
+    float pend_value;                                 // 32
+    int32_t pend_depth;                               // 36  levels of the pending path (pend_path)
+    uint32_t ec_hits, ec_lookups;                     // 40  evaluation cache statistics of the tree
+    unsigned long long pend_key;                      // 48  Zobrist key of the pending leaf (evaluation cache)
+    uint16_t pend_nmoves;                             // 56
+    uint8_t root_side, pend_side;                     // 58
+    uint32_t pad_;                                    // 60
+};
+static_assert(sizeof(CzTreeRec) == 64, "CzTreeRec is one 64-byte line per tree");
+
+template <typename T, int OFF>
+struct CzRecField {
+    char *base;
+    __host__ __device__ __forceinline__ T &operator[](int g) const { return *reinterpret_cast<T *>(base + (size_t)g * sizeof(CzTreeRec) + OFF); }
+};
+#define CZ_REC_FIELD(type, name) CzRecField<type, offsetof(CzTreeRec, name)> name
+
 struct CzTrees {
     CzPool pool;         // [max_games * cap]
     int cap;
     int words;           // ceil(cap / 64): 64-node words of the advance bitmap
     unsigned long long *mark_bits;   // [max_games][words] k_advance: which nodes of the tree are kept
     uint32_t *mark_rank;             // [max_games][words] kept nodes before the word = new index of its first kept node
-    // per tree [max_games]
     uint8_t *root_board; // [max_games][96]
-    uint8_t *root_side;
-    int32_t *root_rr, *root_node, *n_nodes, *status, *sims, *last_depth;
-    // pending leaf between select and expand_backup
-    int32_t *pend_kind, *pend_leaf;
-    float *pend_value;
-    uint8_t *pend_side;
-    uint16_t *pend_nmoves, *pend_moves;  // [max_games][128]
+    union {              // [max_games] records; t.<field>[g] addresses rec[g].<field>
+        CzTreeRec *rec;
+        CZ_REC_FIELD(int32_t, root_rr); CZ_REC_FIELD(int32_t, root_node); CZ_REC_FIELD(int32_t, n_nodes);
+        CZ_REC_FIELD(int32_t, status); CZ_REC_FIELD(int32_t, sims); CZ_REC_FIELD(int32_t, last_depth);
+        CZ_REC_FIELD(int32_t, pend_kind); CZ_REC_FIELD(int32_t, pend_leaf); CZ_REC_FIELD(float, pend_value);
+        CZ_REC_FIELD(int32_t, pend_depth); CZ_REC_FIELD(uint32_t, ec_hits); CZ_REC_FIELD(uint32_t, ec_lookups);
+        CZ_REC_FIELD(unsigned long long, pend_key); CZ_REC_FIELD(uint16_t, pend_nmoves);
+        CZ_REC_FIELD(uint8_t, root_side); CZ_REC_FIELD(uint8_t, pend_side);
+    };
+    uint16_t *pend_moves;             // [max_games * width][128] legal moves of the pending leaves
     // the selected path of the pending simulation (width 1): node index per level below the root, so that the backup
     // updates all levels in parallel instead of chasing parent pointers (one dependent round trip per level)
-    int32_t *pend_depth;              // [max_games]
     int32_t *pend_path;               // [max_games][CZ_PATH_MAX]
+    // pending leaves of the width > 1 kernels (k_select_k / k_expand_backup_k), slot = tree * width + j
+    int32_t *pk_kind, *pk_leaf;       // [max_games * width]
+    float *pk_value;
+    uint8_t *pk_side;
+    uint16_t *pk_nmoves;
     // evaluation cache (cz_search_set_eval_cache): per tree CZ_EC_BUCKETS buckets of 64 entries {Zobrist key of an expanded
     // node's position, its node index, the value its evaluation backed up}.  The priors are the node's children's P.
     unsigned long long *ec_key;       // [max_games][CZ_EC_ENTRIES]  0 = empty      (NULL: cache off)
     int32_t *ec_node;                 // [max_games][CZ_EC_ENTRIES]
     float *ec_val;                    // [max_games][CZ_EC_ENTRIES]
-    unsigned long long *pend_key;     // [max_games] key of the pending leaf (select -> expand_backup)
-    uint32_t *ec_stats;               // [max_games][2] hits, lookups of the tree (summed by cz_search_eval_cache_stats)
     // compact evaluation batches (cz_search_select_compact): row of the step's leaf in planes / z / value, or -1
     int32_t *slot_of;                 // [max_games]
     int32_t *evcnt;                   // [2] rows handed out this step / next step (ping-pong, zeroed one step ahead)
@@ -153,6 +182,8 @@ int czk_apply_move(cz_ctx *, uint8_t *, uint8_t *, const uint16_t *, int, uint64
 int czk_hash(cz_ctx *, const uint8_t *, const uint8_t *, int, uint64_t *);
 int czk_encode_planes(cz_ctx *, const uint8_t *, const uint8_t *, int, void *, int, int, int);
 int czk_search_reset(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *, int, const uint8_t *which);
+int czk_search_status(cz_ctx *, int32_t *, int32_t *, int32_t *, int32_t *);
+int czk_search_clear_cache_stats(cz_ctx *);
 int czk_search_select(cz_ctx *, int, const uint8_t *, void *, int, int, uint8_t *, bool compact = false);
 int czk_search_expand_backup(cz_ctx *, const void *, const void *, int);
 int czk_search_expand_backup_fc(cz_ctx *, const float *, const float *, const float *, const float *, bool compact);

@@ -51,6 +51,9 @@ __device__ __forceinline__ unsigned long long wave_position_key(const uint8_t *b
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) h ^= __shfl_xor(h, d, 64);
     if (side) h ^= zob[15 * CZ_NSQ];
+    // the key is wave-uniform: keep it in scalar registers (the select kernel sits exactly at its 64-VGPR budget)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)h), hi = __builtin_amdgcn_readfirstlane((uint32_t)(h >> 32));
+    h = ((unsigned long long)hi << 32) | lo;
     return h ? h : 1ull;
 }
 __device__ __forceinline__ int ec_bucket(unsigned long long key) { return (int)((key >> 17) & (CZ_EC_BUCKETS - 1)); }
@@ -99,12 +102,14 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
         const int c0 = b[lane], c1 = (lane + 64 < CZ_NSQ) ? b[lane + 64] : 0;
         const bool Kmiss0 = (__ballot(c0 == 1) | __ballot(c1 == 1)) == 0ull;
         const bool kmiss0 = (__ballot(c0 == 8) | __ballot(c1 == 8)) == 0ull;
-        const int rcb = v.child_begin[root];
+        // wave-uniform values are moved to scalar registers explicitly (readfirstlane / readlane): the compiler cannot prove
+        // that the result of the butterfly argmax is uniform, and the kernel sits at its 64-VGPR budget
+        const int rcb = __builtin_amdgcn_readfirstlane(v.child_begin[root]);
         if (rcb < 0) {
             kind = 3; leaf = root;  // MCTS_tree.main root expansion, main.py:475-487
         } else if (mode != 0) {
             // the root's own record does not change while simulations complete (the root is never backed up, quirk Q2)
-            const int rcc = v.child_count[root], rN = v.N[root];
+            const int rcc = __builtin_amdgcn_readfirstlane((int)v.child_count[root]), rN = __builtin_amdgcn_readfirstlane(v.N[root]);
             int extra_left = extra;
             for (;;) {   // one descent per iteration
                 if (sim_target > 0 && s0 + done_here >= sim_target) { kind = 0; break; }   // this tree has had its playouts
@@ -151,14 +156,14 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                         Cand o; o.s = __shfl_xor(best.s, d, 64); o.i = __shfl_xor(best.i, d, 64);
                         best = better(best, o);
                     }
-                    int bi = best.i;
-                    if (__shfl((int)first_nan, 0, 64)) bi = 0;  // a NaN first element is never displaced by `>`
+                    int bi = __builtin_amdgcn_readfirstlane(best.i);
+                    if (__builtin_amdgcn_readfirstlane((int)first_nan)) bi = 0;  // a NaN first element is never displaced by `>`
                     const int c = cb + bi;
                     const int wl = bi & 63, wr = bi >> 6;   // the winner sits in lane wl, round wr
-                    const int sd = __shfl(wr ? cSd[1] : cSd[0], wl, 64);
-                    const int nbeg = __shfl(wr ? cBeg[1] : cBeg[0], wl, 64);
-                    const int ncnt = __shfl(wr ? cCnt[1] : cCnt[0], wl, 64);
-                    const int nn = __shfl(wr ? cN[1] : cN[0], wl, 64);
+                    const int sd = __builtin_amdgcn_readlane(wr ? cSd[1] : cSd[0], wl);
+                    const int nbeg = __builtin_amdgcn_readlane(wr ? cBeg[1] : cBeg[0], wl);
+                    const int ncnt = __builtin_amdgcn_readlane(wr ? cCnt[1] : cCnt[0], wl);
+                    const int nn = __builtin_amdgcn_readlane(wr ? cN[1] : cN[0], wl);
                     const int src = sd & 0xFF, dst = sd >> 8;
                     const int cap = b[dst];
                     __syncthreads();
@@ -202,11 +207,11 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                         const unsigned long long m = __ballot(ek == key);
                         if (m) {
                             const int hl = __ffsll((long long)m) - 1;
-                            src = __shfl(en, hl, 64);
-                            pend = __shfl(ev, hl, 64);
+                            src = __builtin_amdgcn_readlane(en, hl);
+                            pend = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), hl));
                             hit = true;
                         }
-                        if (lane == 0) { t.ec_stats[2 * g] += hit ? 1u : 0u; t.ec_stats[2 * g + 1] += 1u; }
+                        if (lane == 0) { t.ec_hits[g] += hit ? 1u : 0u; t.ec_lookups[g] += 1u; }
                     }
                     if (!hit) break;
                     const int scb = v.child_begin[src], n = v.child_count[src];
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(64) void k_select_compact(CzTrees t, CzTables tab, 
 // With the evaluation cache (cz_search_set_eval_cache): the same descent, plus the lookup at the leaf and the expansion from
 // a lender node inside the launch.
 template <typename T>
-__global__ __launch_bounds__(64) void k_select_cache(CzTrees t, CzTables tab, int G, int mode,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_select_cache(CzTrees t, CzTables tab, int G, int mode,
                                                      const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                                      T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
     select_body<T, false, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
@@ -687,8 +692,8 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
             for (int e = lane; e < 90 * C; e += 64) pl[e] = (T)0;
         }
         if (lane == 0) {
-            t.pend_kind[slot] = kind; t.pend_leaf[slot] = leaf; t.pend_value[slot] = 0.f;
-            t.pend_side[slot] = (uint8_t)side; t.pend_nmoves[slot] = (uint16_t)nmoves;
+            t.pk_kind[slot] = kind; t.pk_leaf[slot] = leaf; t.pk_value[slot] = 0.f;
+            t.pk_side[slot] = (uint8_t)side; t.pk_nmoves[slot] = (uint16_t)nmoves;
             if (kind) t.last_depth[g] = depth;
             if (needs_eval) needs_eval[slot] = kind ? 1 : 0;
         }
@@ -709,11 +714,11 @@ __global__ __launch_bounds__(64) void k_expand_backup_k(CzTrees t, CzTables tab,
     const int root = t.root_node[g];
     for (int j = 0; j < K; ++j) {
         const size_t slot = (size_t)g * K + j;
-        const int kind = t.pend_kind[slot];
+        const int kind = t.pk_kind[slot];
         if (kind == 0) continue;
-        const int leaf = t.pend_leaf[slot];
-        const int n = t.pend_nmoves[slot];
-        const int sd = t.pend_side[slot];
+        const int leaf = t.pk_leaf[slot];
+        const int n = t.pk_nmoves[slot];
+        const int sd = t.pk_side[slot];
         const int begin = t.n_nodes[g];
         const bool fits = begin + n <= t.cap;
         __syncthreads();
@@ -763,7 +768,7 @@ __global__ __launch_bounds__(64) void k_expand_backup_k(CzTrees t, CzTables tab,
             }
             t.sims[g] += 1;
         }
-        if (lane == 0) t.pend_kind[slot] = 0;
+        if (lane == 0) t.pk_kind[slot] = 0;
         __threadfence_block();
         __syncthreads();
     }
@@ -943,7 +948,34 @@ __global__ void k_root_state(CzTrees t, int G, uint8_t *__restrict__ boards, uin
     if (lane == 0) { if (side) side[g] = t.root_side[g]; if (rr) rr[g] = t.root_rr[g]; }
 }
 
+__global__ void k_status(CzTrees t, int G, int32_t *__restrict__ status, int32_t *__restrict__ nodes, int32_t *__restrict__ sims,
+                         int32_t *__restrict__ depth) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    if (status) status[g] = t.status[g];
+    if (nodes) nodes[g] = t.n_nodes[g];
+    if (sims) sims[g] = t.sims[g];
+    if (depth) depth[g] = t.last_depth[g];
+}
+
+__global__ void k_clear_cache_stats(CzTrees t, int G) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) { t.ec_hits[g] = 0u; t.ec_lookups[g] = 0u; }
+}
+
 }  // namespace
+
+int czk_search_status(cz_ctx *c, int32_t *status, int32_t *nodes, int32_t *sims, int32_t *depth) {
+    hipLaunchKernelGGL(k_status, dim3((c->G + 255) / 256), dim3(256), 0, c->stream, c->t, c->G, status, nodes, sims, depth);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_clear_cache_stats(cz_ctx *c) {
+    hipLaunchKernelGGL(k_clear_cache_stats, dim3((c->max_games + 255) / 256), dim3(256), 0, c->stream, c->t, c->max_games);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
 
 int czk_search_reset(cz_ctx *c, const uint8_t *boards, const uint8_t *side, const int32_t *rr, int G, const uint8_t *which) {
     hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, c->stream, c->t, boards, side, rr, G, which);
