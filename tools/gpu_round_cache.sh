@@ -1,5 +1,5 @@
 #!/bin/bash
-# Final check of the round: full GPU suite + the evaluation-cache lines quoted in DESIGN.md.  usage: tools/gpu_round_ec2.sh [tag]
+# Final check of the round: full GPU suite + the evaluation-cache lines quoted in DESIGN.md.  usage: tools/gpu_round_cache.sh [tag]
 TAG=${1:-r02q}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
