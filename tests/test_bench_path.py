@@ -178,3 +178,58 @@ def test_fused_search_agrees_with_fp32_engine(dname):
                                                          np.abs(sa["P"] - sb["P"]).max()))
     assert agree >= min_agree
     assert l1.mean() <= max_l1
+
+
+def test_schedule_optimisations_leave_full_batch_search_unchanged():
+    """BASELINE configs[2] batch (8192 trees, 7-block bf16 fused net), 200 simulations per tree, crossing one re-root:
+    the product schedule bench.py times (simulations that need no net row completed inside the select launch, §4.8) and
+    the opt-in evaluation cache (§4.9) against the plain one-simulation-per-step schedule — every root statistic of every
+    tree (labels, N, W, Q, P bits) and every node count must be equal.  This is the size-independent form of the golden /
+    oracle tree tests: whatever the number of trees, the REAL net returns the same bits for the same position, so
+    completing a simulation early or lending an earlier evaluation cannot change a tree."""
+    from cchess_zero_amd.engine import Context, SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet
+    G, playouts, cap = 8192, 200, 200 * 96
+    boards, side, rr = _positions(G, 1000)
+
+    def run(extra, cache):
+        ctx = Context(G, cap, 0)
+        eng = SearchEngine(G, cap, 0, plane_dtype=torch.bfloat16, channels=16, ctx=ctx)
+        net = PolicyValueNet(7, "cuda:0", torch.bfloat16, seed=0, ctx=ctx)
+        if cache:
+            eng.set_eval_cache(True)
+        eng.reset(boards, side, rr)
+        eng.set_terminal_extra(extra)
+        out, steps = [], 0
+        for ply in range(2):
+            steps += eng.search(net.forward_device, playouts)
+            rs = eng.root_stats()
+            st, nodes, sims, _ = eng.status()
+            assert bool(((sims == playouts) | ((st & ~8) != 0)).all().item())   # a tree that stopped (full pool, no moves) keeps its flag
+            assert int(((st & ~8) != 0).sum().item()) < G // 100
+            out.append({k: v.clone() for k, v in rs.items()})
+            out[-1]["nodes"], out[-1]["status"], out[-1]["sims"] = nodes.clone(), st.clone(), sims.clone()
+            n = rs["N"].clone()
+            cnt = (rs["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
+            n[torch.arange(128, device=n.device).unsqueeze(0) >= cnt] = -1
+            played = rs["label"].gather(1, n.argmax(dim=1, keepdim=True)).squeeze(1)
+            eng.advance(torch.where(cnt.squeeze(1) > 0, played, torch.full_like(played, -1)))
+        hits = eng.eval_cache_stats() if cache else (0, 0)
+        eng.set_terminal_extra(0)
+        if cache:
+            eng.set_eval_cache(False)
+        return out, steps, hits
+
+    ref, steps0, _ = run(0, False)
+    assert steps0 == 2 * playouts
+    for extra, cache in ((4, False), (4, True)):
+        got, steps, hits = run(extra, cache)
+        for ply in range(2):
+            for k in ref[ply]:
+                a, b = ref[ply][k], got[ply][k]
+                if a.dtype.is_floating_point:
+                    a, b = a.view(torch.int32), b.view(torch.int32)
+                assert torch.equal(a, b), (extra, cache, ply, k)
+        print("8192 trees x 2 plies x %d playouts, terminal_extra %d, cache %s: %d lock-steps instead of %d; cache hits %d / %d" %
+              (playouts, extra, cache, steps, steps0, hits[0], hits[1]))
+        assert steps <= steps0
