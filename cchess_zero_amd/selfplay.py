@@ -219,6 +219,7 @@ class SelfPlay:
         assert self.continuous, "asynchronous plies re-seed finished slots at once"
         eng = self.eng
         fwd = forward or self.net.forward_device
+        prev_extra = eng.terminal_extra
         eng.set_terminal_extra(terminal_extra)
         eng.set_sim_target(self.playouts)
         try:
@@ -229,7 +230,7 @@ class SelfPlay:
                     self._transition(self.playouts)
         finally:
             eng.set_sim_target(0)
-            eng.set_terminal_extra(0)
+            eng.set_terminal_extra(prev_extra)
 
     def play(self, forward=None, max_plies=None):
         """continuous=False: play until every game has ended (or max_plies plies); returns the drained records.
