@@ -158,6 +158,30 @@ def cpu_baseline(blocks, seconds_target=12.0):
     return out
 
 
+def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
+    """K1 on its own (48 B board in + 264 B mask out = 312 B/position, HBM-bound in principle): cz_movegen_mask
+    over n positions (the run's synthetic positions, tiled), HIP events around `reps` launches."""
+    G = boards.shape[0]
+    b = boards.repeat((n + G - 1) // G, 1)[:n].contiguous()
+    sd = side.repeat((n + G - 1) // G)[:n].contiguous()
+    rules.movegen(b, sd, want_mask=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        rules.movegen(b, sd, want_mask=True)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    alg = 312.0 * n
+    abi = (90 + 1 + 256 + 264 + 2) * float(n)
+    return {"bound": "hbm", "kernel": "k_movegen (stand-alone K1: ordered move list + 2086-bit mask; inside the search the generator runs in k_select)",
+            "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "positions": n, "positions_per_s": n / sec, "us_per_launch": sec * 1e6, "algorithmic_bytes_per_position": 312,
+            "abi_bytes_per_position": abi / n, "abi_GBps": abi / sec / 1e9,
+            "note": "issue-bound (VALU + LDS round trips of the per-piece generator), not bandwidth-bound: see DESIGN.md"}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a bare shell: start the N ranks through torch.distributed.run."""
     s = socket.socket()
@@ -179,7 +203,10 @@ def main():
     ap.add_argument("--games", type=int, default=8192, help="game trees per GPU")
     ap.add_argument("--playout", type=int, default=1600)
     ap.add_argument("--blocks", type=int, default=7)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="MFMA operand type of the tower (fp32 accumulate).  fp16 (default): the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output)")
+    ap.add_argument("--age-steps", type=int, default=800, help="untimed lock-steps BEFORE --warmup that bring every tree to a representative phase of its search: each tree's first search is cut at its own threshold (uniform in [8, age-steps] simulations), so when the timed region starts the trees are spread over the phases of a playout-long search on subtrees kept from a previous ply — the state of a long run — instead of all standing 25 simulations into a fresh search")
+    ap.add_argument("--steady-steps", type=int, default=800, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
@@ -279,10 +306,20 @@ def main():
     start_side, start_rr = torch.zeros(G, dtype=torch.uint8, device=dev), torch.zeros(G, dtype=torch.int32, device=dev)
     TE = max(0, args.terminal_extra) if K == 1 else 0
 
+    # ageing: the FIRST search of tree g ends after thr[g] simulations (uniform in [8, age_steps]), every later one after `playout`
+    gen_age = torch.Generator(device=dev).manual_seed(4242 + rank)
+    age = max(0, args.age_steps)
+    thr = torch.full((G,), playout, dtype=torch.int32, device=dev)
+    if age >= 8 and not args.selfplay:
+        thr = torch.randint(8, age + 1, (G,), generator=gen_age, device=dev, dtype=torch.int32).clamp(max=playout)
+    min_thr = int(thr.min().item())
+    playout_t = torch.full((G,), playout, dtype=torch.int32, device=dev)
+
     def advance_ready():
         """update_tree for every tree whose search has had its playouts (or whose node pool is full): most visited child."""
         st, _, sims, _ = eng.status()
-        ready = (sims >= playout) | ((st & 1) != 0)
+        ready = (sims >= thr) | ((st & 1) != 0)
+        thr.copy_(torch.where(ready, playout_t, thr))
         banked.add_((sims.to(torch.int64) * ready).sum())
         rs = eng.root_stats()
         n = rs["N"].clone()
@@ -312,7 +349,7 @@ def main():
                 one_step(1, timed)   # mode 1 also expands the roots of trees that have just advanced
             steps_since_reset[0] += 1
             # no tree can have had its playouts before playout / (K * (TE + 1)) steps have passed since the common start
-            if (i + 1) % args.advance_every == 0 and steps_since_reset[0] * K * (TE + 1) >= playout:
+            if (i + 1) % args.advance_every == 0 and steps_since_reset[0] * K * (TE + 1) >= min_thr:
                 advance_ready()
 
     sp = None
@@ -340,6 +377,7 @@ def main():
                     gather_stats["seconds"] += time.perf_counter() - t1
                 else:   # the consumer of the records: the finished games leave the device
                     gather_stats["records"] += len(sp.drain())
+        run_plies(age, False)
         run_plies(args.warmup, False)
     else:
         if args.eval_cache:
@@ -348,6 +386,7 @@ def main():
         eng.set_terminal_extra(TE)
         eng.set_sim_target(playout)
         one_step(0, False)          # MCTS_tree.main root expansion (not a simulation)
+        run(age, False)             # ageing (see --age-steps): independent of --warmup
         run(args.warmup, False)
     torch.cuda.synchronize()
     if args.graph and fused_fc and not compact and not args.selfplay:
@@ -362,29 +401,46 @@ def main():
             print("bench: HIP graph capture failed (%r), running eagerly" % (e,), file=sys.stderr)
             graph[0] = None
             torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
     count_sims = (lambda: sp.stats()["sims"]) if sp else (lambda: int(banked.item()) + int(eng.status()[2].sum().item()))
-    sims0 = count_sims()
-    rows0, csteps0 = eng.eval_totals() if compact else (0, 0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if sp:
-        run_plies(args.steps, True)
-    else:
-        run(args.steps, True)
-    torch.cuda.synchronize()
+
+    def timed_region(nsteps):
+        """barrier + synchronize, EXACTLY nsteps lock-steps, synchronize + barrier: -> (max-over-ranks seconds, this rank's
+        seconds, this rank's completed simulations, net rows of this rank [compact mode: measured])."""
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sims0 = count_sims()
+        rows0, csteps0 = eng.eval_totals() if compact else (0, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if sp:
+            run_plies(nsteps, True)
+        else:
+            run(nsteps, True)
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        dtm = mine
+        if dist_on:
+            tt = torch.tensor([mine], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtm = float(tt.item())
+        rows = float(G * K) * nsteps
+        rpl = float(G * K)
+        if compact:
+            rows1, csteps1 = eng.eval_totals()
+            rows = float(rows1 - rows0)
+            rpl = rows / max(1, csteps1 - csteps0)
+        return dtm, mine, count_sims() - sims0, rows, rpl
+
+    dt, my_dt, my_sims, my_rows, rows_per_launch = timed_region(args.steps)
+    steady = None
+    if args.steady_steps > 0:
+        steady = timed_region(args.steady_steps)
     if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    my_dt = dt
-    if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        # outside the timed region: the record exchange of the self-play loop (one all-gather of packed (s, pi, z) records,
+        # outside the timed regions: the record exchange of the self-play loop (one all-gather of packed (s, pi, z) records,
         # device-resident end to end) on a ragged token batch, so every N>1 run exercises the collective path
         from cchess_zero_amd import parallel, selfplay
         tok = torch.zeros((4 + rank, selfplay.REC_BYTES), dtype=torch.uint8, device=cdev)
@@ -395,7 +451,6 @@ def main():
         except Exception as e:   # the throughput number above must survive a failure of this (untimed) exchange
             gather_ok = "failed: %r" % (e,)
 
-    my_sims = count_sims() - sims0
     if sp:   # the self-play loop launches through SelfPlay.run_async: sample the kernels' durations on 16 extra, uncounted steps
         eng.set_terminal_extra(TE)
         eng.set_sim_target(playout)
@@ -427,20 +482,26 @@ def main():
     exp_us = float(np.mean([el(e[2], e[3]) for e in ev])) * 1e3 if ev else float("nan")
     # simulations are COUNTED (completed backups, per-tree device counters), not assumed: a parked tree (node pool
     # exhausted) or an abandoned descent (k > 1) contributes nothing.  With k = 1 and no parked tree this is G * steps.
-    mine = torch.tensor([float(my_sims)], dtype=torch.float64, device=cdev)
-    per_rank = [float(my_sims) / my_dt]
-    if dist_on:
-        pr = torch.zeros(world, dtype=torch.float64, device=cdev)
-        pr[rank] = float(my_sims) / my_dt
-        dist.all_reduce(pr)
-        per_rank = pr.tolist()
-        dist.all_reduce(mine)
-    total_sims = float(mine.item())
-    # rows the net evaluated per launch: all G without compaction, else the measured mean over the timed region
-    rows_per_launch = float(G * K)
-    if compact:
-        rows1, csteps1 = eng.eval_totals()
-        rows_per_launch = (rows1 - rows0) / max(1, csteps1 - csteps0)
+    def totals(leg):
+        """(max-over-ranks seconds, my seconds, my sims, my rows, .) -> (sims of all ranks, net rows of all ranks, per-rank sims/s)."""
+        dtm, mine_dt, sims_, rows_, _ = leg
+        t = torch.tensor([float(sims_), float(rows_)], dtype=torch.float64, device=cdev)
+        pr_ = [float(sims_) / mine_dt]
+        if dist_on:
+            pr = torch.zeros(world, dtype=torch.float64, device=cdev)
+            pr[rank] = float(sims_) / mine_dt
+            dist.all_reduce(pr)
+            pr_ = pr.tolist()
+            dist.all_reduce(t)
+        return float(t[0].item()), float(t[1].item()), pr_
+    total_sims, total_rows, per_rank = totals((dt, my_dt, my_sims, my_rows, rows_per_launch))
+    steady_out = None
+    if steady is not None:
+        s_sims, s_rows, s_pr = totals(steady)
+        steady_out = {"steps": args.steady_steps, "seconds": steady[0], "value": s_sims / steady[0], "unit": "sims/s",
+                      "ms_per_step": steady[0] / args.steady_steps * 1e3, "net_rows_per_s": s_rows / steady[0],
+                      "simulations_per_net_row": s_sims / max(1.0, s_rows), "per_rank_sims_per_s": s_pr,
+                      "note": "a second barrier-bracketed timed region run right after the K contract steps, long enough (>= 2 s) for the driver's 5 s smi sampler to see the GPU busy; same loop, same counters"}
     flops = flops_per_position(args.blocks) * rows_per_launch
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     if conv_ev:
@@ -503,9 +564,10 @@ def main():
            "positions": "seeded random playouts from the start position, ply~U[0,80]",
            "nodes_per_tree": cap, "node_pool_GB": G * cap * 28 / 1e9,
            "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "per_rank_sims_per_s": per_rank,
-           "simulations_counted": total_sims, "net_rows_nominal": float(G) * args.steps * world * K,
-           "simulations_per_net_row": total_sims / (float(G) * args.steps * world * K), "terminal_extra": TE, "advance_every": args.advance_every,
-           "net_rows_per_s": float(G) * args.steps * world * K / dt,
+           "simulations_counted": total_sims, "net_rows": total_rows,
+           "simulations_per_net_row": total_sims / max(1.0, total_rows), "terminal_extra": TE, "advance_every": args.advance_every,
+           "net_rows_per_s": total_rows / dt,
+           "age_steps": age, "tree_state_at_t0": ("every tree has finished a first, shortened search (cut at its own threshold, uniform in [8, %d] simulations) and stands at its own phase of a %d-playout search on the subtree it kept" % (age, playout)) if (age >= 8 and not sp) else "fresh searches",
            "eval_cache": (dict(zip(("hits", "lookups"), eng.eval_cache_stats())) if args.eval_cache else None), "games_reloaded_rank0": int(reloaded.item()),
            "mean_leaf_depth": mean_depth, "mean_nodes_per_tree": float(nodes.float().mean().item()),
            "trees_with_error_status": bad, "status_bits": st_bits}
@@ -520,17 +582,39 @@ def main():
         "metric": "MCTS simulations/sec (whole node), playout=%d, %d-block net" % (playout, args.blocks),
         "value": total_sims / dt, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic", "config": cfg, "roofline": roof, "roofline_tree": tree_roof,
+        "dtype": args.dtype, "data": "synthetic", "steady_state": steady_out, "net_error": None, "config": cfg,
+        "roofline": roof, "roofline_tree": tree_roof, "roofline_rules": None,
     }
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.blocks, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        # precision of the benchmarked engine, measured here: the net exactly as timed (same weights) and a peaked,
+        # trained-like weight set, against fp32 on the same inputs (256 of the run's own synthetic positions)
+        try:
+            from cchess_zero_amd.net import net_error, trained_like_
+            xs = rules.encode_planes(boards[:256], side[:256]).float()
+            ne = {"reference": "fp32 torch module on the device, same weights and inputs (that engine: <= 3e-5 of the NumPy restatement of the reference graph, tests/test_net.py)",
+                  "as_benchmarked_glorot": net_error(net, xs)}
+            net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
+            trained_like_(net_t, xs[:96])
+            ne["trained_like"] = net_error(net_t, xs)
+            ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] = bool(ne["as_benchmarked_glorot"]["dlogit"] <= 1e-3 and ne["as_benchmarked_glorot"]["dvalue"] <= 1e-3)
+            out["net_error"] = ne
+        except Exception as e:
+            out["net_error"] = {"error": repr(e)}
+        try:
+            out["roofline_rules"] = rules_roofline(rules, boards, side)
+        except Exception as e:
+            out["roofline_rules"] = {"error": repr(e)}
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU baseline runs after every rank has left the timed regions and the process group (N > 1: the other ranks
+        # have exited or are exiting; a shorter sample keeps the multi-GPU line quick)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.blocks, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 5.0))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -170,6 +170,7 @@ class SelfPlay:
         self._stats = torch.zeros(len(SP_STATS), dtype=torch.int64, device=self.dev)
         self.plies = 0
         self.lock_steps = 0
+        self._dropped_seen = 0
 
     # -- one ply of every game ------------------------------------------------------------------------
     def step_ply(self, forward=None, forced=None):
@@ -259,7 +260,18 @@ class SelfPlay:
 
     def drain_device(self):
         """-> uint8 [n, REC_BYTES] DEVICE tensor with the records finished since the last drain (synchronises on the
-        cursor only).  The returned rows stay valid until the ring wraps over them."""
+        cursor and the drop counter).  The returned rows stay valid until the ring wraps over them.  Raises if finished
+        games have been DROPPED since the last drain because the ring was full of undrained rows (cz_selfplay_flush skips
+        such a game but the cursor still advances by its length: the rows returned here would contain stale slots) —
+        drain more often or pass a larger ring_records."""
+        self.eng.ctx.bind_stream()
+        check(lib().cz_selfplay_stats(self.eng.ctx.h, C.c_void_p(self._stats.data_ptr())), "cz_selfplay_stats")
+        dropped = int(self._stats[SP_STATS.index("dropped")].item())
+        if dropped > self._dropped_seen:
+            n_new = dropped - self._dropped_seen
+            self._dropped_seen = dropped
+            raise RuntimeError("self-play record ring overflow: %d records of finished games were dropped since the last drain "
+                               "(ring of %d records; drain more often or raise ring_records)" % (n_new, self.ring.shape[0]))
         c = int(self.cursor.item())
         r, R = self._read, self.ring.shape[0]
         n = min(c - r, R)

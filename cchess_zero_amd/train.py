@@ -101,7 +101,17 @@ class Trainer:
         self.global_step = int(d.get("global_step", 0))
 
 
-def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multiplier, kl_targ, seed=0, log=print, temperature=1.0):
+def kl_estimate_rows(old_probs, new_probs):
+    """The reference's per-row KL estimate on what forward() returns — RAW LOGITS (main.py:1175-1181): the terms
+    old * log((old + 1e-10) / (new + 1e-10)), minus the ones that print as 'nan' or 'inf' (a '-inf' term is kept, like
+    there), summed per row — in the dtype forward() returns (float32), as np.sum / np.mean do there."""
+    with np.errstate(all="ignore"):
+        kl_tmp = old_probs * (np.log((old_probs + 1e-10) / (new_probs + 1e-10)))
+    return np.array([np.sum(line[~(np.isnan(line) | (line == np.inf))]) for line in kl_tmp])
+
+
+def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multiplier, kl_targ, seed=0, log=print, temperature=1.0,
+                  save=True, sample=None):
     """cchess_main.policy_update (main.py:1157-1204).  net: forward(list of planes) -> (logits, value) ndarrays,
     train_step(...) -> (accuracy, loss, global_step), save(step), global_step.  Returns (lr_multiplier, info dict).
 
@@ -109,11 +119,17 @@ def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multip
 
     Rank-consistent by construction: the mini-batch indices come from random.Random(seed, global step) — identical on
     every rank because every rank holds the same gathered buffer —, rank r trains on elements r::world of it, and the
-    KL estimate is averaged over the ranks before the early-stop / learning-rate decisions."""
+    KL estimate is averaged over the ranks before the early-stop / learning-rate decisions.
+    save=False skips the checkpoint (the batched loop of main.py saves once per self-play batch, not once per update);
+    sample: explicit buffer indices instead of the seeded draw (tests)."""
     world = dist.get_world_size() if _dist_on() else 1
     rank = dist.get_rank() if _dist_on() else 0
     rng = random.Random((int(seed) << 32) ^ int(net.global_step))
-    mini_batch = rng.sample(list(data_buffer), batch_size)[rank::world]   # main.py:1159 (random.sample)
+    if batch_size < world:
+        raise ValueError("batch_size %d is smaller than the number of ranks %d: a rank would train on nothing" % (batch_size, world))
+    # main.py:1159 (random.sample): indices are drawn, the buffer itself (possibly hundreds of thousands of records) is not copied
+    idx = list(sample) if sample is not None else rng.sample(range(len(data_buffer)), batch_size)
+    mini_batch = [data_buffer[i] for i in idx[rank::world]]
     if isinstance(mini_batch[0], np.ndarray) and mini_batch[0].dtype == np.uint8 and mini_batch[0].ndim == 1:
         # the buffer holds PACKED records (608 bytes each instead of 22 KB of dense planes + pi): only the mini-batch is
         # expanded to the reference's (state planes, pi[2086], z) tuples, pi with the reference's exact float64 expression
@@ -131,11 +147,9 @@ def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multip
         accuracy, loss, global_step = net.train_step(state_batch, mcts_probs_batch, winner_batch, learning_rate * lr_multiplier)
         steps += 1
         new_probs, new_v = net.forward(state_batch)
-        with np.errstate(all="ignore"):   # the reference feeds raw logits into its KL estimate (main.py:1175)
-            kl_tmp = old_probs * (np.log((old_probs + 1e-10) / (new_probs + 1e-10)))
-        kl_rows = np.array([np.sum(line[np.isfinite(line)]) for line in kl_tmp], np.float64)
+        kl_rows = kl_estimate_rows(old_probs, new_probs)   # the reference feeds raw logits into its KL estimate (main.py:1175)
         if world > 1:
-            t = torch.tensor([kl_rows.sum(), float(len(kl_rows))], dtype=torch.float64)
+            t = torch.tensor([float(kl_rows.astype(np.float64).sum()), float(len(kl_rows))], dtype=torch.float64)
             if dist.get_backend() == "nccl":
                 t = t.cuda()
             dist.all_reduce(t)
@@ -148,16 +162,18 @@ def policy_update(net, data_buffer, batch_size, epochs, learning_rate, lr_multip
         broadcast_weights(net.module, src=0)   # replicas stay bit-identical whatever the reduction order did
         if hasattr(net, "refresh"):
             net.refresh()
-    if rank == 0:
+    if rank == 0 and save:
         net.save(net.global_step)
     log("train using time {} s".format(time.time() - start_time))
     if kl > kl_targ * 2 and lr_multiplier > 0.1:
         lr_multiplier /= 1.5
     elif kl < kl_targ / 2 and lr_multiplier < 10:
         lr_multiplier *= 1.5
-    wb = np.array(winner_batch).flatten()
-    var = np.var(wb) + 1e-12
-    info = dict(kl=kl, lr_multiplier=lr_multiplier, loss=loss, accuracy=accuracy, steps=steps,
-                explained_var_old=1 - np.var(wb - np.asarray(old_v).flatten()) / var,
-                explained_var_new=1 - np.var(wb - np.asarray(new_v).flatten()) / var)
+    # the figures the reference logs (main.py:1197-1198): winner_batch is [B,1] there and old_v.flatten() is [B], so the
+    # difference broadcasts to a [B,B] matrix of z_i - v_j — reproduced as written (a report, nothing is decided on it)
+    wb = np.array(winner_batch)
+    with np.errstate(all="ignore"):
+        info = dict(kl=kl, lr_multiplier=lr_multiplier, loss=loss, accuracy=accuracy, steps=steps,
+                    explained_var_old=1 - np.var(wb - np.asarray(old_v).flatten()) / np.var(wb),
+                    explained_var_new=1 - np.var(wb - np.asarray(new_v).flatten()) / np.var(wb))
     return lr_multiplier, info

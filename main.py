@@ -478,9 +478,15 @@ class cchess_main(object):
     # ---- the batched training loop (main.py:1157-1248) ------------------------------------------------------
     def selfplay_batch(self, games=None, max_plies=None, target_games=None):
         """Self-play on `games` game slots of this GPU, device-resident and continuous (a finished game's slot starts
-        the next game at once, cchess_zero_amd/selfplay.py) until `target_games` games (default: one per slot) have
+        the next game at once, cchess_zero_amd/selfplay.py) until `target_games` more games (default: one per slot) have
         finished; returns the packed (s, pi, z) records of all ranks (one all-gather).  max_plies bounds the number of
-        plies played (tests)."""
+        plies played (tests).
+
+        The game slots LIVE ACROSS BATCHES: a game still in progress when the batch has its `target_games` is neither
+        thrown away nor restarted — it goes on in the next batch (with the new weights from there on; the evaluation cache
+        is emptied when the weights change) and its records are drained when it ends.  So every game that is started
+        reaches the buffer, long games and 60-ply draws included, as in the reference, which plays every game to its end
+        (main.py:1228-1240); stopping all slots at a batch boundary would keep only the games shorter than the batch."""
         import torch
         from cchess_zero_amd import parallel
         from cchess_zero_amd.engine import SearchEngine
@@ -491,18 +497,30 @@ class cchess_main(object):
         # stops expanding for the rest of that ply (the move is chosen from the visits it has) and gets its room back when
         # cz_search_advance compacts it
         cap = max(4096, (self.playout_counts + 2) * 128)
-        if getattr(self, "_batch_eng", None) is None or self._batch_eng.ctx.max_games < G or self._batch_eng.ctx.cap < cap:
-            self._batch_eng = SearchEngine(G, cap, torch.cuda.current_device())
-        # every rank seeds its games differently but reproducibly from the shared Python RNG state
-        base_seed = random.randrange(1 << 30)
-        rank = int(os.environ.get("RANK", "0"))
-        sp = SelfPlay(self._batch_eng, self.policy_value_netowrk.net, self.playout_counts, self.exploration, self.temperature,
-                      seed=base_seed + 7919 * rank, continuous=True,
-                      # the evaluation cache pays from a few hundred playouts per move on (in-tree repeat rate 1 % at 100
-                      # playouts, 4 % at 400, 12 % at 1600; the lookup costs the select launch 10-25 us)
-                      eval_cache=self.playout_counts >= 400)
-        b0 = np.tile(state_to_board(START_STATE), (G, 1))
-        sp.start(b0, np.zeros(G, np.uint8), np.zeros(G, np.int32))
+        net = self.policy_value_netowrk.net
+        sp = getattr(self, "_sp", None)
+        if sp is None or sp.eng.G != G or sp.eng.ctx.cap < cap or sp.playouts != self.playout_counts or sp.net is not net:
+            # planes are written by the select kernel straight in the fused net's input format (16 channels of its 16-bit type)
+            fused = net.backend == "hip" and net.dtype in (torch.float16, torch.bfloat16)
+            eng = SearchEngine(G, cap, torch.cuda.current_device(), plane_dtype=net.dtype if fused else torch.float32,
+                               channels=16 if fused else 14)
+            # every rank seeds its games differently but reproducibly from the shared Python RNG state
+            base_seed = random.randrange(1 << 30)
+            rank = int(os.environ.get("RANK", "0"))
+            sp = SelfPlay(eng, net, self.playout_counts, self.exploration, self.temperature,
+                          seed=base_seed + 7919 * rank, continuous=True,
+                          # the evaluation cache pays from a few hundred playouts per move on (in-tree repeat rate 1 % at 100
+                          # playouts, 4 % at 400, 12 % at 1600; the lookup costs the select launch 10-25 us)
+                          eval_cache=self.playout_counts >= 400)
+            b0 = np.tile(state_to_board(START_STATE), (G, 1))
+            sp.start(b0, np.zeros(G, np.uint8), np.zeros(G, np.int32))
+            self._sp, self._batch_eng = sp, eng
+            self._sp_weights_step = self.policy_value_netowrk.global_step
+        elif self._sp_weights_step != self.policy_value_netowrk.global_step:
+            if sp.eval_cache:
+                sp.eng.set_eval_cache(True)      # new weights: remembered evaluations are stale (turning it on empties it)
+            self._sp_weights_step = self.policy_value_netowrk.global_step
+        before = sp.stats()
         # asynchronous plies: every game moves when ITS search has had its playouts (simulations that end on a king capture
         # or the 60-ply rule complete inside the select launch and use no net row, so searches differ in length)
         chunks, plies = [], 0
@@ -512,20 +530,20 @@ class cchess_main(object):
             n = 8 if max_plies is None else max(1, min(8, max_plies - plies))
             sp.run_async(n * steps_per_ply, every=every, terminal_extra=4)
             plies += n
-            chunks.append(sp.drain_device().clone())
+            chunks.append(sp.drain_device().clone())     # raises if the ring overflowed (records would be missing)
             st = sp.stats()
-            if st["games"] >= target or (max_plies is not None and plies >= max_plies):
+            if st["games"] - before["games"] >= target or (max_plies is not None and plies >= max_plies):
                 break
-        self.last_selfplay_stats = sp.stats()
+        self.last_selfplay_stats = {k: (st[k] - before[k] if k in ("games", "red_wins", "black_wins", "draws", "plies", "sims", "lock_steps") else st[k]) for k in st}
         self.last_selfplay_sims = self.last_selfplay_stats["sims"]
         rec = torch.cat(chunks, 0) if chunks else sp.ring[:0]
         return parallel.gather_records(rec)
 
-    def policy_update(self):
+    def policy_update(self, save=True):
         from cchess_zero_amd.train import policy_update
         self.lr_multiplier, info = policy_update(self.policy_value_netowrk, self.data_buffer, self.batch_size, self.epochs,
                                                  self.learning_rate, self.lr_multiplier, self.kl_targ, seed=self.update_seed,
-                                                 temperature=self.temperature)
+                                                 temperature=self.temperature, save=save)
         self.global_step = self.policy_value_netowrk.global_step
         msg = "kl:{:.5f},lr_multiplier:{:.3f},loss:{},accuracy:{},explained_var_old:{:.3f},explained_var_new:{:.3f}".format(
             info["kl"], self.lr_multiplier, info["loss"], info["accuracy"], info["explained_var_old"], info["explained_var_new"])
@@ -559,8 +577,9 @@ class cchess_main(object):
                 order = np.random.RandomState(self.update_seed + batch_iter).permutation(n)   # same on every rank
                 self.data_buffer.extend(rec[i] for i in order)
                 if len(self.data_buffer) > self.batch_size:
-                    for _ in range(max(1, min(64, n // self.batch_size))):
-                        self.policy_update()
+                    updates = max(1, min(64, n // self.batch_size))
+                    for u in range(updates):   # the reference saves after its one update per game (main.py:1188): once per batch here
+                        self.policy_update(save=(u == updates - 1))
         except KeyboardInterrupt:
             self.log_file.close()
             self.policy_value_netowrk.save(self.global_step)

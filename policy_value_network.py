@@ -4,7 +4,7 @@
 
   reference (TF1 graph + session)                       here
   policy_value_network.py:45-74,151-162  graph          cchess_zero_amd/net.py (PyTorch-ROCm), tower convs by
-                                                         the fused MFMA kernel cz_net_trunk_bf16 (csrc/)
+                                                         the fused MFMA kernel cz_net_trunk_f16 (csrc/)
   :202-214  forward(positions)->(logits[B,2086], v[B,1]) identical signature; ndarray or list of [9,10,14]
   :77-126,186-199  loss / Nesterov-momentum SGD / clip   cchess_zero_amd/train.py Trainer: CE + MSE + 1e-4*sum(w^2)/2,
                                                          momentum 0.9, use_nesterov, clip_by_global_norm(100), NaN check
@@ -25,7 +25,11 @@ from cchess_zero_amd.train import Trainer
 
 
 class policy_value_network(object):
-    def __init__(self, res_block_nums=7, device=None, dtype=torch.bfloat16, save_dir="./models", seed=0):
+    def __init__(self, res_block_nums=7, device=None, dtype=torch.float16, save_dir="./models", seed=0):
+        """dtype: the tower's MFMA operand type.  fp16 (default) keeps forward() within the 1e-3 the hot path is specified
+        to (policy_value_network.py:202-214 is fp32 TF): |dlogit| 1.2e-4 on TF-default weights, 1.1e-3 of the largest
+        logit on peaked weights, 7 blocks; torch.float32 selects the torch/MIOpen fp32 engine (1e-7 .. 3e-5), bf16 the
+        same MFMA rate at 8x the error (tests/test_net.py)."""
         if not torch.cuda.is_available():
             raise RuntimeError("policy_value_network needs an MI355X (HIP) device; the cchess_hip path has no CPU fallback")
         self.save_dir = save_dir

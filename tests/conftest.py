@@ -33,6 +33,13 @@ def mcts_golden():
 
 
 @pytest.fixture(scope="session")
+def mcts_deep_golden():
+    """Reference searches at the metric's depth (playout 1600) and with selected paths of 40-60 levels (gen_mcts_deep)."""
+    import json
+    return json.load(open(os.path.join(GOLDEN, "mcts_deep.json")))
+
+
+@pytest.fixture(scope="session")
 def tables_golden():
     import json
     return json.load(open(os.path.join(GOLDEN, "tables.json")))

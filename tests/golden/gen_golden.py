@@ -16,6 +16,10 @@ Fixtures
   mcts.json    MCTS_tree.main (main.py:473) runs with search_threads=1 and the exact-integer
                fake forward of tests/fakenet.py: root children (label, N, W, Q, P bit
                patterns), whole-tree digests, the ordered list of evaluated positions.
+  mcts_deep.json  the same at the metric's depth — playout 1600, one black-to-move root, one near the 60-ply rule, one
+               across update_tree — and with the 'deep' fake forward whose searches select paths of 40-60 levels.
+  policy_update.npz  cchess_main.policy_update (main.py:1157-1204) through a stand-in self with a scripted net: train steps
+               taken, learning rates passed, lr_multiplier after, the logged KL / explained variances.
   selfplay.npz cchess_main.selfplay (main.py:1493) games with search_threads=1, the fake forward and
                a seeded np.random: per ply (canonical state, pi[2086] float64, z), the root
                children's visit counts and the sampled move (get_action, main.py:1332-1358).
@@ -25,6 +29,7 @@ import json
 import os
 import random
 import sys
+import types
 
 import numpy as np
 
@@ -234,6 +239,47 @@ def dump_tree(node):
     return rec
 
 
+def run_spec(m, sp, deep=False):
+    """One golden search case: MCTS_tree.main per ply with the fake forward, most visited move played (update_tree).
+    deep=True (mcts_deep.json): additionally the deepest level of the tree per ply, and the evaluated positions as a
+    digest instead of a list (1600-playout cases evaluate ~1600 positions per ply)."""
+    log = []
+    fwd = fakenet.make_forward(sp["mode"], sp["salt"], log)
+    state, player, rr = sp["fen"], sp["player"], sp["rr"]
+    t = rh.new_mcts(state, fwd, 1)
+    plies = []
+    for po in sp["playouts"]:
+        with rh.quiet(), np.errstate(all="ignore"):
+            t.main(state, player, rr, po)
+        root_children = [(m.label2i[a], int(c.N), f32bits(c.W), f32bits(c.Q), f32bits(c.P)) for a, c in t.root.child.items()]
+        tree = dump_tree(t.root)
+        digest = hashlib.sha256(np.asarray([(d, m.label2i[a], n, w, q, p, k) for (d, a, n, w, q, p, k) in tree],
+                                           dtype=np.int64).astype(np.int32).tobytes()).hexdigest()
+        # play the most visited move (first max), like update_tree after get_action
+        best = max(t.root.child.items(), key=lambda kv: kv[1].N)[0]
+        ply = dict(state=state, player=player, rr=rr, playouts=po, root=root_children,
+                   tree_records=len(tree), tree_sha256=digest, played=m.label2i[best],
+                   root_N=int(t.root.N), evals=len(log))
+        if deep:
+            ply["max_level"] = max(d for (d, a, n, w, q, p, k) in tree if n > 0)   # deepest VISITED node, root children = level 0
+        plies.append(ply)
+        nxt = m.GameBoard.sim_do_action(best, state)
+        rr = rr + 1 if m.is_kill_move(state, nxt) == 0 else 0
+        state = nxt
+        player = "b" if player == "w" else "w"
+        t.update_tree(best)
+        if "K" not in state or "k" not in state:
+            break
+    case = dict(name=sp["name"], mode=sp["mode"], salt=sp["salt"], plies=plies)
+    if deep:
+        case["eval_keys_sha256"] = hashlib.sha256(",".join("%016x" % k for k in log).encode()).hexdigest()
+    else:
+        case["eval_keys"] = ["%016x" % k for k in log]
+    print("mcts case %-18s plies=%d evals=%d tree=%s%s" % (sp["name"], len(plies), len(log), [p["tree_records"] for p in plies],
+                                                         (" max level %s" % [p["max_level"] for p in plies]) if deep else ""))
+    return case
+
+
 def gen_mcts(m, out, positions, king_roots, seed=7):
     rng = random.Random(seed)
     cases = []
@@ -253,34 +299,47 @@ def gen_mcts(m, out, positions, king_roots, seed=7):
         specs.append(dict(name="kingcap_signed%d" % i, fen=fen, player=pl, rr=0, playouts=[150, 80], mode="signed", salt=70 + i))
 
     for sp in specs:
-        log = []
-        fwd = fakenet.make_forward(sp["mode"], sp["salt"], log)
-        state, player, rr = sp["fen"], sp["player"], sp["rr"]
-        t = rh.new_mcts(state, fwd, 1)
-        plies = []
-        for po in sp["playouts"]:
-            with rh.quiet(), np.errstate(all="ignore"):
-                t.main(state, player, rr, po)
-            root_children = [(m.label2i[a], int(c.N), f32bits(c.W), f32bits(c.Q), f32bits(c.P)) for a, c in t.root.child.items()]
-            tree = dump_tree(t.root)
-            digest = hashlib.sha256(np.asarray([(d, m.label2i[a], n, w, q, p, k) for (d, a, n, w, q, p, k) in tree],
-                                               dtype=np.int64).astype(np.int32).tobytes()).hexdigest()
-            # play the most visited move (first max), like update_tree after get_action
-            best = max(t.root.child.items(), key=lambda kv: kv[1].N)[0]
-            plies.append(dict(state=state, player=player, rr=rr, playouts=po, root=root_children,
-                              tree_records=len(tree), tree_sha256=digest, played=m.label2i[best],
-                              root_N=int(t.root.N), evals=len(log)))
-            nxt = m.GameBoard.sim_do_action(best, state)
-            rr = rr + 1 if m.is_kill_move(state, nxt) == 0 else 0
-            state = nxt
-            player = "b" if player == "w" else "w"
-            t.update_tree(best)
-            if "K" not in state or "k" not in state:
-                break
-        cases.append(dict(name=sp["name"], mode=sp["mode"], salt=sp["salt"], plies=plies,
-                          eval_keys=["%016x" % k for k in log]))
-        print("mcts case %-18s plies=%d evals=%d tree=%s" % (sp["name"], len(plies), len(log), [p["tree_records"] for p in plies]))
+        cases.append(run_spec(m, sp))
     json.dump(dict(numpy=np.__version__, cases=cases), open(os.path.join(out, "mcts.json"), "w"), separators=(",", ":"))
+
+
+def gen_mcts_deep(m, out):
+    """mcts_deep.json: searches at the METRIC's depth (playout 1600, main.py:473-493 / README: train_playout) and searches
+    whose selected paths run far below 32 levels (fakenet mode 'deep'; the 60-ply rule, main.py:415-416, ends the longest
+    lines at level 60) — the long-path backups of the device search.  Positions come from the committed rules.npz."""
+    g = np.load(os.path.join(out, "rules.npz"))
+
+    def fen_of(i):
+        b = g["boards"][i].reshape(10, 9)
+        rows = []
+        for y in range(10):
+            row, run = "", 0
+            for x in range(9):
+                if b[y, x] == 0:
+                    run += 1
+                else:
+                    row += (str(run) if run else "") + PIECES[b[y, x]]
+                    run = 0
+            rows.append(row + (str(run) if run else ""))
+        return "/".join(rows), ("b" if g["side"][i] else "w")
+    ok = [i for i in range(len(g["boards"])) if (g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 20]
+    blacks = [i for i in ok if g["side"][i] == 1]
+    whites = [i for i in ok if g["side"][i] == 0]
+    fb, pb = fen_of(blacks[len(blacks) // 3])
+    fw, pw = fen_of(whites[len(whites) // 2])
+    fb2, pb2 = fen_of(blacks[2 * len(blacks) // 3])
+    specs = [
+        dict(name="p1600_start", fen=START, player="w", rr=0, playouts=[1600], mode="pos", salt=1600),
+        dict(name="p1600_black", fen=fb, player=pb, rr=7, playouts=[1600], mode="pos", salt=1601),
+        dict(name="p1600_rr52", fen=fw, player=pw, rr=52, playouts=[1600], mode="signed", salt=1602),
+        dict(name="p1600_2plies", fen=fb2, player=pb2, rr=0, playouts=[1600, 800], mode="pos", salt=1603),
+        dict(name="deep_start800", fen=START, player="w", rr=0, playouts=[800], mode="deep", salt=913),
+        dict(name="deep_2plies", fen=START, player="w", rr=0, playouts=[400, 200], mode="deep", salt=915),
+        dict(name="deep_black", fen=fb, player=pb, rr=0, playouts=[600], mode="deep", salt=904),
+        dict(name="deep_rr40", fen=fw, player=pw, rr=40, playouts=[500], mode="deep", salt=912),
+    ]
+    cases = [run_spec(m, sp, deep=True) for sp in specs]
+    json.dump(dict(numpy=np.__version__, cases=cases), open(os.path.join(out, "mcts_deep.json"), "w"), separators=(",", ":"))
 
 
 SELFPLAY_CASES = [
@@ -373,14 +432,100 @@ def gen_selfplay(m, out):
                         meta=np.asarray(json.dumps(meta)))
 
 
+def scripted_outputs(states, k, scale):
+    """The scripted net of the policy_update fixture: (logits, value) as exact functions of (state content, number of
+    train steps taken so far k, drift scale) — shared by this generator and tests/test_train.py."""
+    s = np.asarray(states, np.float64).reshape(len(states), -1)
+    key = s @ (np.arange(s.shape[1], dtype=np.float64) % 97 + 1.0)
+    j = np.arange(2086, dtype=np.float64)
+    base = ((key[:, None] * 0.37 + j[None, :] * 1.61) % 1.0) - 0.2          # raw logits, some negative (log -> nan, filtered)
+    drift = ((key[:, None] * 0.11 + j[None, :] * 0.73) % 1.0) - 0.5
+    logits = base + scale * k * drift
+    v = np.tanh(((key * 0.013) % 2.0) - 1.0 + 0.05 * k)
+    return logits.astype(np.float32), v.astype(np.float32).reshape(-1, 1)
+
+
+POLICY_UPDATE_CASES = [
+    # (name, drift scale of the scripted net per train step, lr_multiplier before)
+    dict(name="kl_small_raises_lr", scale=1e-4, lrm=1.0),
+    dict(name="kl_small_at_cap", scale=1e-4, lrm=10.5),
+    dict(name="kl_mid_keeps_lr", scale=6e-4, lrm=1.0),
+    dict(name="kl_large_lowers_lr", scale=1.6e-3, lrm=1.0),
+    dict(name="kl_stops_at_epoch3", scale=4e-3, lrm=3.0),
+    dict(name="kl_huge_stops_early", scale=0.6, lrm=2.25),
+    dict(name="kl_huge_at_floor", scale=0.6, lrm=0.09),
+]
+
+
+def gen_policy_update(m, out):
+    """cchess_main.policy_update of the UNMODIFIED reference (main.py:1157-1204) driven through a stand-in `self` with a
+    scripted net: the KL estimate on raw logits, the early stop at 4 x kl_targ, the x / 1.5 learning-rate adaptation with
+    its 0.1 / 10 bounds, and the explained-variance figures it logs."""
+    import re
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def write(self, x):
+            self.lines.append(x)
+
+        def flush(self):
+            pass
+
+    rng = np.random.RandomState(5)
+    B = 24
+    states = [(rng.rand(9, 10, 14) < 0.07).astype(np.float32) for _ in range(B)]
+    pis = [rng.dirichlet(np.ones(2086) * 0.05) for _ in range(B)]
+    zs = [float(rng.choice([-1.0, 0.0, 1.0])) for _ in range(B)]
+    cases = []
+    for c in POLICY_UPDATE_CASES:
+        class Net(object):
+            k = 0
+            lrs = []
+
+            def train_step(self, sb, pb, wb, lr):
+                Net.k += 1
+                Net.lrs.append(float(lr))
+                return 0.5, 1.25, 100 + Net.k
+
+            def save(self, step):
+                Net.saved = int(step)
+        Net.k, Net.lrs = 0, []
+
+        class Mcts(object):
+            def forward(self, sb):
+                return scripted_outputs(sb, Net.k, c["scale"])
+        fake = types.SimpleNamespace(data_buffer=list(zip(states, pis, zs)), batch_size=B, mcts=Mcts(), epochs=5,
+                                     policy_value_netowrk=Net(), learning_rate=0.001, lr_multiplier=c["lrm"], kl_targ=0.025,
+                                     log_file=Log(), global_step=0)
+        random.seed(99)
+        with rh.quiet(), np.errstate(all="ignore"):
+            m.cchess_main.policy_update(fake)
+        msg = fake.log_file.lines[-1]
+        f = dict(re.findall(r"(kl|lr_multiplier|explained_var_old|explained_var_new):([-+0-9.einfa]+)", msg))
+        cases.append(dict(c, steps=Net.k, lrs=Net.lrs, lr_multiplier_after=float(fake.lr_multiplier), saved_step=Net.saved,
+                          global_step=int(fake.global_step), kl_logged=f["kl"], explained_var_old_logged=f["explained_var_old"],
+                          explained_var_new_logged=f["explained_var_new"]))
+        print("policy_update case %-22s steps=%d lrm %.4f -> %.4f  log: %s" % (c["name"], Net.k, c["lrm"], fake.lr_multiplier, msg.strip()))
+    np.savez_compressed(os.path.join(out, "policy_update.npz"), states=np.stack(states).astype(np.uint8), pi=np.stack(pis), z=np.asarray(zs),
+                        meta=np.asarray(json.dumps(cases)))
+
+
 def main():
     m = rh.load_main()
     out = HERE
+    if "--policy-update-only" in sys.argv:
+        return gen_policy_update(m, out)
+    if "--deep-only" in sys.argv:
+        return gen_mcts_deep(m, out)
     if "--selfplay-only" not in sys.argv:
         gen_tables(m, out)
         positions, king_roots = gen_rules(m, out)
         gen_mcts(m, out, positions, king_roots)
     gen_selfplay(m, out)
+    gen_mcts_deep(m, out)
+    gen_policy_update(m, out)
 
 
 if __name__ == "__main__":

@@ -36,36 +36,9 @@ def structured_(net, seed=11):
 
 
 def trained_like_(net, seed=5):
-    """A weight set with the statistics of a trained net rather than of Glorot noise: non-negative policy FC weights
-    with a few strong feature -> move links (raw logits are the priors of this engine — quirk Q3 — and a trained net's
-    are positive and peaked on a few moves: |logit| ~ 10, softmax far from uniform), a value head with spread,
-    non-trivial BN statistics and biases."""
-    gen = torch.Generator().manual_seed(seed)
-    m = net.module
-    with torch.no_grad():
-        for cb in m.convbns():
-            dev = cb.conv.bias.device
-            cb.conv.bias.copy_((torch.randn(cb.conv.bias.shape, generator=gen) * 0.05).to(dev))
-            cb.moving_var.copy_((torch.rand(cb.moving_var.shape, generator=gen) * 0.5 + 0.75).to(dev))
-        w = m.policy_fc.weight
-        peaked = (torch.rand(w.shape, generator=gen) < 0.06).to(w.device)
-        w.copy_(w.abs() + peaked * w.abs() * 15.0)
-        m.policy_fc.bias.copy_((torch.rand(2086, generator=gen) * 0.02).to(w.device))
-        # both heads are calibrated on corpus positions, whatever the depth of the tower: the policy FC is scaled so that
-        # the largest logit of a position averages 10; the last value layer so that tanh's argument has mean 0 and std
-        # 0.6 (a Glorot-initialised head answers ~-0.65 +- 0.03 for every position: the search would see no value signal)
-        feats = []
-        hook = m.value_fc2.register_forward_hook(lambda mod, inp, out: feats.append(inp[0].detach()))
-        x = torch.from_numpy(positions(96, 123)).to(w.device).permute(0, 3, 1, 2)
-        logits, _ = m(x)
-        hook.remove()
-        w.mul_(10.0 / float(logits.max(dim=1).values.mean()))
-        pre = feats[0] @ m.value_fc2.weight.t()
-        k = 0.6 / float(pre.std())
-        m.value_fc2.weight.mul_(k)
-        m.value_fc2.bias.fill_(-float(pre.mean()) * k)
-    net.refresh()
-    return net
+    """Trained-like weight set (cchess_zero_amd.net.trained_like_), heads calibrated on 96 corpus positions."""
+    from cchess_zero_amd.net import trained_like_ as tl
+    return tl(net, positions(96, 123), seed)
 
 
 WEIGHT_SETS = {"glorot": lambda net: net, "structured": structured_, "trained_like": trained_like_}

@@ -73,7 +73,9 @@ def run_cases(engine, cases):
             root = [(int(st["label"][g, i]), int(st["N"][g, i]), int(st["W"][g, i].view(np.uint32)),
                      int(st["Q"][g, i].view(np.uint32)), int(st["P"][g, i].view(np.uint32))) for i in range(n)]
             rec = engine.tree_dump(g)
-            results[g].append(dict(root=root, digest=tree_digest(rec), records=len(rec), evals=len(logs[g])))
+            visited = rec[rec[:, 2] > 0]
+            results[g].append(dict(root=root, digest=tree_digest(rec), records=len(rec), evals=len(logs[g]),
+                                   max_level=int(visited[:, 0].max()) if len(visited) else -1))
             played[g] = cases[g]["plies"][ply]["played"]
             if ply + 1 >= len(cases[g]["plies"]):
                 played[g] = 0xFFFF
@@ -90,7 +92,13 @@ def check_against_golden(results, logs, cases):
             assert r["records"] == gp["tree_records"], "case %s ply %d: tree size" % (c["name"], ply)
             assert r["digest"] == gp["tree_sha256"], "case %s ply %d: whole-tree digest" % (c["name"], ply)
             assert r["evals"] == gp["evals"], "case %s ply %d: number of net evaluations" % (c["name"], ply)
-        assert ["%016x" % k for k in logs[g]] == c["eval_keys"], "case %s: evaluated positions / order" % c["name"]
+            if "max_level" in gp:
+                assert r["max_level"] == gp["max_level"], "case %s ply %d: deepest visited level" % (c["name"], ply)
+        if "eval_keys" in c:
+            assert ["%016x" % k for k in logs[g]] == c["eval_keys"], "case %s: evaluated positions / order" % c["name"]
+        else:   # mcts_deep.json stores a digest of the (long) key list
+            assert hashlib.sha256(",".join("%016x" % k for k in logs[g]).encode()).hexdigest() == c["eval_keys_sha256"], \
+                "case %s: evaluated positions / order" % c["name"]
 
 
 def fc_logits_restated(z, w, b):

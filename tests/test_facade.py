@@ -134,3 +134,12 @@ def test_cchess_main_selfplay_and_update(tmp_path, monkeypatch):
     assert len(cm.data_buffer) >= st["plies"] > 0 and cm.data_buffer.maxlen >= 2 * st["plies"]
     # asynchronous plies: every recorded ply had its full search; at most (terminal_extra + 1) simulations per slot and step
     assert cm.global_step > step1 and st["plies"] * cm.playout_counts <= st["sims"] <= st["lock_steps"] * 8 * 5
+    # the slots live across batches: the games in progress at the end of a batch go on in the next one, so long
+    # games reach the buffer too; the second batch's statistics are deltas and the totals add up
+    sp1, tot1 = cm._sp, cm._sp.stats()
+    in_progress = int(cm._sp.active().sum())
+    assert in_progress == 8
+    cm.run(max_batches=1)
+    st2, tot2 = cm.last_selfplay_stats, cm._sp.stats()
+    assert cm._sp is sp1 and st2["games"] >= 8 and tot2["games"] == tot1["games"] + st2["games"]
+    assert tot2["plies"] == tot1["plies"] + st2["plies"] and st2["dropped"] == 0

@@ -49,6 +49,19 @@ def test_search_matches_reference_golden(mcts_golden):
     searchdrive.check_against_golden(results, logs, cases)
 
 
+def test_search_matches_reference_at_depth(mcts_deep_golden):
+    """The device search against the unmodified reference at the METRIC's depth (playout 1600: 58-75 k nodes per tree; a
+    black-to-move root, a root at restrict_round 52, a second ply on the kept subtree) and on searches whose selected
+    paths are 33-62 levels long — longer than CZ_PATH_MAX = 32, so both the recorded-path backup and the parent-pointer
+    backup of k_expand_backup run (main.py:189-194,426-435), net leaves and the 60-ply draws at level 60 alike."""
+    cases = mcts_deep_golden["cases"]
+    eng = _HipEngine(len(cases))
+    results, logs = searchdrive.run_cases(eng, cases)
+    assert not np.any(eng.status() & ~8)
+    searchdrive.check_against_golden(results, logs, cases)
+    assert max(r["max_level"] for res in results for r in res) >= 60
+
+
 @pytest.mark.parametrize("mode", ["pos", "signed"])
 def test_search_vs_oracle_batch(rules_golden, mode):
     """256 trees from corpus positions, 3 plies x 48 playouts, device-resident loop; compared with the
@@ -222,13 +235,10 @@ def _run_to_target(eng, fwds, playouts, extra):
     return steps
 
 
-@pytest.mark.parametrize("extra", [1, 3])
-def test_terminal_simulations_complete_inside_select_golden(mcts_golden, extra):
-    """cz_search_set_terminal_extra: simulations that end on a king capture / the 60-ply rule are backed up inside the select
-    launch and the tree goes on to its next descent.  The trees must still be the UNMODIFIED reference's (golden root
-    children, whole-tree digests, number and order of net evaluations) — with fewer lock-steps than playouts wherever such
-    simulations occur."""
-    cases = mcts_golden["cases"]
+def _check_terminal_extra_first_ply(cases, extra):
+    """First ply of every case with `extra` in-select completions per launch: golden root children, tree digest, number
+    and order of net evaluations.  Returns the lock-steps saved."""
+    import hashlib
     by_playouts = {}
     for c in cases:
         by_playouts.setdefault(c["plies"][0]["playouts"], []).append(c)
@@ -257,8 +267,30 @@ def test_terminal_simulations_complete_inside_select_golden(mcts_golden, extra):
             rec = eng.tree_dump(g)
             assert len(rec) == gp["tree_records"] and searchdrive.tree_digest(rec) == gp["tree_sha256"], c["name"]
             assert len(logs[g]) == gp["evals"], c["name"]
-            assert ["%016x" % k for k in logs[g]] == c["eval_keys"][:gp["evals"]], c["name"]
+            if "eval_keys" in c:
+                assert ["%016x" % k for k in logs[g]] == c["eval_keys"][:gp["evals"]], c["name"]
+            elif len(c["plies"]) == 1:
+                assert hashlib.sha256(",".join("%016x" % k for k in logs[g]).encode()).hexdigest() == c["eval_keys_sha256"], c["name"]
+    return saved
+
+
+@pytest.mark.parametrize("extra", [1, 3])
+def test_terminal_simulations_complete_inside_select_golden(mcts_golden, extra):
+    """cz_search_set_terminal_extra: simulations that end on a king capture / the 60-ply rule are backed up inside the select
+    launch and the tree goes on to its next descent.  The trees must still be the UNMODIFIED reference's (golden root
+    children, whole-tree digests, number and order of net evaluations) — with fewer lock-steps than playouts wherever such
+    simulations occur."""
+    saved = _check_terminal_extra_first_ply(mcts_golden["cases"], extra)
     print("terminal_extra=%d: %d lock-steps saved over the golden cases" % (extra, saved))
+    assert saved > 0
+
+
+def test_terminal_simulations_complete_inside_select_at_depth(mcts_deep_golden):
+    """The same at playout 1600 and on the 33-62-level lines: a terminal leaf deeper than CZ_PATH_MAX is NOT completed inside
+    the select launch (its path is not recorded) and goes through k_expand_backup's parent-pointer walk instead; the
+    trees stay the reference's either way."""
+    saved = _check_terminal_extra_first_ply(mcts_deep_golden["cases"], 4)
+    print("terminal_extra=4 at depth: %d lock-steps saved" % saved)
     assert saved > 0
 
 

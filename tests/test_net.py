@@ -97,6 +97,28 @@ def test_inference_engine_fp32_within_1e3(blocks):
     assert np.allclose(l2, logits[:4], atol=1e-5)
 
 
+@pytest.mark.gpu
+def test_facade_default_forward_meets_1e3(tmp_path):
+    """policy_value_network(res_block_nums=7).forward — the API north_star names (policy_value_network.py:202-214) with its
+    DEFAULT engine (fused fp16 MFMA tower) — against the fp32 NumPy restatement of the reference graph on the same
+    TF-default weights: |dlogit| <= 1e-3 and |dvalue| <= 1e-3 absolute (measured 1.2e-4 / 1.1e-4).  bench.py and
+    main.py run this engine."""
+    from policy_value_network import policy_value_network
+    pv = policy_value_network(7, save_dir=str(tmp_path))
+    assert pv.net.dtype == torch.float16 and pv.net.backend == "hip" and pv.net.fused_search
+    x = _positions(64, 2)
+    logits, v = pv.forward(x)
+    ln, vn = net_numpy.forward(pv.module.export_tf_layout(), x, 7)
+    e = H.errors(logits, v, ln, vn)
+    print("facade default (fp16, 7 blocks, TF-default weights): dlogit %.3g dvalue %.3g dsoftmax %.3g" % (e["dlogit"], e["dvalue"], e["dprob"]))
+    assert logits.dtype == np.float32 and logits.shape == (64, 2086) and v.shape == (64, 1)
+    assert e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3 and e["dprob"] <= 1e-6
+    # the package-level error probe bench.py prints (net_error: against the fp32 torch module on the device) agrees
+    from cchess_zero_amd.net import net_error
+    ne = net_error(pv.net, torch.from_numpy(x).cuda())
+    assert abs(ne["dlogit"] - e["dlogit"]) <= 5e-5 and abs(ne["dvalue"] - e["dvalue"]) <= 5e-5
+
+
 # Fused MFMA net (bf16 / fp16 operands, fp32 accumulate) vs the fp32 NumPy restatement of the reference graph.
 # north_star's tolerance (1e-3) is stated for fp32 and is asserted for the fp32 engine above.  A 16-bit tower is a
 # different function: every one of the 2*blocks+1 conv layers rounds its activations to 8 (bf16) or 11 (fp16) mantissa

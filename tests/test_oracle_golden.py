@@ -149,6 +149,19 @@ class _PerTreeOracle:
         return np.concatenate([e.status()[0] for e in self.e])
 
 
+def test_search_matches_reference_at_depth(mcts_deep_golden):
+    """The oracle against the unmodified reference at the METRIC's depth (playout 1600, main.py:473-493; one black-to-move
+    root, one at restrict_round 52, one across update_tree) and on searches whose selected paths are 33-62 levels long
+    (fakenet mode 'deep'): root children, whole-tree digests, evaluated positions, deepest visited level."""
+    cases = mcts_deep_golden["cases"]
+    assert max(p["playouts"] for c in cases for p in c["plies"]) == 1600
+    assert max(p["max_level"] for c in cases for p in c["plies"]) > 48 and sum(p["max_level"] >= 32 for c in cases for p in c["plies"]) >= 4
+    eng = _PerTreeOracle(len(cases))
+    results, logs = searchdrive.run_cases(eng, cases)
+    assert not np.any(eng.status() & ~8)
+    searchdrive.check_against_golden(results, logs, cases)
+
+
 def test_search_matches_reference(mcts_golden):
     cases = mcts_golden["cases"]
     eng = _PerTreeOracle(len(cases))

@@ -15,8 +15,8 @@ def _setup(G, cap, playouts, continuous=True, seed=3, **kw):
     from cchess_zero_amd.net import PolicyValueNet
     from cchess_zero_amd.selfplay import SelfPlay
     from oracle import oracle as O
-    net = PolicyValueNet(2, "cuda:0", torch.bfloat16, seed=2)
-    eng = SearchEngine(G, cap, plane_dtype=torch.bfloat16, channels=16)
+    net = PolicyValueNet(2, "cuda:0", torch.float16, seed=2)
+    eng = SearchEngine(G, cap, plane_dtype=torch.float16, channels=16)
     sp = SelfPlay(eng, net, playouts, exploration=True, temperature=1.0, seed=seed, continuous=continuous, **kw)
     sp.start(np.tile(O.fen_to_board(START_FEN), (G, 1)), np.zeros(G, np.uint8), np.zeros(G, np.int32))
     return net, eng, sp
@@ -170,3 +170,19 @@ def test_eval_cache_and_terminal_extra_leave_real_net_selfplay_unchanged():
     assert len(rec0) > 0 and rec0.shape == rec1.shape and np.array_equal(rec0, rec1)
     assert {k: st0[k] for k in ("games", "red_wins", "black_wins", "draws", "plies")} == {k: st1[k] for k in ("games", "red_wins", "black_wins", "draws", "plies")}
     assert hits[0] > 0
+
+
+def test_ring_overflow_is_reported_not_silently_drained():
+    """a finished game whose records would overwrite undrained rows is dropped by cz_selfplay_flush while the
+    cursor still advances — drain must not hand back the stale slots: it raises, and the statistics carry the count."""
+    G, playouts = 64, 4
+    net, eng, sp = _setup(G, 4096, playouts, ring_records=256)   # far too small for 64 continuously re-seeded games
+    with pytest.raises(RuntimeError, match="ring overflow"):
+        for _ in range(40):
+            sp.run(20)          # never drained in between: the ring fills with finished games
+            if sp.stats()["dropped"] > 0:
+                sp.drain()
+                break
+        else:
+            sp.drain()
+    assert sp.stats()["dropped"] > 0

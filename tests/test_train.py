@@ -9,6 +9,7 @@
     drives the early stop is all-reduced), ends with bit-identical weights and the same lr_multiplier; rank 0 alone saves.
 """
 import os
+import random
 import socket
 import sys
 
@@ -82,6 +83,18 @@ def _run_restatement(w0, batches, lr, blocks, momentum=0.9, clip=100.0):
 
 @pytest.mark.parametrize("blocks,lr", [(1, 0.05), (2, 0.2)])
 def test_train_step_matches_float64_restatement(blocks, lr):
+    _check_train_step(blocks, lr, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,lr", [(2, 0.2), (7, 0.1)])
+def test_train_step_on_device_matches_float64_restatement(blocks, lr):
+    """The same check where the product trains: the module on cuda:0, forward AND backward through ROCm (MIOpen convolutions,
+    fp32), 2 and 7 residual blocks, against the float64 restatement of the TF graph + MomentumOptimizer computed on the host."""
+    _check_train_step(blocks, lr, "cuda:0")
+
+
+def _check_train_step(blocks, lr, device):
     from cchess_zero_amd.net import PolicyValueModule
     from cchess_zero_amd.train import Trainer
     m = PolicyValueModule(blocks, seed=4)
@@ -93,7 +106,9 @@ def test_train_step_matches_float64_restatement(blocks, lr):
     w0 = m.export_tf_layout()
     batches = [_batch(12, 3), _batch(12, 4)]
     ref = _run_restatement(w0, batches, lr, blocks)
+    m = m.to(device)
     tr = Trainer(m)
+    assert str(tr.device).startswith(device.split(":")[0])
     prev = w0
     for step, (x, pi, z) in enumerate(batches):
         acc, loss, gs = tr.train_step(x, pi, z, lr)
@@ -132,6 +147,71 @@ def test_clip_and_nan_check():
     bad[0, 0] = np.nan
     with pytest.raises(FloatingPointError):
         tr.train_step(x, pi, bad, 0.1)
+
+
+def test_policy_update_control_flow_matches_reference_golden(golden_dir):
+    """cchess_main.policy_update of the unmodified reference (main.py:1157-1204) was run through a stand-in self with a
+    scripted net (tests/golden/gen_golden.py: gen_policy_update); the same scripted net through train.policy_update must
+    take the same number of train steps at the same learning rates (early stop at kl > 4 * kl_targ), end with the same
+    lr_multiplier (x / 1.5 adaptation, bounds 0.1 / 10), save the same step and log the same KL / explained variances."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from gen_golden import scripted_outputs   # imports nothing of the reference at module scope
+    from cchess_zero_amd.train import policy_update
+    g = np.load(os.path.join(golden_dir, "policy_update.npz"))
+    states = [s.astype(np.float32) for s in g["states"]]
+    buf = list(zip(states, list(g["pi"]), [float(z) for z in g["z"]]))
+    cases = json.loads(str(g["meta"]))
+    assert {c["steps"] for c in cases} == {1, 3, 5}
+    for c in cases:
+        class Net:
+            k, lrs, saved, global_step = 0, [], None, 0
+
+            def forward(self, sb):
+                return scripted_outputs(sb, Net.k, c["scale"])
+
+            def train_step(self, sb, pb, wb, lr):
+                Net.k += 1
+                Net.lrs.append(float(lr))
+                Net.global_step = 100 + Net.k
+                return 0.5, 1.25, Net.global_step
+
+            def save(self, step):
+                Net.saved = int(step)
+        order = random.Random(99).sample(range(len(buf)), len(buf))   # the mini-batch order random.sample drew there (seed 99)
+        lrm, info = policy_update(Net(), buf, len(buf), 5, 0.001, c["lrm"], 0.025, log=lambda *a: None, sample=order)
+        assert Net.k == c["steps"] == info["steps"], c["name"]
+        assert Net.lrs == c["lrs"], c["name"]
+        assert lrm == c["lr_multiplier_after"], c["name"]
+        assert Net.saved == c["saved_step"], c["name"]
+        assert "{:.5f}".format(info["kl"]) == c["kl_logged"], (c["name"], info["kl"])
+        assert "{:.3f}".format(info["explained_var_old"]) == c["explained_var_old_logged"], c["name"]
+        assert "{:.3f}".format(info["explained_var_new"]) == c["explained_var_new_logged"], c["name"]
+
+
+@pytest.mark.gpu
+def test_policy_update_on_device(tmp_path):
+    """policy_update with the real network on cuda:0 (fused fp16 forward, ROCm training step): the KL it reports is the
+    reference's estimate recomputed here from forward() before / after the steps it took, the step count obeys the early
+    stop, the weights moved and the checkpoint of the last step exists."""
+    sys.path.insert(0, ROOT)
+    from policy_value_network import policy_value_network
+    from cchess_zero_amd.train import kl_estimate_rows, policy_update
+    net = policy_value_network(2, save_dir=str(tmp_path), seed=3)
+    x, pi, z = _batch(32, 6)
+    buf = [(x[i], pi[i], float(z[i, 0])) for i in range(len(x))]
+    old_l, _ = net.forward(list(x))
+    w_before = torch.cat([p.detach().reshape(-1).clone() for p in net.module.parameters()])
+    lrm, info = policy_update(net, buf, 32, 5, 0.02, 1.0, 0.025, log=lambda *a: None, sample=range(32))
+    new_l, _ = net.forward(list(x))
+    kl = float(np.mean(kl_estimate_rows(old_l, new_l)))
+    assert 1 <= info["steps"] <= 5 and net.global_step == info["steps"]
+    assert abs(kl - info["kl"]) <= 1e-6 * max(1.0, abs(kl)), (kl, info["kl"])
+    assert info["steps"] == 5 or info["kl"] > 0.1
+    assert lrm == (1.0 / 1.5 if info["kl"] > 0.05 else 1.5 if info["kl"] < 0.0125 else 1.0)
+    w_after = torch.cat([p.detach().reshape(-1) for p in net.module.parameters()])
+    assert float((w_after - w_before).abs().max()) > 0
+    assert os.path.exists(os.path.join(str(tmp_path), "best_model.ckpt-%d.pt" % net.global_step))
 
 
 class _CpuNet:
