@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--eval-cache", action="store_true", help="evaluation cache (cz_search_set_eval_cache): a leaf whose position the tree has evaluated before is expanded from the remembered node inside the select launch, without a net row; trees are bit-identical with it on or off.  Off in the default (headline) run")
     ap.add_argument("--advance-every", type=int, default=8, help="steps between checks for trees that have had their playouts")
     ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records every 64 lock-steps, inside the timed region")
+    ap.add_argument("--torch-advance", action="store_true", help="A/B only: the round-2 advance of ready trees (status / root statistics / argmax / reload as ~20 torch ops) instead of cz_search_pick_ready + cz_search_advance + cz_search_reload_finished")
     ap.add_argument("--force-dist", action="store_true", help="testing only: initialise the process group and run every collective even with a world of 1 (RCCL API check on one GPU)")
     ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
     args = ap.parse_args()
@@ -316,7 +317,11 @@ def main():
     playout_t = torch.full((G,), playout, dtype=torch.int32, device=dev)
 
     def advance_ready():
-        """update_tree for every tree whose search has had its playouts (or whose node pool is full): most visited child."""
+        """update_tree for every tree whose search has had its playouts (or whose node pool is full): most visited child;
+        games that are over restart from the START position.  Three launches of the library, nothing on the host."""
+        if not args.torch_advance:
+            eng.advance_ready(thr, playout, start_boards, start_side, start_rr, banked, reloaded)
+            return
         st, _, sims, _ = eng.status()
         ready = (sims >= thr) | ((st & 1) != 0)
         thr.copy_(torch.where(ready, playout_t, thr))

@@ -56,6 +56,8 @@ _SIGS = {
     "cz_search_expand_backup_k": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int]),
     "cz_search_root_stats": (C.c_int, [C.c_void_p, _u16p, _i32p, _f32p, _f32p, _f32p, _u16p]),
     "cz_search_advance": (C.c_int, [C.c_void_p, _u16p]),
+    "cz_search_pick_ready": (C.c_int, [C.c_void_p, _i32p, C.c_int, _u16p, _u8p, _vp]),
+    "cz_search_reload_finished": (C.c_int, [C.c_void_p, _u8p, _u16p, _u8p, _u8p, _i32p, _vp]),
     "cz_search_status": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p]),
     "cz_search_root_state": (C.c_int, [C.c_void_p, _u8p, _u8p, _i32p]),
     "cz_search_tree_dump": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),

@@ -347,6 +347,15 @@ int cz_search_advance(cz_ctx *c, const uint16_t *played) {
     CZ_REQUIRE(c && c->G > 0 && played, "cz_search_advance: null argument / no search");
     return czk_search_advance(c, played);
 }
+int cz_search_pick_ready(cz_ctx *c, int32_t *sim_threshold, int next_threshold, uint16_t *played, uint8_t *ready, unsigned long long *banked_sims) {
+    CZ_REQUIRE(c && c->G > 0 && sim_threshold && played, "cz_search_pick_ready: null argument / no search");
+    return czk_search_pick_ready(c, sim_threshold, next_threshold, played, ready, banked_sims);
+}
+int cz_search_reload_finished(cz_ctx *c, const uint8_t *ready, const uint16_t *played, const uint8_t *boards, const uint8_t *side,
+                              const int32_t *rr, unsigned long long *reloaded) {
+    CZ_REQUIRE(c && c->G > 0 && ready && played && boards && side, "cz_search_reload_finished: null argument / no search");
+    return czk_search_reload_finished(c, ready, played, boards, side, rr, reloaded);
+}
 int cz_search_status(cz_ctx *c, int32_t *status, int32_t *nodes, int32_t *sims, int32_t *depth) {
     CZ_REQUIRE(c && c->G > 0, "cz_search_status: no search");
     return czk_search_status(c, status, nodes, sims, depth);

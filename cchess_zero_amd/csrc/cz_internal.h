@@ -189,6 +189,8 @@ int czk_search_expand_backup(cz_ctx *, const void *, const void *, int);
 int czk_search_expand_backup_fc(cz_ctx *, const float *, const float *, const float *, const float *, bool compact);
 int czk_search_root_stats(cz_ctx *, uint16_t *, int32_t *, float *, float *, float *, uint16_t *);
 int czk_search_advance(cz_ctx *, const uint16_t *);
+int czk_search_pick_ready(cz_ctx *, int32_t *, int, uint16_t *, uint8_t *, unsigned long long *);
+int czk_search_reload_finished(cz_ctx *, const uint8_t *, const uint16_t *, const uint8_t *, const uint8_t *, const int32_t *, unsigned long long *);
 int czk_search_select_k(cz_ctx *, int, int, const uint8_t *, void *, int, int, uint8_t *);
 int czk_search_expand_backup_k(cz_ctx *, int, const void *, const void *, int);
 int czk_selfplay_seed(cz_ctx *, const uint8_t *, const uint8_t *, const int32_t *);

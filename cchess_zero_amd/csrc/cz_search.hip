@@ -17,11 +17,8 @@
 namespace {
 
 // ---- reset: MCTS_tree.__init__ / reload, main.py:235-259 ---------------------------------------
-__global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restrict__ boards,
-                                              const uint8_t *__restrict__ side, const int32_t *__restrict__ rr, int G,
-                                              const uint8_t *__restrict__ which) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    if (g >= G || (which && !which[g])) return;   // cz_search_reload: only the trees whose game is over start afresh
+__device__ __forceinline__ void reset_tree(const CzTrees &t, int g, int lane, const uint8_t *__restrict__ boards,
+                                           const uint8_t *__restrict__ side, const int32_t *__restrict__ rr) {
     for (int i = lane; i < CZD_BOARD_LDS; i += 64)
         t.root_board[(size_t)g * CZD_BOARD_LDS + i] = i < CZ_NSQ ? boards[(size_t)g * CZ_NSQ + i] : 0;
     if (lane == 0) {
@@ -32,6 +29,66 @@ __global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restri
         init_root(view_of(t, g), 0);
     }
     ec_clear_tree(t, g, lane, 64);
+}
+
+__global__ __launch_bounds__(64) void k_reset(CzTrees t, const uint8_t *__restrict__ boards,
+                                              const uint8_t *__restrict__ side, const int32_t *__restrict__ rr, int G,
+                                              const uint8_t *__restrict__ which) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G || (which && !which[g])) return;   // cz_search_reload: only the trees whose game is over start afresh
+    reset_tree(t, g, lane, boards, side, rr);
+}
+
+// ---- greedy re-rooting driver: the temperature -> 0 limit of get_action (main.py:1332-1341: softmax(log(visits) / 1e-3) is
+// the most visited child) for the trees whose search is complete, and check_end + reload (main.py:1380-1392,255-258) for the
+// games that are then over.  bench.py's search loop and any "play the strongest move" loop: no host round trip, no torch op.
+__global__ __launch_bounds__(64) void k_pick_ready(CzTrees t, int G, int32_t *__restrict__ thr, int next_thr,
+                                                   uint16_t *__restrict__ played, uint8_t *__restrict__ ready_out,
+                                                   unsigned long long *__restrict__ banked) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const int sims = t.sims[g];
+    const bool ready = sims >= thr[g] || (t.status[g] & CZ_ST_POOL_EXHAUSTED) != 0;
+    uint16_t label = 0xFFFF;
+    if (ready) {
+        const TreeView v = view_of(t, g);
+        const int root = t.root_node[g];
+        const int cb = v.child_begin[root];
+        const int n = cb < 0 ? 0 : v.child_count[root];
+        // first maximum of N in generation order (Python max() over root.child.items())
+        int bn = -1, bi = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const int x = v.N[cb + i];
+            if (x > bn) { bn = x; bi = i; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int on = __shfl_xor(bn, d, 64), oi = __shfl_xor(bi, d, 64);
+            if (on > bn || (on == bn && oi < bi)) { bn = on; bi = oi; }
+        }
+        if (n > 0) label = v.move[cb + bi];
+        if (lane == 0) {
+            thr[g] = next_thr;
+            if (banked) atomicAdd(banked, (unsigned long long)sims);
+        }
+    }
+    if (lane == 0) { played[g] = label; if (ready_out) ready_out[g] = ready ? 1 : 0; }
+}
+
+__global__ __launch_bounds__(64) void k_reload_finished(CzTrees t, int G, const uint8_t *__restrict__ ready,
+                                                        const uint16_t *__restrict__ played, const uint8_t *__restrict__ boards,
+                                                        const uint8_t *__restrict__ side, const int32_t *__restrict__ rr,
+                                                        unsigned long long *__restrict__ reloaded) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G || !ready[g]) return;
+    const uint8_t *b = t.root_board + (size_t)g * CZD_BOARD_LDS;
+    const int c0 = b[lane], c1 = lane + 64 < CZ_NSQ ? b[lane + 64] : 0;
+    const bool hasK = __ballot(c0 == 1 || c1 == 1) != 0ull, hask = __ballot(c0 == 8 || c1 == 8) != 0ull;
+    // check_end (main.py:1380-1392): a king is gone or 60 plies without a capture; a root without a move to play is over too
+    const bool over = !hasK || !hask || t.root_rr[g] >= 60 || played[g] == 0xFFFF;
+    if (!over) return;
+    reset_tree(t, g, lane, boards, side, rr);
+    if (lane == 0 && reloaded) atomicAdd(reloaded, 1ull);
 }
 
 // ---- K4: selection descent + leaf preparation ----------------------------------------------------
@@ -1021,6 +1078,19 @@ int czk_search_expand_backup_fc(cz_ctx *c, const float *z, const float *value, c
 
 int czk_search_root_stats(cz_ctx *c, uint16_t *label, int32_t *N, float *Q, float *P, float *W, uint16_t *count) {
     hipLaunchKernelGGL(k_root_stats, dim3(c->G), dim3(64), 0, c->stream, c->t, c->G, label, N, Q, P, W, count);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_pick_ready(cz_ctx *c, int32_t *thr, int next_thr, uint16_t *played, uint8_t *ready, unsigned long long *banked) {
+    hipLaunchKernelGGL(k_pick_ready, dim3(c->G), dim3(64), 0, c->stream, c->t, c->G, thr, next_thr, played, ready, banked);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+int czk_search_reload_finished(cz_ctx *c, const uint8_t *ready, const uint16_t *played, const uint8_t *boards, const uint8_t *side,
+                               const int32_t *rr, unsigned long long *reloaded) {
+    hipLaunchKernelGGL(k_reload_finished, dim3(c->G), dim3(64), 0, c->stream, c->t, c->G, ready, played, boards, side, rr, reloaded);
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

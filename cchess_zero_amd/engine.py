@@ -236,6 +236,24 @@ class SearchEngine:
         played = played.to(self.dev).contiguous()
         check(lib().cz_search_advance(self.ctx.h, _ptr(played)), "cz_search_advance")
 
+    def advance_ready(self, thr, next_thr, start_boards, start_side, start_rr=None, banked=None, reloaded=None):
+        """The greedy driver of a long search loop, all on the device (cz_search_pick_ready -> cz_search_advance ->
+        cz_search_reload_finished): every tree that has completed thr[g] simulations (int32 [G] device tensor, set to
+        next_thr for the trees that move) plays its most visited root child; games that are then over restart from
+        start_boards / start_side / start_rr.  banked / reloaded: int64 device scalars accumulating the simulations of the
+        searches closed and the games restarted.  Returns the (played, ready) device tensors of this call."""
+        self.ctx.bind_stream()
+        G, dev = self.G, self.dev
+        if getattr(self, "_ar", None) is None or self._ar[0].numel() != G:
+            self._ar = (torch.empty(G, dtype=torch.int16, device=dev), torch.empty(G, dtype=torch.uint8, device=dev))
+        played, ready = self._ar
+        assert thr.dtype == torch.int32 and thr.is_cuda and thr.numel() == G
+        check(lib().cz_search_pick_ready(self.ctx.h, _ptr(thr), int(next_thr), _ptr(played), _ptr(ready), _ptr(banked)), "cz_search_pick_ready")
+        check(lib().cz_search_advance(self.ctx.h, _ptr(played)), "cz_search_advance")
+        check(lib().cz_search_reload_finished(self.ctx.h, _ptr(ready), _ptr(played), _ptr(start_boards), _ptr(start_side), _ptr(start_rr),
+                                              _ptr(reloaded)), "cz_search_reload_finished")
+        return played, ready
+
     def status(self):
         self.ctx.bind_stream()   # launches go to torch's CURRENT stream (also under HIP graph capture)
         G, dev = self.G, self.dev

@@ -213,6 +213,21 @@ int cz_search_root_stats(cz_ctx *, uint16_t *move_label, int32_t *N, float *Q, f
  *   (:1522-1528): re-root on the played child keeping its subtree (compacted in place: one node
  *   pool per tree); clears CZ_ST_POOL_EXHAUSTED.  played_label 0xFFFF leaves the tree untouched. */
 int cz_search_advance(cz_ctx *, const uint16_t *played_label);
+/* greedy re-rooting driver (device arrays, no host round trip; bench.py's search loop, "play the strongest move" loops)
+ * replaces: get_action in its temperature -> 0 limit (main.py:1332-1341, default temperature 1e-3: softmax(log(visits)/T)
+ *   puts all mass on the most visited child; first maximum in generation order like Python's max()) for the trees whose
+ *   search is complete.  A tree is READY when it has completed sim_threshold[g] simulations since its last reset /
+ *   advance or its node pool is full: played[g] = label of its most visited root child (0xFFFF: not ready, or no child),
+ *   ready[g] = 1 / 0 (may be NULL), sim_threshold[g] = next_threshold, *banked_sims += its simulation count (device
+ *   scalar, may be NULL).  Follow with cz_search_advance(played) and cz_search_reload_finished. */
+int cz_search_pick_ready(cz_ctx *, int32_t *sim_threshold /*[G] in/out*/, int next_threshold, uint16_t *played /*[G]*/,
+                         uint8_t *ready /*[G]*/, unsigned long long *banked_sims);
+/* replaces: check_end + reload after the move (main.py:1380-1392 king gone / restrict_round >= 60; :255-258,604-608):
+ *   the READY trees whose game is now over — or that had no move to play — start afresh from root_boards[g] /
+ *   root_side[g] / restrict_round[g] (may be NULL = 0) like cz_search_reload; *reloaded (device scalar, may be NULL)
+ *   counts them. */
+int cz_search_reload_finished(cz_ctx *, const uint8_t *ready, const uint16_t *played, const uint8_t *root_boards,
+                              const uint8_t *root_side, const int32_t *restrict_round, unsigned long long *reloaded);
 int cz_search_status(cz_ctx *, int32_t *status, int32_t *nodes_used, int32_t *sims,
                      int32_t *last_depth); /* device [G] arrays, any may be NULL */
 int cz_search_root_state(cz_ctx *, uint8_t *boards, uint8_t *side, int32_t *restrict_round);

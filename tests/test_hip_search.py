@@ -497,3 +497,68 @@ def test_eval_cache_follows_the_tree_through_advances(rules_golden):
           (playouts, G, hits, lookups, np.diff([0] + hits_by_ply).tolist(), rows_hip, rows_orc))
     assert hits > 0 and rows_hip < rows_orc and hits_by_ply[2] > hits_by_ply[1] > hits_by_ply[0]
     hip.e.set_eval_cache(False)
+
+
+def test_advance_ready_device_driver_matches_host_logic():
+    """cz_search_pick_ready -> cz_search_advance -> cz_search_reload_finished (the greedy driver bench.py's search loop
+    runs every few steps) against the same decisions taken on the host from cz_search_status / root_stats / root_state:
+    per-tree thresholds, first-maximum most-visited child (get_action's temperature -> 0 limit, main.py:1332-1341),
+    check_end + reload from the start position (main.py:1380-1392,255-258).  Two engines, the same net, 160 lock-steps
+    with a check every 8: every root, counter, statistic, the banked simulations and the restart count must agree."""
+    import bench
+    from cchess_zero_amd.engine import SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet
+    from cchess_zero_amd.rules import Rules
+    G, playout = 512, 24
+    boards, side, rr = bench.synth_positions(Rules(), G, 4242, max_ply=160)   # late positions: some games end within the run
+    net = PolicyValueNet(2, "cuda:0", torch.float16, seed=5)
+    dev = boards.device
+    start_b = torch.from_numpy(np.tile(bench.START, (G, 1))).to(dev)
+    start_s, start_r = torch.zeros(G, dtype=torch.uint8, device=dev), torch.zeros(G, dtype=torch.int32, device=dev)
+    thr0 = torch.randint(4, 40, (G,), generator=torch.Generator(device=dev).manual_seed(1), device=dev, dtype=torch.int32)
+    out = []
+    for device_driver in (True, False):
+        eng = SearchEngine(G, 8192, plane_dtype=torch.float16, channels=16)
+        eng.reset(boards, side, rr)
+        eng.set_terminal_extra(2)
+        eng.set_sim_target(playout)
+        thr = thr0.clone()
+        banked = torch.zeros(1, dtype=torch.int64, device=dev)
+        reloaded = torch.zeros(1, dtype=torch.int64, device=dev)
+        eng.step(net.forward_device, mode=0)
+        for step in range(160):
+            eng.step(net.forward_device, mode=1)
+            if (step + 1) % 8:
+                continue
+            if device_driver:
+                eng.advance_ready(thr, playout, start_b, start_s, start_r, banked, reloaded)
+                continue
+            st, _, sims, _ = eng.status()
+            ready = (sims >= thr) | ((st & 1) != 0)
+            thr = torch.where(ready, torch.full_like(thr, playout), thr)
+            banked += (sims.to(torch.int64) * ready).sum()
+            rs = eng.root_stats()
+            n = rs["N"].clone()
+            cnt = (rs["count"].to(torch.int64) & 0xFFFF).unsqueeze(1)
+            n[torch.arange(128, device=dev).unsqueeze(0) >= cnt] = -1
+            played = rs["label"].gather(1, n.argmax(dim=1, keepdim=True)).squeeze(1)
+            eng.advance(torch.where(ready & (cnt.squeeze(1) > 0), played, torch.full_like(played, -1)))
+            b, _, r = eng.root_state()
+            over = ready & (~(b == 1).any(dim=1) | ~(b == 8).any(dim=1) | (r >= 60) | (cnt.squeeze(1) == 0))
+            eng.reload(over, start_b, start_s, start_r)
+            reloaded += over.sum()
+        rs = eng.root_stats()
+        out.append(dict(thr=thr.clone(), banked=int(banked.item()), reloaded=int(reloaded.item()),
+                        state=[x.clone() for x in eng.root_state()], status=[x.clone() for x in eng.status()],
+                        stats={k: v.clone() for k, v in rs.items()}))
+        eng.set_sim_target(0)
+        eng.set_terminal_extra(0)
+    a, b = out
+    assert a["banked"] == b["banked"] > 0 and a["reloaded"] == b["reloaded"] > 0
+    assert torch.equal(a["thr"], b["thr"])
+    for x, y in zip(a["state"] + a["status"], b["state"] + b["status"]):
+        assert torch.equal(x, y)
+    for k in a["stats"]:
+        x, y = a["stats"][k], b["stats"][k]
+        assert torch.equal(x.view(torch.int32) if x.dtype.is_floating_point else x, y.view(torch.int32) if y.dtype.is_floating_point else y), k
+    print("advance_ready: %d simulations banked, %d games restarted, identical under both drivers" % (a["banked"], a["reloaded"]))
