@@ -239,7 +239,8 @@ int cz_search_set_eval_cache(cz_ctx *c, int on) {
     if (on && c->width != 1) { cz_set_error("cz_search_set_eval_cache: needs width 1 (one simulation in flight per tree)"); return CZ_EINVAL; }
     const size_t per = (size_t)c->max_games * CZ_EC_ENTRIES;
     if (on && !c->ec_block) {
-        const size_t bytes = per * (8 + 4 + 4);
+        // per entry: key 8 B, node 4 B, value 4 B, the packed position 48 B; per tree: the pending leaf's packed position
+        const size_t bytes = per * (8 + 4 + 4 + 48) + (size_t)c->max_games * 48;
         CZ_HIP(hipSetDevice(c->device));
         if (hipMalloc(&c->ec_block, bytes) != hipSuccess) { c->ec_block = nullptr; cz_set_error("cz_search_set_eval_cache: hipMalloc(%zu B) failed", bytes); return CZ_ENOMEM; }
     }
@@ -248,12 +249,31 @@ int cz_search_set_eval_cache(cz_ctx *c, int on) {
         c->t.ec_key = (unsigned long long *)b;
         c->t.ec_node = (int32_t *)(b + per * 8);
         c->t.ec_val = (float *)(b + per * 12);
+        c->t.ec_board = (uint32_t *)(b + per * 16);
+        c->t.pend_board = (uint32_t *)(b + per * 64);
+        if (!c->t.ec_key_mask) c->t.ec_key_mask = ~0ull;
         // an empty cache: entries of an earlier use would point into trees that no longer exist
         CZ_HIP(hipMemsetAsync(c->ec_block, 0, per * 8, c->stream));
         czk_search_clear_cache_stats(c);
     } else {
-        c->t.ec_key = nullptr; c->t.ec_node = nullptr; c->t.ec_val = nullptr;
+        c->t.ec_key = nullptr; c->t.ec_node = nullptr; c->t.ec_val = nullptr; c->t.ec_board = nullptr; c->t.pend_board = nullptr;
     }
+    return CZ_OK;
+}
+int cz_search_debug_eval_cache_key_bits(cz_ctx *c, int bits) {
+    CZ_REQUIRE(c && (bits == 64 || (bits >= 8 && bits <= 24)), "cz_search_debug_eval_cache_key_bits: bits must be 8..24 or 64");
+    // narrowed keys keep the 7-bit bucket field (bits 17..23) plus the bits - 7 lowest bits: entries still spread over the buckets
+    c->t.ec_key_mask = bits == 64 ? ~0ull : ((0x7Full << 17) | ((1ull << (bits - 7)) - 1ull));
+    return CZ_OK;
+}
+int cz_search_eval_cache_collisions(cz_ctx *c, unsigned long long *collisions) {
+    CZ_REQUIRE(c && collisions, "cz_search_eval_cache_collisions: null argument");
+    *collisions = 0;
+    if (c->G <= 0) return CZ_OK;
+    std::vector<CzTreeRec> h((size_t)c->G);
+    CZ_HIP(hipMemcpyAsync(h.data(), c->t.rec, h.size() * sizeof(CzTreeRec), hipMemcpyDeviceToHost, c->stream));
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    for (int g = 0; g < c->G; ++g) *collisions += h[(size_t)g].ec_collisions;
     return CZ_OK;
 }
 int cz_search_eval_cache_stats(cz_ctx *c, unsigned long long *hits, unsigned long long *lookups) {

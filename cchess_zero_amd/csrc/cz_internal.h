@@ -64,6 +64,7 @@ struct CzSelfplay {
 
 #define CZ_EC_BUCKETS 128
 #define CZ_EC_ENTRIES (CZ_EC_BUCKETS * 64)
+#define CZ_EC_BUDGET 4   // evaluation-cache hits a tree may complete inside one select launch (its own budget, beside terminal_extra)
 
 // Per-tree scalars: ONE 64-byte record per tree instead of sixteen arrays.  A wave owns a tree, so what it reads at entry
 // (root, counters, status) and leaves behind (the pending leaf) is one cache line, and the kernels hold one base pointer
@@ -78,7 +79,7 @@ struct CzTreeRec {
     unsigned long long pend_key;                      // 48  Zobrist key of the pending leaf (evaluation cache)
     uint16_t pend_nmoves;                             // 56
     uint8_t root_side, pend_side;                     // 58
-    uint32_t pad_;                                    // 60
+    uint32_t ec_collisions;                           // 60  key matches whose stored position differed (taken as misses)
 };
 static_assert(sizeof(CzTreeRec) == 64, "CzTreeRec is one 64-byte line per tree");
 
@@ -101,7 +102,7 @@ struct CzTrees {
         CZ_REC_FIELD(int32_t, root_rr); CZ_REC_FIELD(int32_t, root_node); CZ_REC_FIELD(int32_t, n_nodes);
         CZ_REC_FIELD(int32_t, status); CZ_REC_FIELD(int32_t, sims); CZ_REC_FIELD(int32_t, last_depth);
         CZ_REC_FIELD(int32_t, pend_kind); CZ_REC_FIELD(int32_t, pend_leaf); CZ_REC_FIELD(float, pend_value);
-        CZ_REC_FIELD(int32_t, pend_depth); CZ_REC_FIELD(uint32_t, ec_hits); CZ_REC_FIELD(uint32_t, ec_lookups);
+        CZ_REC_FIELD(int32_t, pend_depth); CZ_REC_FIELD(uint32_t, ec_hits); CZ_REC_FIELD(uint32_t, ec_lookups); CZ_REC_FIELD(uint32_t, ec_collisions);
         CZ_REC_FIELD(unsigned long long, pend_key); CZ_REC_FIELD(uint16_t, pend_nmoves);
         CZ_REC_FIELD(uint8_t, root_side); CZ_REC_FIELD(uint8_t, pend_side);
     };
@@ -119,6 +120,9 @@ struct CzTrees {
     unsigned long long *ec_key;       // [max_games][CZ_EC_ENTRIES]  0 = empty      (NULL: cache off)
     int32_t *ec_node;                 // [max_games][CZ_EC_ENTRIES]
     float *ec_val;                    // [max_games][CZ_EC_ENTRIES]
+    uint32_t *ec_board;               // [max_games][CZ_EC_ENTRIES][12] the entry's position, packed (wave_pack_board): checked on every hit
+    uint32_t *pend_board;             // [max_games][12] packed position of the pending leaf (select -> expand_backup)
+    unsigned long long ec_key_mask;   // ~0; tests narrow it (cz_search_debug_eval_cache_key_bits) to force key collisions
     // compact evaluation batches (cz_search_select_compact): row of the step's leaf in planes / z / value, or -1
     int32_t *slot_of;                 // [max_games]
     int32_t *evcnt;                   // [2] rows handed out this step / next step (ping-pong, zeroed one step ahead)

@@ -114,6 +114,20 @@ __device__ __forceinline__ unsigned long long wave_position_key(const uint8_t *b
     return h ? h : 1ull;
 }
 __device__ __forceinline__ int ec_bucket(unsigned long long key) { return (int)((key >> 17) & (CZ_EC_BUCKETS - 1)); }
+// The position itself, packed: 90 squares x 4 bits (piece codes 0..14) in 12 dwords, side to move in the top nibble of the
+// last one.  Lane j < 12 packs squares 8j .. 8j+7 (LDS bytes 90..95 of the board are zero).  A cache entry carries this
+// image of its node's position and a hit is only taken when it equals the leaf's: the 64-bit key finds the candidate, the
+// position decides — a key collision cannot lend a wrong node.
+__device__ __forceinline__ uint32_t wave_pack_board(const uint8_t *b, int side, int lane) {
+    uint32_t pk = 0u;
+    if (lane < 12) {
+        const uint32_t w0 = ((const uint32_t *)b)[2 * lane], w1 = ((const uint32_t *)b)[2 * lane + 1];
+        pk = (w0 & 15u) | ((w0 >> 4) & 0xF0u) | ((w0 >> 8) & 0xF00u) | ((w0 >> 12) & 0xF000u);
+        pk |= ((w1 & 15u) | ((w1 >> 4) & 0xF0u) | ((w1 >> 8) & 0xF00u) | ((w1 >> 12) & 0xF000u)) << 16;
+        if (lane == 11) pk |= (uint32_t)side << 28;
+    }
+    return pk;
+}
 
 // COMPACT: the leaf planes of the trees that need a net evaluation are written to consecutive rows handed out by an
 // atomic counter (t.evcnt[parity]); t.slot_of[g] records the row (or -1), the other counter is zeroed for the next
@@ -144,6 +158,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
     int kind = 0, leaf = 0, depth = 0, done_here = 0;
     float pend = 0.f;
     unsigned long long key = 0ull;
+    uint32_t pk = 0u;   // evaluation cache: the leaf position packed (wave_pack_board), lanes 0..11
     int side = t.root_side[g];
     if (!parked) {
         for (int i = lane; i < CZD_BOARD_LDS / 4; i += 64) {
@@ -167,7 +182,9 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
         } else if (mode != 0) {
             // the root's own record does not change while simulations complete (the root is never backed up, quirk Q2)
             const int rcc = __builtin_amdgcn_readfirstlane((int)v.child_count[root]), rN = __builtin_amdgcn_readfirstlane(v.N[root]);
-            int extra_left = extra;
+            // per-launch budgets of simulations completed inside this launch: `extra` terminal ones (cz_search_set_terminal_extra)
+            // and, independently of it, CZ_EC_BUDGET evaluation-cache hits — the cache works with terminal_extra = 0 too
+            int extra_left = extra, cache_left = CACHE ? CZ_EC_BUDGET : 0;
             for (;;) {   // one descent per iteration
                 if (sim_target > 0 && s0 + done_here >= sim_target) { kind = 0; break; }   // this tree has had its playouts
                 int rr = root_rr, node = root;
@@ -246,6 +263,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                     node = c; cb = nbeg; cc = ncnt; nN = nn;
                 }
                 const bool may = extra_left > 0 && depth <= CZ_PATH_MAX;
+                const bool may_cache = cache_left > 0 && depth <= CZ_PATH_MAX;
                 bool full = false;
                 if (CACHE && kind == 1) {
                     // Evaluation cache.  The net is a pure function of (board, side to move) and every row of a batch is
@@ -253,20 +271,28 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                     // same priors and value, bit for bit.  An expanded node with the same key lends its children's move
                     // labels and priors and the value its evaluation backed up: the simulation completes here, without
                     // a net row, and the tree is the one the net would have produced.
-                    key = wave_position_key(b, side, tab.zob, lane);
+                    key = wave_position_key(b, side, tab.zob, lane) & t.ec_key_mask;
+                    key = key ? key : 1ull;
+                    pk = wave_pack_board(b, side, lane);
                     bool hit = false;
                     int src = 0;
-                    if (may) {
-                        const size_t eb = (size_t)g * CZ_EC_ENTRIES + (size_t)ec_bucket(key) * 64 + lane;
-                        const unsigned long long ek = t.ec_key[eb];
-                        const int en = t.ec_node[eb];
-                        const float ev = t.ec_val[eb];
+                    if (may_cache) {
+                        const size_t eb0 = (size_t)g * CZ_EC_ENTRIES + (size_t)ec_bucket(key) * 64;
+                        const unsigned long long ek = t.ec_key[eb0 + lane];
+                        const int en = t.ec_node[eb0 + lane];
+                        const float ev = t.ec_val[eb0 + lane];
                         const unsigned long long m = __ballot(ek == key);
                         if (m) {
                             const int hl = __ffsll((long long)m) - 1;
-                            src = __builtin_amdgcn_readlane(en, hl);
-                            pend = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), hl));
-                            hit = true;
+                            // the candidate's position against the leaf's: 12 lanes, one dword each
+                            const uint32_t lb = lane < 12 ? t.ec_board[(eb0 + hl) * 12 + lane] : 0u;
+                            if (__ballot(lb != pk) == 0ull) {
+                                src = __builtin_amdgcn_readlane(en, hl);
+                                pend = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), hl));
+                                hit = true;
+                            } else if (lane == 0) {
+                                t.ec_collisions[g] += 1u;   // same key, another position: treated as a miss
+                            }
                         }
                         if (lane == 0) { t.ec_hits[g] += hit ? 1u : 0u; t.ec_lookups[g] += 1u; }
                     }
@@ -302,7 +328,8 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                     w = w + x;
                     v.N[n] = cnt; v.W[n] = w; v.Q[n] = w / (float)cnt;
                 }
-                ++done_here; --extra_left;
+                ++done_here;
+                if (CACHE && kind == 1) --cache_left; else --extra_left;
                 if (full) { kind = 0; break; }
                 __threadfence_block();
                 __syncthreads();
@@ -336,8 +363,13 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
         for (int e = lane; e < 90 * C; e += 64) pl[e] = (T)0;
     }
     if (CACHE && (kind == 1 || kind == 3)) {
-        if (kind == 3) key = wave_position_key(b, side, tab.zob, lane);
+        if (kind == 3) {
+            key = wave_position_key(b, side, tab.zob, lane) & t.ec_key_mask;
+            key = key ? key : 1ull;
+            pk = wave_pack_board(b, side, lane);
+        }
         if (lane == 0) t.pend_key[g] = key;
+        if (lane < 12) t.pend_board[(size_t)g * 12 + lane] = pk;   // k_expand_backup files it with the cache entry
     }
     if (lane == 0) {
         t.pend_kind[g] = kind; t.pend_leaf[g] = leaf; t.pend_value[g] = pend;
@@ -549,6 +581,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
                 const unsigned long long em = __ballot(ek == 0ull);
                 const int slot = em ? __ffsll((long long)em) - 1 : (int)((key >> 40) & 63);
                 if (lane == slot) { t.ec_key[eb0 + lane] = key; t.ec_node[eb0 + lane] = leaf; t.ec_val[eb0 + lane] = val; }
+                if (lane < 12) t.ec_board[(eb0 + slot) * 12 + lane] = t.pend_board[(size_t)g * 12 + lane];
             }
         }
         if (kind == 3) { if (lane == 0) t.pend_kind[g] = 0; return; }
@@ -1017,7 +1050,7 @@ __global__ void k_status(CzTrees t, int G, int32_t *__restrict__ status, int32_t
 
 __global__ void k_clear_cache_stats(CzTrees t, int G) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < G) { t.ec_hits[g] = 0u; t.ec_lookups[g] = 0u; }
+    if (g < G) { t.ec_hits[g] = 0u; t.ec_lookups[g] = 0u; t.ec_collisions[g] = 0u; }
 }
 
 }  // namespace

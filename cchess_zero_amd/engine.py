@@ -92,7 +92,9 @@ class SearchEngine:
 
     def set_eval_cache(self, on):
         """Evaluation cache (include/cchess_hip.h: cz_search_set_eval_cache): a leaf whose position the tree has
-        evaluated before is expanded from the remembered node inside the select launch, without a net row."""
+        evaluated before is expanded from the remembered node inside the select launch, without a net row.  A hit is
+        taken only when the stored position equals the leaf's (a key collision is a miss); up to 4 hits per tree and
+        launch, independently of set_terminal_extra."""
         assert self.width == 1 or not on, "the evaluation cache needs one simulation in flight per tree"
         self.ctx.bind_stream()
         check(lib().cz_search_set_eval_cache(self.ctx.h, 1 if on else 0), "cz_search_set_eval_cache")
@@ -103,6 +105,12 @@ class SearchEngine:
         h, n = C.c_ulonglong(0), C.c_ulonglong(0)
         check(lib().cz_search_eval_cache_stats(self.ctx.h, C.byref(h), C.byref(n)), "cz_search_eval_cache_stats")
         return int(h.value), int(n.value)
+
+    def eval_cache_collisions(self):
+        """Key matches the cache refused because the stored position differed from the leaf's (taken as misses)."""
+        n = C.c_ulonglong(0)
+        check(lib().cz_search_eval_cache_collisions(self.ctx.h, C.byref(n)), "cz_search_eval_cache_collisions")
+        return int(n.value)
 
     def set_sim_target(self, target):
         """Trees stop at `target` completed simulations since their last reset / advance (0: no limit)."""

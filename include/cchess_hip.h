@@ -195,13 +195,20 @@ int cz_search_set_terminal_extra(cz_ctx *, int n);
  *   computes every row of a batch independently of the others, so a position a tree has evaluated before would get the
  *   same priors and value again, bit for bit (the reference re-evaluates it: transpositions are separate nodes,
  *   main.py:357-384).  With the cache on, every expanded node is remembered under the 64-bit Zobrist key of its position
- *   (cz_zobrist; per tree 128 buckets x 64 entries, 128 KB); a leaf whose key is found is expanded inside the select
- *   launch from the remembered node's children (labels, priors) and backed up with the remembered value — no net row —
- *   subject to the same per-launch budget as cz_search_set_terminal_extra.  Trees are identical with the cache on or
- *   off; entries follow their nodes through cz_search_advance and are dropped with them.  Turning it on empties it.
- *   cz_search_eval_cache_stats: hits / lookups summed over the trees since the cache was turned on (synchronises). */
+ *   (cz_zobrist; per tree 128 buckets x 64 entries of {key, node, value, the position itself packed into 48 bytes} =
+ *   512 KB); a leaf whose key is found AND whose position equals the stored one is expanded inside the select launch from
+ *   the remembered node's children (labels, priors) and backed up with the remembered value — no net row.  The key only
+ *   finds the candidate, the position decides: a key collision is a miss (counted), never a wrong node.  Up to 4 hits
+ *   complete per tree and launch, a budget of their own beside cz_search_set_terminal_extra (the cache works with
+ *   terminal_extra = 0).  Trees are identical with the cache on or off; entries follow their nodes through
+ *   cz_search_advance and are dropped with them.  Turning it on empties it.
+ *   cz_search_eval_cache_stats: hits / lookups summed over the trees since the cache was turned on (synchronises);
+ *   cz_search_eval_cache_collisions: key matches refused because the stored position differed;
+ *   cz_search_debug_eval_cache_key_bits (tests): keys narrowed to 8..24 bits so that collisions DO occur (64 = full). */
 int cz_search_set_eval_cache(cz_ctx *, int on);
 int cz_search_eval_cache_stats(cz_ctx *, unsigned long long *hits, unsigned long long *lookups);
+int cz_search_eval_cache_collisions(cz_ctx *, unsigned long long *collisions);
+int cz_search_debug_eval_cache_key_bits(cz_ctx *, int bits);
 int cz_search_select_k(cz_ctx *, int mode, int k, const uint8_t *active, void *leaf_planes, int dtype,
                        int channels, uint8_t *needs_eval);
 int cz_search_expand_backup_k(cz_ctx *, int k, const void *logits, const void *value, int dtype);

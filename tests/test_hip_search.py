@@ -439,10 +439,14 @@ def test_eval_cache_keeps_the_golden_trees(mcts_golden):
     assert spared > 0
 
 
-def test_eval_cache_follows_the_tree_through_advances(rules_golden):
+@pytest.mark.parametrize("key_bits,extra", [(64, 4), (64, 0), (11, 4)])
+def test_eval_cache_follows_the_tree_through_advances(rules_golden, key_bits, extra):
     """48 trees, 3 plies x 500 playouts with re-rooting in between, evaluation cache + terminal simulations inside select,
     against the oracle's plain schedule: identical root statistics and whole trees after every ply (the cache entries of
-    kept nodes are remapped by cz_search_advance, the others dropped), with fewer net rows."""
+    kept nodes are remapped by cz_search_advance, the others dropped), with fewer net rows.
+    extra = 0: the cache has its own per-launch budget and must hit with terminal_extra = 0 too.
+    key_bits = 11: keys narrowed to 2048 values so that different positions DO share a key — every such match must be
+    refused by the position check (collisions counted, taken as misses) and the trees must still be the oracle's."""
     from oracle import oracle as O
     g = rules_golden
     ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
@@ -452,6 +456,8 @@ def test_eval_cache_follows_the_tree_through_advances(rules_golden):
     rr = (np.arange(G) * 3 % 40).astype(np.int32)
     hip = _HipEngine(G, 80000)
     orc = O.Search(G, 80000)
+    from cchess_zero_amd._lib import check, lib
+    check(lib().cz_search_debug_eval_cache_key_bits(hip.e.ctx.h, key_bits), "cz_search_debug_eval_cache_key_bits")
     hip.e.set_eval_cache(True)
     hip.reset(boards, side, rr)
     orc.reset(boards, side, rr)
@@ -464,7 +470,7 @@ def test_eval_cache_follows_the_tree_through_advances(rules_golden):
             rows_orc += int(on.sum())
             lg, v = fwd(op)
             orc.expand_backup(lg, v)
-        hip.e.set_terminal_extra(4)
+        hip.e.set_terminal_extra(extra)
         hip.e.set_sim_target(playouts)
         for mode in [0] + [1] * playouts:
             busy = (hip.e.status()[2].cpu().numpy() < playouts) & (hip.status() & ~8 == 0)
@@ -493,10 +499,14 @@ def test_eval_cache_follows_the_tree_through_advances(rules_golden):
         hip.advance(played)
         orc.advance(played)
     hits, lookups = hip.e.eval_cache_stats()
-    print("evaluation cache over 3 plies x %d playouts x %d trees: %d hits / %d lookups (by ply: %s), net rows %d instead of %d" %
-          (playouts, G, hits, lookups, np.diff([0] + hits_by_ply).tolist(), rows_hip, rows_orc))
+    collisions = hip.e.eval_cache_collisions()
+    print("evaluation cache (%d-bit keys, terminal_extra %d) over 3 plies x %d playouts x %d trees: %d hits / %d lookups (by ply: %s), "
+          "%d key collisions refused, net rows %d instead of %d" %
+          (key_bits, extra, playouts, G, hits, lookups, np.diff([0] + hits_by_ply).tolist(), collisions, rows_hip, rows_orc))
     assert hits > 0 and rows_hip < rows_orc and hits_by_ply[2] > hits_by_ply[1] > hits_by_ply[0]
+    assert (collisions > 100) if key_bits < 64 else (collisions == 0)
     hip.e.set_eval_cache(False)
+    check(lib().cz_search_debug_eval_cache_key_bits(hip.e.ctx.h, 64), "cz_search_debug_eval_cache_key_bits")
 
 
 def test_advance_ready_device_driver_matches_host_logic():
