@@ -256,9 +256,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = dev if (dist_on and args.dist_backend == "nccl") else torch.device("cpu")   # where collectives run
 
+    from cchess_zero_amd import parallel as PL
     from cchess_zero_amd.engine import Context, SearchEngine
     from cchess_zero_amd.net import PolicyValueNet, flops_per_position
     from cchess_zero_amd.rules import Rules
+    # one process per GPU: every rank keeps to its own CPUs (the launcher thread of a rank must not be migrated over, or
+    # throttled together with, the other ranks' under the box's CPU quota)
+    cpus = PL.pin_rank_to_cpus(local_rank, world) if world > 1 else None
+    if world > 1:
+        torch.set_num_threads(max(1, min(4, len(cpus) if cpus else 2)))
 
     G, playout = args.games, args.playout
     tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
@@ -359,6 +365,7 @@ def main():
 
     sp = None
     gather_stats = {"gathers": 0, "records": 0, "seconds": 0.0}
+    exchange, gathered = [None], []
     if args.selfplay:
         from cchess_zero_amd import parallel
         from cchess_zero_amd.selfplay import SelfPlay
@@ -376,9 +383,14 @@ def main():
                 if timed and args.timed_gather and dist_on:
                     rec = sp.drain_device()                       # device rows of the games that just finished (syncs on the cursor)
                     t1 = time.perf_counter()
-                    allrec, counts = parallel.gather_records_device(rec if cdev.type == "cuda" else rec.cpu())
+                    if exchange[0] is None:   # fixed capacity: nothing to agree on, no host wait on the collective
+                        exchange[0] = PL.RecordExchange(max(4096, G // 2), cdev)
+                    out = exchange[0].exchange(rec if cdev.type == "cuda" else rec.cpu())
                     gather_stats["gathers"] += 1
-                    gather_stats["records"] += int(counts.sum().item())   # the host looks at the result: the collective is done
+                    gathered.append(out[:, 0, :8].clone())               # the counts are looked at after the timed region
+                    if len(gathered) > 64:
+                        gather_stats["records"] += int(torch.stack(gathered).contiguous().view(torch.int64).sum().item())
+                        del gathered[:]
                     gather_stats["seconds"] += time.perf_counter() - t1
                 else:   # the consumer of the records: the finished games leave the device
                     gather_stats["records"] += len(sp.drain())
@@ -427,11 +439,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
-        dtm = mine
-        if dist_on:
-            tt = torch.tensor([mine], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtm = float(tt.item())
+        dtm = PL.max_over_ranks(mine, cdev) if dist_on else mine
         rows = float(G * K) * nsteps
         rpl = float(G * K)
         if compact:
@@ -445,17 +453,14 @@ def main():
     if args.steady_steps > 0:
         steady = timed_region(args.steady_steps)
     if dist_on:
-        # outside the timed regions: the record exchange of the self-play loop (one all-gather of packed (s, pi, z) records,
-        # device-resident end to end) on a ragged token batch, so every N>1 run exercises the collective path
-        from cchess_zero_amd import parallel, selfplay
-        tok = torch.zeros((4 + rank, selfplay.REC_BYTES), dtype=torch.uint8, device=cdev)
-        tok[:, 0] = rank + 1
-        try:
-            allrec, counts = parallel.gather_records_device(tok)
-            gather_ok = bool(counts.tolist() == [4 + r for r in range(world)] and int(allrec[world - 1, 0, 0]) == world)
-        except Exception as e:   # the throughput number above must survive a failure of this (untimed) exchange
-            gather_ok = "failed: %r" % (e,)
+        # outside the timed regions: the record exchange of the self-play loop (all-gather of packed (s, pi, z) records,
+        # device-resident end to end; both the sized and the fixed-capacity form) on a ragged token batch, so every N>1 run
+        # exercises the collective path; a failure is reported in the line, it does not take the throughput number with it
+        gather_ok = PL.gather_selfcheck(cdev)
 
+    if gathered:
+        gather_stats["records"] += int(torch.stack(gathered).contiguous().view(torch.int64).sum().item())
+        del gathered[:]
     if sp:   # the self-play loop launches through SelfPlay.run_async: sample the kernels' durations on 16 extra, uncounted steps
         eng.set_terminal_extra(TE)
         eng.set_sim_target(playout)
@@ -490,15 +495,10 @@ def main():
     def totals(leg):
         """(max-over-ranks seconds, my seconds, my sims, my rows, .) -> (sims of all ranks, net rows of all ranks, per-rank sims/s)."""
         dtm, mine_dt, sims_, rows_, _ = leg
-        t = torch.tensor([float(sims_), float(rows_)], dtype=torch.float64, device=cdev)
-        pr_ = [float(sims_) / mine_dt]
-        if dist_on:
-            pr = torch.zeros(world, dtype=torch.float64, device=cdev)
-            pr[rank] = float(sims_) / mine_dt
-            dist.all_reduce(pr)
-            pr_ = pr.tolist()
-            dist.all_reduce(t)
-        return float(t[0].item()), float(t[1].item()), pr_
+        if not dist_on:
+            return float(sims_), float(rows_), [float(sims_) / mine_dt]
+        tot = PL.sum_over_ranks([sims_, rows_], cdev)
+        return tot[0], tot[1], PL.per_rank(float(sims_) / mine_dt, cdev)
     total_sims, total_rows, per_rank = totals((dt, my_dt, my_sims, my_rows, rows_per_launch))
     steady_out = None
     if steady is not None:
@@ -568,7 +568,7 @@ def main():
            "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "hip_graph": graph[0] is not None, "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
            "positions": "seeded random playouts from the start position, ply~U[0,80]",
            "nodes_per_tree": cap, "node_pool_GB": G * cap * 28 / 1e9,
-           "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "per_rank_sims_per_s": per_rank,
+           "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "rank0_cpus": cpus, "per_rank_sims_per_s": per_rank,
            "simulations_counted": total_sims, "net_rows": total_rows,
            "simulations_per_net_row": total_sims / max(1.0, total_rows), "terminal_extra": TE, "advance_every": args.advance_every,
            "net_rows_per_s": total_rows / dt,

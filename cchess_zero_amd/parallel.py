@@ -8,6 +8,8 @@ the CPU tests) — the multi-GPU form of `self.data_buffer.extend(...)`, main.py
 fixed-size (selfplay.REC_BYTES), ranks pad to the longest shard so that a single all_gather moves
 everything; on the 8-GPU full mesh that is one hop per peer (per-link bound, 7 x ~153 GB/s per GPU).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -43,6 +45,126 @@ def gather_records_device(rec, group=None):
         pad[:rec.shape[0]] = rec
     dist.all_gather_into_tensor(out.view(world * m, REC_BYTES), pad, group=group)
     return out, counts
+
+
+class RecordExchange:
+    """The per-ply record exchange of a long self-play run (configs[3]): every rank contributes what it drained since
+    the last call, WITHOUT any host synchronisation on the collective — the payload has a fixed capacity, so nothing has
+    to be agreed on before the buffers are allocated.  gather_records_device needs the largest shard size on the host
+    (a count all-gather + .item()), i.e. a host wait on the slowest rank in every exchange: with 8 ranks under a small CPU
+    quota that wait is scheduling jitter inside the timed region.  Here: one all_gather_into_tensor of [capacity + 1, REC_BYTES]
+    per rank (row 0 carries the count); rows beyond the capacity are carried over to the next exchange, so the number of
+    collectives is the same on every rank whatever the shard sizes.  The gathered tensor and the counts stay on the
+    collective's device; the consumer looks at them whenever it wants (results())."""
+
+    def __init__(self, capacity, device, group=None):
+        self.capacity, self.device, self.group = int(capacity), torch.device(device), group
+        self.world = dist.get_world_size(group)
+        self.carry = torch.zeros((0, REC_BYTES), dtype=torch.uint8, device=self.device)
+        self.exchanges = 0
+        self._last = None
+
+    def exchange(self, rec):
+        """rec: uint8 [n, REC_BYTES] on the collective's device (n is known on the host: it is a tensor shape)."""
+        rec = rec.reshape(-1, REC_BYTES)
+        if self.carry.shape[0]:
+            rec = torch.cat([self.carry, rec], 0)
+        n = min(rec.shape[0], self.capacity)
+        send = torch.zeros((self.capacity + 1, REC_BYTES), dtype=torch.uint8, device=self.device)
+        send[0, :8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(self.device, non_blocking=True)
+        if n:
+            send[1:1 + n] = rec[:n]
+        self.carry = rec[n:].clone() if rec.shape[0] > n else rec[:0]
+        out = torch.empty((self.world, self.capacity + 1, REC_BYTES), dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(out.view(self.world * (self.capacity + 1), REC_BYTES), send, group=self.group)
+        self.exchanges += 1
+        self._last = out
+        return out
+
+    def pending(self):
+        """Records held back because the last shard exceeded the capacity (sent by the next exchange)."""
+        return int(self.carry.shape[0])
+
+    @staticmethod
+    def unpack(out):
+        """[world, capacity + 1, REC_BYTES] -> (records [sum n_r, REC_BYTES] host array in rank order, counts int64 [world])."""
+        o = out.cpu()
+        counts = o[:, 0, :8].contiguous().view(torch.int64).reshape(-1)
+        parts = [o[r, 1:1 + int(counts[r])] for r in range(o.shape[0])]
+        rec = torch.cat(parts, 0).numpy() if parts else np.zeros((0, REC_BYTES), np.uint8)
+        return rec.reshape(-1, REC_BYTES), counts.numpy()
+
+
+# ---- bench.py's multi-rank plumbing (kept here so that the gloo CPU tests run the very same code with 8 ranks) ----------
+def max_over_ranks(seconds, device):
+    """The slowest rank's time for a barrier-bracketed region (the bench contract: MAX over ranks)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(values, device):
+    """Element-wise sum of a short list of numbers over the ranks -> list of floats (float64 on the collective's device)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return t.tolist()
+
+
+def per_rank(value, device):
+    """[value of rank 0, value of rank 1, ...] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[rank] = float(value)
+    dist.all_reduce(t)
+    return t.tolist()
+
+
+def gather_selfcheck(device):
+    """A ragged token batch through gather_records_device and through RecordExchange: True when every rank sees every
+    rank's rows, else a string saying what failed (the bench line must survive a broken exchange)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    try:
+        tok = torch.zeros((4 + rank, REC_BYTES), dtype=torch.uint8, device=device)
+        tok[:, 0] = rank + 1
+        allrec, counts = gather_records_device(tok)
+        ok = counts.tolist() == [4 + r for r in range(world)] and int(allrec[world - 1, 0, 0]) == world
+        ex = RecordExchange(5, device)                     # capacity 5 < the larger shards: exercises the carry-over
+        rounds = (4 + world - 1 + 4) // 5                   # enough rounds for the largest shard (4 + world - 1 rows)
+        seen = [0] * world
+        for i in range(rounds):
+            rec_i, c_i = RecordExchange.unpack(ex.exchange(tok if i == 0 else tok[:0]))
+            o = 0
+            for r in range(world):
+                n = int(c_i[r])
+                ok = ok and n <= 5 and all(int(x) == r + 1 for x in rec_i[o:o + n, 0])
+                seen[r] += n
+                o += n
+        ok = ok and seen == [4 + r for r in range(world)] and ex.pending() == 0
+        return bool(ok)
+    except Exception as e:
+        return "failed: %r" % (e,)
+
+
+def pin_rank_to_cpus(local_rank, local_world, max_per_rank=8):
+    """One process per GPU: give every rank its own CPUs so that 8 launcher threads do not migrate over (and contend for)
+    the same cores — under a cgroup CPU quota smaller than the visible CPU count the scheduler otherwise spreads runnable
+    threads over all visible CPUs and throttles them together.  Returns the CPU list, or None when affinity cannot be
+    set.  The CPUs of a rank are contiguous: rank r gets allowed[r * k : (r + 1) * k], k = min(max_per_rank,
+    allowed // local_world)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        k = max(1, min(int(max_per_rank), len(allowed) // max(1, int(local_world))))
+        mine = allowed[int(local_rank) * k:(int(local_rank) + 1) * k] or allowed
+        os.sched_setaffinity(0, mine)
+        return mine
+    except Exception:
+        return None
 
 
 def gather_records(rec, device=None, group=None):

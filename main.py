@@ -637,8 +637,12 @@ if __name__ == '__main__':
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from cchess_zero_amd import parallel as _pl
+        _pl.pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))   # own CPUs per rank
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if args.mode == 'train':
         train_main = cchess_main(args.train_playout, args.batch_size, True, args.search_threads, args.processor, args.num_gpus,

@@ -112,3 +112,74 @@ def test_record_roundtrip_and_dense_expansion():
     # the vectorised expansion agrees to the last bits
     _, pi_fast, _ = SP.to_dense(rec, exact=False)
     assert np.allclose(pi_fast, pi, rtol=1e-14, atol=0)
+
+
+def _plumbing_worker(rank, world, port, q):
+    """bench.py's multi-rank plumbing (cchess_zero_amd/parallel.py), 8 ranks over gloo on the CPU."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cchess_zero_amd import parallel as PL
+    from cchess_zero_amd._lib import REC_BYTES
+    dev = torch.device("cpu")
+    cpus = PL.pin_rank_to_cpus(rank, world)
+    slowest = PL.max_over_ranks(1.0 + 0.25 * rank, dev)
+    tot = PL.sum_over_ranks([10 * (rank + 1), 2.5], dev)
+    pr = PL.per_rank(100.0 + rank, dev)
+    ok = PL.gather_selfcheck(dev)
+    # fixed-capacity exchange, 6 rounds of ragged shards (0 .. 40 records) through a capacity of 16: every record must
+    # arrive exactly once, in per-rank order, whatever was carried over; two flushing rounds at the end
+    rng = np.random.default_rng(1234)                     # the same shard-size table on every rank
+    sizes = rng.integers(0, 41, size=(6, world))
+    sizes[2, :] = 0                                       # a round in which nobody has anything
+    sizes[3, 1 % world] = 40
+    ex = PL.RecordExchange(16, dev)
+    sent, got = [], [[] for _ in range(world)]
+    serial = 0
+    for rnd in range(6 + 3):
+        n = int(sizes[rnd, rank]) if rnd < 6 else 0
+        rec = torch.zeros((n, REC_BYTES), dtype=torch.uint8)
+        for i in range(n):
+            rec[i, 0], rec[i, 1], rec[i, 2] = rank, serial & 255, serial >> 8
+            serial += 1
+        sent.append(n)
+        out = ex.exchange(rec)
+        recs, counts = PL.RecordExchange.unpack(out)
+        assert counts.max() <= 16
+        o = 0
+        for r in range(world):
+            got[r].extend((int(x[0]), int(x[1]) | (int(x[2]) << 8)) for x in recs[o:o + int(counts[r])])
+            o += int(counts[r])
+    want = [[(r, i) for i in range(int(sizes[:, r].sum()))] for r in range(world)]
+    q.put((rank, cpus, slowest, tot, pr, ok, ex.pending(), got == want, ex.exchanges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world8_bench_plumbing_and_fixed_capacity_exchange():
+    """SURVEY §8(e) at the size the driver will run it (8 ranks), on the CPU: the helpers bench.py times its N > 1 runs with
+    (max-over-ranks time, summed counters, per-rank list), the record-exchange self check, per-rank CPU pinning, and the
+    fixed-capacity RecordExchange with carry-over (no host agreement on sizes, same number of collectives on every rank)."""
+    world = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plumbing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, cpus, slowest, tot, pr, ok, pending, complete, nex in res:
+        assert slowest == 1.0 + 0.25 * (world - 1)
+        assert tot == [10.0 * world * (world + 1) / 2, 2.5 * world]
+        assert pr == [100.0 + r for r in range(world)]
+        assert ok is True, ok
+        assert pending == 0 and complete and nex == 9
+        assert cpus is None or len(cpus) >= 1
+    pinned = [tuple(r[1]) for r in res if r[1] is not None]
+    if len(pinned) == world and len(set(sum(pinned, ()))) >= world:   # enough CPUs here: the ranks' sets are disjoint
+        assert len(set(sum(pinned, ()))) == sum(len(c) for c in pinned)
