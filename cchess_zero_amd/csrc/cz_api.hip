@@ -46,6 +46,7 @@ void carve_trees(Carver &c, CzTrees &t, size_t G, size_t words) {
     t.pk_side = c.take<uint8_t>(G); t.pk_nmoves = c.take<uint16_t>(G);
     t.slot_of = c.take<int32_t>(G);
     t.evcnt = c.take<int32_t>(2);
+    t.adv_list = c.take<int32_t>(G); t.adv_cnt = c.take<int32_t>(4);
     t.evtotal = c.take<unsigned long long>(2);
 }
 

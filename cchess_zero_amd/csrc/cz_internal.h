@@ -96,6 +96,7 @@ struct CzTrees {
     int words;           // ceil(cap / 64): 64-node words of the advance bitmap
     unsigned long long *mark_bits;   // [max_games][words] k_advance: which nodes of the tree are kept
     uint32_t *mark_rank;             // [max_games][words] kept nodes before the word = new index of its first kept node
+    int32_t *adv_list, *adv_cnt;     // [max_games], [1]  k_advance_list: the trees that move at this cz_search_advance
     uint8_t *root_board; // [max_games][96]
     union {              // [max_games] records; t.<field>[g] addresses rec[g].<field>
         CzTreeRec *rec;
@@ -138,6 +139,7 @@ struct cz_ctx {
     CzTrees t;
     void *tree_block;  // single allocation behind the per-tree arrays
     void *pool_block;
+    bool adv_attr_set;   // dynamic-LDS opt-in of k_advance_lds done
     bool conv_attr_set, tower_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1

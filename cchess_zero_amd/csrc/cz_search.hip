@@ -13,6 +13,7 @@
 #include "cz_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -907,7 +908,7 @@ __device__ __forceinline__ int mark_rank_of(const unsigned long long *bits, cons
     return (int)rank[i >> 6] + __popcll(below);
 }
 
-__global__ __launch_bounds__(256) void k_advance(CzTrees t, CzTables tab, int G, const uint16_t *__restrict__ played) {
+__global__ __launch_bounds__(256) void k_advance_global(CzTrees t, CzTables tab, int G, const uint16_t *__restrict__ played) {
     __shared__ int s_found, s_total;
     __shared__ int s_flag[256];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1031,6 +1032,174 @@ __global__ __launch_bounds__(256) void k_advance(CzTrees t, CzTables tab, int G,
     }
 }
 
+// The same compaction with the bitmap and its ranks in LDS, 1024 nodes per chunk (16 waves) and the next chunk's loads in
+// flight while the current one is resolved: a tree of a 1600-playout search has ~62 k nodes — 245 strictly sequential
+// 256-node chunks of the kernel above, each paying two or three dependent global round trips (parent, bitmap word, rank),
+// ~0.6 ms for the handful of trees that move at one check of an asynchronous loop, i.e. ~3 % of the run.  Here a chunk costs
+// LDS round trips only (61 chunks, parent / node fields prefetched one chunk ahead).  Used when the tree's bitmap fits the
+// workgroup's dynamic LDS (12 bytes per 64 nodes); the global-memory variant above remains for larger pools.
+#define CZ_ADV_T 1024
+__device__ __forceinline__ bool lmark_tst(const unsigned long long *bits, int i) { return (bits[i >> 6] >> (i & 63)) & 1ull; }
+__device__ __forceinline__ int lmark_rank_of(const unsigned long long *bits, const uint32_t *rank, int i) {
+    const unsigned long long below = (i & 63) ? (bits[i >> 6] & ((1ull << (i & 63)) - 1ull)) : 0ull;
+    return (int)rank[i >> 6] + __popcll(below);
+}
+
+// the trees that move at this call (a handful of thousands in an asynchronous loop): compacted into a list so that the
+// 1024-thread workgroups below are launched for them only
+__global__ __launch_bounds__(256) void k_advance_list(CzTrees t, int G, const uint16_t *__restrict__ played) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < G && played[g] < CZ_NLABELS) t.adv_list[atomicAdd(t.adv_cnt, 1)] = g;
+}
+
+__device__ __forceinline__ void advance_tree_lds(const CzTrees &t, const CzTables &tab, int g, unsigned long long *adv_lds,
+                                                 const uint16_t *__restrict__ played) {
+    __shared__ int s_found, s_total;
+    __shared__ int s_flag[CZ_ADV_T];
+    __shared__ int s_wave[CZ_ADV_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t l = played[g];
+    const TreeView v = view_of(t, g);
+    unsigned long long *bits = adv_lds;                          // [t.words]
+    uint32_t *rank = (uint32_t *)(adv_lds + t.words);            // [t.words]
+    const int root = t.root_node[g];
+    const int n = t.n_nodes[g];
+    const int cb = v.child_begin[root];
+    const int cc = cb < 0 ? 0 : v.child_count[root];
+    if (tid == 0) s_found = -1;
+    __syncthreads();
+    if (tid < cc && v.move[cb + tid] == l) s_found = cb + tid;
+    uint8_t *rb = t.root_board + (size_t)g * CZD_BOARD_LDS;
+    if (tid == 0) {   // board bookkeeping (selfplay, main.py:1522-1528)
+        const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+        const int cap = rb[dst];
+        rb[dst] = rb[src]; rb[src] = 0;
+        t.root_side[g] ^= 1;
+        t.root_rr[g] = cap ? 0 : t.root_rr[g] + 1;
+        t.sims[g] = 0;
+    }
+    __syncthreads();
+    const int found = s_found;
+    if (found < 0) {
+        if (tid == 0) {
+            t.status[g] = (t.status[g] & ~CZ_ST_POOL_EXHAUSTED) | CZ_ST_BAD_ADVANCE;
+            init_root(v, 0);
+            t.root_node[g] = 0; t.n_nodes[g] = 1;
+        }
+        ec_clear_tree(t, g, tid, CZ_ADV_T);
+        return;
+    }
+    // ---- pass 1: the kept-node bitmap (nothing below `found` can be in its subtree)
+    const int w0 = found >> 6, W = (n + 63) >> 6;
+    for (int w = tid; w < w0; w += CZ_ADV_T) bits[w] = 0ull;
+    const int first = w0 << 6;
+    int pn = (first + tid < n && first + tid > found) ? v.parent[first + tid] : -1;
+    __syncthreads();
+    for (int base = first; base < n; base += CZ_ADV_T) {
+        const int i = base + tid;
+        const int p = pn;
+        const int in = i + CZ_ADV_T;
+        pn = (in < n) ? v.parent[in] : -1;      // the next chunk's parents are in flight while this chunk is resolved
+        int st;   // 0 unknown, 1 kept, 2 dropped
+        if (i >= n || i < found) st = 2;
+        else if (i == found) st = 1;
+        else if (p < found) st = 2;
+        else if (p == found) st = 1;
+        else if (p < base) st = lmark_tst(bits, p) ? 1 : 2;
+        else st = 0;
+        s_flag[tid] = st;
+        __syncthreads();
+        for (;;) {   // parents inside the chunk: iterate (parent < child bounds the rounds by the chunk's chain depth)
+            int open = 0;
+            if (st == 0) { const int ps = s_flag[p - base]; if (ps) st = ps; else open = 1; }
+            open = __syncthreads_or(open);
+            s_flag[tid] = st;
+            __syncthreads();
+            if (!open) break;
+        }
+        const unsigned long long m = __ballot(st == 1);
+        if (lane == 0 && (base >> 6) + wave < W) bits[(base >> 6) + wave] = m;
+        __syncthreads();
+    }
+    // ---- rank: exclusive prefix count over the bitmap words
+    {
+        const int per = (W + CZ_ADV_T - 1) / CZ_ADV_T;
+        const int lo = tid * per, hi = min(W, lo + per);
+        int c = 0;
+        for (int w = lo; w < hi; ++w) c += __popcll(bits[w]);
+        int x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        if (wave == 0) {
+            int tv = lane < CZ_ADV_T / 64 ? s_wave[lane] : 0, ti = tv;
+#pragma unroll
+            for (int d = 1; d < CZ_ADV_T / 64; d <<= 1) { const int y = __shfl_up(ti, d, 64); if (lane >= d) ti += y; }
+            if (lane < CZ_ADV_T / 64) s_wave[lane] = ti - tv;
+            if (lane == CZ_ADV_T / 64 - 1) s_total = ti;
+        }
+        __syncthreads();
+        int acc = x - c + s_wave[wave];
+        for (int w = lo; w < hi; ++w) { rank[w] = (uint32_t)acc; acc += __popcll(bits[w]); }
+        __syncthreads();
+    }
+    // ---- evaluation cache: entries of kept nodes follow them to their new indices, the others are forgotten
+    if (t.ec_key) {
+        unsigned long long *ek = t.ec_key + (size_t)g * CZ_EC_ENTRIES;
+        int32_t *en = t.ec_node + (size_t)g * CZ_EC_ENTRIES;
+        for (int e = tid; e < CZ_EC_ENTRIES; e += CZ_ADV_T) {
+            if (ek[e] == 0ull) continue;
+            const int nd = en[e];
+            if (nd >= found && nd < n && lmark_tst(bits, nd)) en[e] = lmark_rank_of(bits, rank, nd);
+            else ek[e] = 0ull;
+        }
+    }
+    // ---- pass 2: move the kept nodes down, ascending (new index <= old index: a chunk's stores never reach the next chunk,
+    // whose loads are therefore issued before this chunk's stores)
+    float nP = 0.f, nW = 0.f, nQ = 0.f;
+    int nN = 0, np = -1, ncb = -1;
+    uint16_t ncc = 0, nmv = 0;
+    bool nkeep = first + tid < n && lmark_tst(bits, first + tid);
+    if (nkeep) {
+        const int i = first + tid;
+        nP = v.P[i]; nW = v.W[i]; nQ = v.Q[i]; nN = v.N[i]; np = v.parent[i]; ncb = v.child_begin[i]; ncc = v.child_count[i]; nmv = v.move[i];
+    }
+    for (int base = first; base < n; base += CZ_ADV_T) {
+        const int i = base + tid;
+        const bool keep = nkeep;
+        const float cP = nP, cW = nW, cQ = nQ;
+        const int cN = nN, cp = np, ccb = ncb;
+        const uint16_t ccc = ncc, cmv = nmv;
+        const int in = i + CZ_ADV_T;
+        nkeep = in < n && lmark_tst(bits, in);
+        if (nkeep) {
+            nP = v.P[in]; nW = v.W[in]; nQ = v.Q[in]; nN = v.N[in]; np = v.parent[in]; ncb = v.child_begin[in]; ncc = v.child_count[in]; nmv = v.move[in];
+        }
+        __syncthreads();   // every thread holds its node of this chunk (loaded one iteration ago) before any slot of it is overwritten
+        if (keep) {
+            const int o = lmark_rank_of(bits, rank, i);
+            v.P[o] = cP; v.W[o] = cW; v.Q[o] = cQ; v.N[o] = cN;
+            v.parent[o] = i == found ? -1 : lmark_rank_of(bits, rank, cp);
+            v.child_begin[o] = ccb >= 0 ? lmark_rank_of(bits, rank, ccb) : -1;
+            v.child_count[o] = ccc; v.move[o] = cmv;
+        }
+    }
+    if (tid == 0) {
+        t.root_node[g] = 0; t.n_nodes[g] = s_total;
+        t.status[g] &= ~CZ_ST_POOL_EXHAUSTED;
+    }
+}
+
+__global__ __launch_bounds__(CZ_ADV_T) void k_advance_lds(CzTrees t, CzTables tab, const uint16_t *__restrict__ played) {
+    extern __shared__ unsigned long long adv_lds[];
+    const int cnt = *t.adv_cnt;
+    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+        advance_tree_lds(t, tab, t.adv_list[e], adv_lds, played);
+        __syncthreads();   // the LDS bitmap and flags are reused by the next tree
+    }
+}
+
 __global__ void k_root_state(CzTrees t, int G, uint8_t *__restrict__ boards, uint8_t *__restrict__ side, int32_t *__restrict__ rr) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
@@ -1129,7 +1298,20 @@ int czk_search_reload_finished(cz_ctx *c, const uint8_t *ready, const uint16_t *
 }
 
 int czk_search_advance(cz_ctx *c, const uint16_t *played) {
-    hipLaunchKernelGGL(k_advance, dim3(c->G), dim3(256), 0, c->stream, c->t, c->tab, c->G, played);
+    // bitmap + ranks of one tree in LDS: 12 bytes per 64 nodes (38 KB for the bench's 205 056-node pools)
+    const size_t lds = (size_t)c->t.words * 12;
+    const size_t lds_max = 150 * 1024;   // 160 KB per CU minus the kernel's static LDS; the attribute is per function, so always the maximum
+    if (lds <= lds_max && !getenv("CCHESS_ADVANCE_GLOBAL")) {
+        if (!c->adv_attr_set) {
+            CZ_HIP(hipFuncSetAttribute((const void *)k_advance_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            c->adv_attr_set = true;
+        }
+        CZ_HIP(hipMemsetAsync(c->t.adv_cnt, 0, sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_advance_list, dim3((c->G + 255) / 256), dim3(256), 0, c->stream, c->t, c->G, played);
+        hipLaunchKernelGGL(k_advance_lds, dim3(c->G < 512 ? c->G : 512), dim3(CZ_ADV_T), lds, c->stream, c->t, c->tab, played);
+    } else {
+        hipLaunchKernelGGL(k_advance_global, dim3(c->G), dim3(256), 0, c->stream, c->t, c->tab, c->G, played);
+    }
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
