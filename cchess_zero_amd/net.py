@@ -177,6 +177,23 @@ def from_tf_variables(variables, res_block_nums=None):
     return out, blocks, gs
 
 
+def momentum_slots_from_tf_variables(variables, res_block_nums):
+    """The MomentumOptimizer slot variables of a checkpoint (`<variable>/Momentum`, what tf.train.Saver persists next to the
+    weights) -> dict keyed like export_tf_layout() (TF layout), or {} when the checkpoint holds none.  All or nothing."""
+    v = {}
+    for k in (variables.files if hasattr(variables, "files") else variables.keys()):
+        name = k[:-2] if k.endswith(":0") else k
+        v[name] = variables[k]
+    out = {}
+    for tf_name, ours in tf_variable_names(res_block_nums).items():
+        if tf_name.split("/")[-1] in ("moving_mean", "moving_variance"):
+            continue
+        if tf_name + "/Momentum" not in v:
+            return {}
+        out[ours] = np.asarray(v[tf_name + "/Momentum"])
+    return out
+
+
 def to_tf_variables(module, global_step=None):
     """The inverse: a dict keyed by the reference graph's TF1 variable names (np.savez(**d) gives a file that a
     three-line TF script can assign back into the reference's graph)."""

@@ -90,6 +90,23 @@ class Trainer:
             return float(t[0]), float(t[1]), self.global_step
         return float(accuracy.detach()), float(loss.detach()), self.global_step
 
+    def load_tf_momentum(self, slots):
+        """Momentum slots in the reference's TF layout (net.momentum_slots_from_tf_variables: HWIO kernels, [in,out] FC
+        weights) -> this optimiser's momentum buffers.  tf.train.MomentumOptimizer's accumulator (accum = momentum * accum +
+        grad) is the quantity torch.optim.SGD keeps as momentum_buffer, so training resumes where the checkpoint stopped."""
+        m = self.module
+        pairs = []
+        for i, cb in enumerate(m.convbns()):
+            pairs.append((cb.conv.weight, torch.from_numpy(np.asarray(slots["conv%d/kernel" % i], np.float32)).permute(3, 2, 0, 1)))
+            pairs.append((cb.conv.bias, torch.from_numpy(np.asarray(slots["conv%d/bias" % i], np.float32))))
+        for name, fc in (("policy_fc", m.policy_fc), ("value_fc1", m.value_fc1), ("value_fc2", m.value_fc2)):
+            pairs.append((fc.weight, torch.from_numpy(np.asarray(slots[name + "/weights"], np.float32)).t()))
+            pairs.append((fc.bias, torch.from_numpy(np.asarray(slots[name + "/biases"], np.float32))))
+        for p, buf in pairs:
+            if tuple(buf.shape) != tuple(p.shape):
+                raise ValueError("momentum slot of shape %s for a parameter of shape %s" % (tuple(buf.shape), tuple(p.shape)))
+            self.opt.state[p]["momentum_buffer"] = buf.contiguous().to(p.device, p.dtype).clone()
+
     def state_dict(self):
         """Model, momentum buffers (tf.train.Saver persists the Momentum slot variables) and the step."""
         return {"model": self.module.state_dict(), "optimizer": self.opt.state_dict(), "global_step": int(self.global_step)}

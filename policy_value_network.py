@@ -20,7 +20,9 @@ import re
 import numpy as np
 import torch
 
-from cchess_zero_amd.net import PolicyValueModule, PolicyValueNet, from_tf_variables, to_tf_variables
+from cchess_zero_amd import tf_checkpoint
+from cchess_zero_amd.net import (PolicyValueModule, PolicyValueNet, from_tf_variables, momentum_slots_from_tf_variables,
+                                 to_tf_variables)
 from cchess_zero_amd.train import Trainer
 
 
@@ -89,20 +91,34 @@ class policy_value_network(object):
         if not os.path.isdir(self.save_dir):
             os.makedirs(self.save_dir, exist_ok=True)
         c = self._ckpts()
+        tf_ckpt = tf_checkpoint.latest_checkpoint(self.save_dir)   # tf.train.get_checkpoint_state(save_dir), :165-168
         if c:
             self.restore(c[-1][1])
             print("Successfully loaded:", c[-1][1])
+        elif tf_ckpt:   # a model directory written by the reference itself (tf.train.Saver: checkpoint + .index + .data)
+            self.restore(tf_ckpt)
+            print("Successfully loaded:", tf_ckpt)
         else:
             print("Could not find old network weights")
 
     def restore(self, file):
-        """A checkpoint written by save(), or an .npz holding the reference's TF1 variables by name (`conv2d/kernel`,
-        `BatchNorm_3/moving_variance`, `fully_connected/weights`, ... — what `tf.train.load_checkpoint(ckpt)` lists for a
-        cchess-zero model; HWIO kernels and [in,out] FC weights are converted by load_tf_layout)."""
+        """A checkpoint written by save(); or the reference's OWN checkpoint — `best_model.ckpt-N` as tf.train.Saver wrote
+        it (V2 tensor bundle: .index + .data-00000-of-00001, read by cchess_zero_amd/tf_checkpoint.py without TensorFlow:
+        weights by their TF1 variable names `conv2d/kernel`, `BatchNorm_3/moving_variance`, `fully_connected/weights`, ...,
+        the Momentum slots and global_step; HWIO kernels and [in,out] FC weights are converted by load_tf_layout); or an
+        .npz holding the same variables by name."""
         print("Restoring from {0}".format(file))
+        variables = None
         if str(file).endswith(".npz"):
-            d, blocks, gs = from_tf_variables(np.load(file), self.module.res_block_nums)
+            variables = np.load(file)
+        elif tf_checkpoint.is_tf_checkpoint(file):
+            variables = tf_checkpoint.read_checkpoint(file)
+        if variables is not None:
+            d, blocks, gs = from_tf_variables(variables, self.module.res_block_nums)
             self.module.load_tf_layout(d)
+            slots = momentum_slots_from_tf_variables(variables, blocks)
+            if slots:
+                self.trainer.load_tf_momentum(slots)
             if gs is not None:
                 self.global_step = gs
         else:

@@ -62,11 +62,14 @@ def test_search_matches_reference_at_depth(mcts_deep_golden):
     assert max(r["max_level"] for res in results for r in res) >= 60
 
 
-@pytest.mark.parametrize("mode", ["pos", "signed"])
-def test_search_vs_oracle_batch(rules_golden, mode):
+@pytest.mark.parametrize("mode,advance", [("pos", "lds"), ("signed", "lds"), ("pos", "global")])
+def test_search_vs_oracle_batch(rules_golden, mode, advance, monkeypatch):
     """256 trees from corpus positions, 3 plies x 48 playouts, device-resident loop; compared with the
-    oracle: needs_eval + planes every step, root stats and whole-tree dumps after each ply."""
+    oracle: needs_eval + planes every step, root stats and whole-tree dumps after each ply.  advance: the in-place
+    compaction of cz_search_advance with the bitmap in LDS (default) or in global memory (pools too large for LDS)."""
     from oracle import oracle as O
+    if advance == "global":
+        monkeypatch.setenv("CCHESS_ADVANCE_GLOBAL", "1")
     g = rules_golden
     ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
     idx = np.nonzero(ok)[0][::11][:256]

@@ -1,0 +1,162 @@
+"""SURVEY §8 row f2 — the reference's own checkpoints (tf.train.Saver, policy_value_network.py:148,164-184) read without
+TensorFlow: cchess_zero_amd/tf_checkpoint.py against bundles written byte by byte from the published format by
+tests/tf_bundle_writer.py (an independent implementation; TensorFlow itself is not installable here), with the reference
+graph's variable names written out literally."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import tf_bundle_writer as W
+from cchess_zero_amd import tf_checkpoint as T
+from oracle import net_numpy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _manual_layout(v, blocks):
+    """TF names -> the keys oracle/net_numpy.py consumes, spelled out here (not through the package's name map):
+    conv2d[_i] / BatchNorm[_i] in creation order = input conv, two per block, policy head, value head;
+    fully_connected, _1, _2 = policy FC, value FC1, value FC2 (policy_value_network.py:45-74)."""
+    d = {}
+    for i in range(1 + 2 * blocks + 2):
+        sfx = "" if i == 0 else "_%d" % i
+        d["conv%d/kernel" % i] = v["conv2d%s/kernel" % sfx]
+        d["conv%d/bias" % i] = v["conv2d%s/bias" % sfx]
+        d["bn%d/moving_mean" % i] = v["BatchNorm%s/moving_mean" % sfx]
+        d["bn%d/moving_variance" % i] = v["BatchNorm%s/moving_variance" % sfx]
+    for ours, tfn in (("policy_fc", "fully_connected"), ("value_fc1", "fully_connected_1"), ("value_fc2", "fully_connected_2")):
+        d[ours + "/weights"] = v[tfn + "/weights"]
+        d[ours + "/biases"] = v[tfn + "/biases"]
+    return d
+
+
+@pytest.mark.parametrize("snappy,block_size,with_crc", [(False, 512, True), (True, 300, True), (False, 1 << 20, False)])
+def test_bundle_reader_roundtrip(tmp_path, snappy, block_size, with_crc):
+    v = W.reference_graph_variables(2, np.random.default_rng(1))
+    v["a_double"] = np.linspace(0, 1, 7)                   # float64
+    v["an_int64_matrix"] = np.arange(12, dtype=np.int64).reshape(3, 4) - 5
+    p = str(tmp_path / "best_model.ckpt-77")
+    W.write_bundle(p, v, block_size=block_size, snappy_blocks=snappy, with_crc=with_crc)
+    got = T.read_checkpoint(p, verify_crc=True)
+    assert sorted(got) == sorted(v)
+    for k in v:
+        assert got[k].dtype == v[k].dtype and got[k].shape == np.shape(v[k]) and np.array_equal(got[k], v[k]), k
+    lv = dict((n, (s, d)) for n, s, d in T.list_variables(p + ".index"))
+    assert lv["conv2d/kernel"] == ((3, 3, 14, 128), np.float32) and lv["global_step"] == ((), np.int32)
+    assert T.is_tf_checkpoint(p) and T.is_tf_checkpoint(p + ".data-00000-of-00001") and not T.is_tf_checkpoint(str(tmp_path / "nope"))
+    # the `checkpoint` state file the Saver keeps (get_checkpoint_state, policy_value_network.py:165)
+    assert T.latest_checkpoint(str(tmp_path)) is None
+    open(tmp_path / "checkpoint", "w").write('model_checkpoint_path: "best_model.ckpt-77"\nall_model_checkpoint_paths: "best_model.ckpt-77"\n')
+    assert T.latest_checkpoint(str(tmp_path)) == p
+
+
+def test_bundle_reader_rejects_damage(tmp_path):
+    v = {"w": np.arange(100, dtype=np.float32), "global_step": np.asarray(3, np.int32)}
+    p = str(tmp_path / "m")
+    W.write_bundle(p, v)
+    idx = bytearray(open(p + ".index", "rb").read())
+    bad = bytearray(idx)
+    bad[-1] ^= 0xFF                                          # table magic
+    open(p + ".index", "wb").write(bytes(bad))
+    with pytest.raises(T.CheckpointError, match="magic"):
+        T.read_checkpoint(p)
+    bad = bytearray(idx)
+    bad[3] ^= 0x01                                           # a byte of the first data block: block checksum
+    open(p + ".index", "wb").write(bytes(bad))
+    with pytest.raises(T.CheckpointError, match="checksum"):
+        T.read_checkpoint(p)
+    open(p + ".index", "wb").write(bytes(idx))
+    dat = bytearray(open(p + ".data-00000-of-00001", "rb").read())
+    dat[17] ^= 0x40                                          # a tensor byte: tensor checksum
+    open(p + ".data-00000-of-00001", "wb").write(bytes(dat))
+    with pytest.raises(T.CheckpointError, match="tensor checksum"):
+        T.read_checkpoint(p)
+    open(p + ".data-00000-of-00001", "wb").write(bytes(dat[:-8]))   # truncated shard
+    with pytest.raises(T.CheckpointError):
+        T.read_checkpoint(p, verify_crc=False)
+    os.remove(p + ".data-00000-of-00001")
+    with pytest.raises(T.CheckpointError, match="missing"):
+        T.read_checkpoint(p)
+
+
+@pytest.mark.parametrize("blocks", [2, 7])
+def test_reference_checkpoint_loads_by_tf1_variable_names(tmp_path, blocks):
+    """A checkpoint carrying the reference graph's TF1 variable names -> PolicyValueModule through from_tf_variables /
+    load_tf_layout: its forward equals the NumPy restatement of the TF graph fed the same arrays through a name table
+    spelled out in THIS file; block count and global_step are recovered; the Momentum slots land in the optimiser so
+    that the next training step continues the checkpoint's trajectory (float64 restatement of MomentumOptimizer)."""
+    import nethelpers as H
+    from cchess_zero_amd.net import PolicyValueModule, from_tf_variables, momentum_slots_from_tf_variables
+    from cchess_zero_amd.train import Trainer
+    v = W.reference_graph_variables(blocks, np.random.default_rng(blocks), with_slots=(blocks == 2))
+    p = str(tmp_path / "best_model.ckpt-4321")
+    W.write_bundle(p, v, block_size=4096)
+    ck = T.read_checkpoint(p)
+    d, nb, gs = from_tf_variables(ck)
+    assert nb == blocks and gs == 4321
+    m = PolicyValueModule(blocks, seed=99)
+    m.load_tf_layout(d)
+    x = H.positions(6, 3)
+    with torch.no_grad():
+        lt, vt = m(torch.from_numpy(x).permute(0, 3, 1, 2))
+    ln, vn = net_numpy.forward(_manual_layout(v, blocks), x, blocks)
+    assert np.abs(lt.numpy() - ln).max() < 2e-4 * max(1.0, np.abs(ln).max()) and np.abs(vt.numpy() - vn).max() < 1e-5
+    if blocks != 2:
+        return
+    # momentum slots: one training step from the checkpoint == the float64 restatement started from the same accumulators
+    from test_train import _batch, _run_restatement
+    slots = momentum_slots_from_tf_variables(ck, nb)
+    assert len(slots) == 2 * (1 + 2 * blocks + 2) + 6
+    tr = Trainer(m)
+    tr.load_tf_momentum(slots)
+    w0 = m.export_tf_layout()
+    batch = _batch(12, 5)
+    manual_slots = _manual_layout({k[:-len("/Momentum")]: a for k, a in v.items() if k.endswith("/Momentum")} |
+                                  {k: a for k, a in v.items() if "BatchNorm" in k}, blocks)
+    ref = _run_restatement(w0, [batch], 0.1, blocks, accum0={k: a for k, a in manual_slots.items() if not k.startswith("bn")})
+    tr.train_step(batch[0], batch[1], batch[2], 0.1)
+    now = m.export_tf_layout()
+    for k, rw in ref[0][2].items():
+        d_got = now[k].astype(np.float64) - w0[k].astype(np.float64)
+        d_ref = rw - np.asarray(w0[k], np.float64)
+        assert np.abs(d_got - d_ref).max() <= 2e-3 * np.abs(d_ref).max() + 5e-7, k
+    # without the slots the step is a different one (the accumulators matter)
+    m2 = PolicyValueModule(blocks, seed=99)
+    m2.load_tf_layout(d)
+    tr2 = Trainer(m2)
+    tr2.train_step(batch[0], batch[1], batch[2], 0.1)
+    assert np.abs(m2.export_tf_layout()["conv1/kernel"] - now["conv1/kernel"]).max() > 1e-5
+
+
+@pytest.mark.gpu
+def test_facade_restores_a_tf_model_directory(tmp_path):
+    """policy_value_network(...) pointed at a directory as the reference's Saver leaves it (checkpoint state file +
+    best_model.ckpt-N.index/.data): train_restore picks the TF checkpoint up, forward() answers with its weights, the
+    step counter continues from its global_step; restore(prefix) does the same explicitly."""
+    import nethelpers as H
+    sys.path.insert(0, ROOT)
+    from policy_value_network import policy_value_network
+    v = W.reference_graph_variables(2, np.random.default_rng(11), global_step=250)
+    mdir = tmp_path / "models"
+    mdir.mkdir()
+    W.write_bundle(str(mdir / "best_model.ckpt-250"), v, block_size=4096)
+    open(mdir / "checkpoint", "w").write('model_checkpoint_path: "best_model.ckpt-250"\n')
+    pv = policy_value_network(2, save_dir=str(mdir), seed=5)
+    assert pv.global_step == 250
+    x = H.positions(16, 4)
+    logits, value = pv.forward(x)
+    ln, vn = net_numpy.forward(_manual_layout(v, 2), x, 2)
+    e = H.errors(logits, value, ln, vn)
+    assert e["dlogit_rel"] <= 2e-3 and e["dvalue"] <= 2e-3, e       # the default fp16 engine on the checkpoint's weights
+    other = tmp_path / "other"
+    pv2 = policy_value_network(2, save_dir=str(other), seed=6)
+    assert pv2.global_step == 0
+    pv2.restore(str(mdir / "best_model.ckpt-250"))
+    l2, v2 = pv2.forward(x)
+    assert pv2.global_step == 250 and np.array_equal(l2, logits) and np.array_equal(v2, value)
+    # the momentum slots are in the optimiser: a step from here changes the weights by lr * (grad + 0.9 * accum) with accum != 0
+    buf = pv2.trainer.opt.state[pv2.module.policy_fc.weight]["momentum_buffer"]
+    assert torch.equal(buf.cpu(), torch.from_numpy(v["fully_connected/weights/Momentum"]).t())

@@ -61,10 +61,10 @@ def _tf_loss64(w, x, pi, z, blocks, c_l2=1e-4):
     return value_loss + policy_loss + l2, trainables
 
 
-def _run_restatement(w0, batches, lr, blocks, momentum=0.9, clip=100.0):
+def _run_restatement(w0, batches, lr, blocks, momentum=0.9, clip=100.0, accum0=None):
     w = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=not k.startswith("bn")) for k, v in w0.items()}
     names = [k for k in w if not k.startswith("bn")]
-    accum = {k: torch.zeros_like(w[k]) for k in names}
+    accum = {k: (torch.zeros_like(w[k]) if accum0 is None else torch.tensor(np.asarray(accum0[k], np.float64))) for k in names}
     out = []
     for (x, pi, z) in batches:
         loss, _ = _tf_loss64(w, torch.tensor(x, dtype=torch.float64), torch.tensor(pi, dtype=torch.float64),
