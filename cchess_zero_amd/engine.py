@@ -323,6 +323,17 @@ class SearchEngine:
             tap(planes, logits, value)
         self.expand_backup(logits, value)
 
+    def _active_bool(self, active):
+        """The active mask as a bool device tensor for the host-side liveness tests of search(): None, a tensor / array,
+        or a raw device pointer (what SelfPlay hands over in parking mode: cz_selfplay_active) — that one is downloaded."""
+        if active is None:
+            return None
+        if isinstance(active, C.c_void_p):
+            buf = np.empty(self.G, np.uint8)
+            check(lib().cz_download(self.ctx.h, buf.ctypes.data_as(C.c_void_p), active, self.G), "cz_download")
+            return torch.from_numpy(buf).to(self.dev).bool()
+        return torch.as_tensor(active).to(self.dev).bool()
+
     def search(self, forward, playouts, active=None):
         """MCTS_tree.main (main.py:473-493) for all trees: expand unexpanded roots, then EXACTLY `playouts` simulations
         per (active, unparked) tree.  With width k > 1 up to k simulations are in flight per tree and step; a descent
@@ -338,6 +349,11 @@ class SearchEngine:
             # terminal simulations complete inside the select launches: a tree needs one lock-step per simulation that
             # needs the net, so the search is over when every tree has counted `playouts` (checked every 32 steps)
             base = self.status()[2]
+            act = self._active_bool(active)   # parked / inactive slots neither decide the schedule nor keep the loop alive
+            if act is not None:
+                if not bool(act.any().item()):
+                    return 0
+                base = base[act]
             if not bool((base == base[0]).all().item()):   # stacked searches on unequal counters: the plain schedule
                 extra = self.terminal_extra
                 self.set_terminal_extra(0)
@@ -348,7 +364,6 @@ class SearchEngine:
                     self.set_terminal_extra(extra)
                 return playouts
             target = int(base[0].item()) + playouts
-            act = None if active is None or isinstance(active, C.c_void_p) else torch.as_tensor(active).to(self.dev).bool()
             steps = 0
             self.set_sim_target(target)
             try:
@@ -380,7 +395,7 @@ class SearchEngine:
                 self.step(forward, mode=1, active=active)
             steps = n
             if uniform:
-                act = None if active is None or isinstance(active, C.c_void_p) else torch.as_tensor(active).to(self.dev).bool()
+                act = self._active_bool(active)
                 for _ in range(4 * n + 8):   # the shortfall of abandoned descents, usually 1-3 steps
                     st, _, sims, _ = self.status()
                     live = (st & ~8) == 0

@@ -186,3 +186,27 @@ def test_ring_overflow_is_reported_not_silently_drained():
         else:
             sp.drain()
     assert sp.stats()["dropped"] > 0
+
+
+def test_parking_mode_search_ends_early_with_terminal_extra():
+    """in parking mode (continuous=False) SelfPlay hands search() the active mask as a raw device pointer; the
+    early exit of a terminal_extra > 0 search must look at it — parked slots never reach the target and used to keep every
+    search running for its full `playouts` lock-steps.  Same games either way, fewer lock-steps."""
+    G, playouts = 48, 40
+
+    def run(extra):
+        net, eng, sp = _setup(G, 8192, playouts, continuous=False, seed=21)
+        eng.set_terminal_extra(extra)
+        steps, plies = 0, 0
+        while bool(sp.active().any()) and plies < 200:
+            steps += eng.search(net.forward_device, playouts, active=sp._active_ptr)
+            sp._transition(0)
+            plies += 1
+        eng.set_terminal_extra(0)
+        return sp.drain(), sp.stats(), steps, plies
+
+    rec0, st0, steps0, plies0 = run(0)
+    rec1, st1, steps1, plies1 = run(4)
+    assert plies0 == plies1 and np.array_equal(rec0, rec1) and st0["games"] == st1["games"] == G
+    print("parking mode, %d games, %d plies: %d lock-steps with terminal_extra 0, %d with 4" % (G, plies0, steps0, steps1))
+    assert steps0 == plies0 * playouts and steps1 < steps0
