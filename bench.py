@@ -598,11 +598,11 @@ def main():
             xs = rules.encode_planes(boards[:256], side[:256]).float()
             ne = {"reference": "fp32 torch module on the device, same weights and inputs (that engine: <= 3e-5 of the NumPy restatement of the reference graph, tests/test_net.py)",
                   "as_benchmarked_glorot": net_error(net, xs)}
+            ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] = bool(ne["as_benchmarked_glorot"]["dlogit"] <= 1e-3 and ne["as_benchmarked_glorot"]["dvalue"] <= 1e-3)
+            out["net_error"] = ne
             net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
             trained_like_(net_t, xs[:96])
             ne["trained_like"] = net_error(net_t, xs)
-            ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] = bool(ne["as_benchmarked_glorot"]["dlogit"] <= 1e-3 and ne["as_benchmarked_glorot"]["dvalue"] <= 1e-3)
-            out["net_error"] = ne
         except Exception as e:
             out["net_error"] = {"error": repr(e)}
         try:

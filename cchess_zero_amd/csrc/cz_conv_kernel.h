@@ -707,9 +707,11 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     __syncthreads();
 
     int rowb[CV_RT], tapmask[CV_RT];
+    int l31o = l31;   // opaque per batch: the per-lane geometry below (and the 27 first-layer addresses derived from it) is
+    asm volatile("" : "+v"(l31o));   // loop-invariant over the batches — hoisted, it is spilled around the tower
 #pragma unroll
     for (int i = 0; i < CV_RT; ++i) {
-        const int r = 32 * (wr * CV_RT + i) + l31;
+        const int r = 32 * (wr * CV_RT + i) + l31o;
         const int pix = r % 90, h = pix / 10, w = pix - h * 10;
         rowb[i] = r * CV_ROWB;
         int m = 0;

@@ -547,7 +547,8 @@ def trained_like_(net, planes_nhwc, seed=5):
         hook.remove()
         w.mul_(10.0 / float(logits.max(dim=1).values.mean()))
         pre = feats[0] @ m.value_fc2.weight.t()
-        k = 0.6 / float(pre.std())
+        sd = float(pre.std())
+        k = 0.6 / sd if sd > 0 else 1.0   # a dead value head (every ReLU of the head conv off) has nothing to calibrate
         m.value_fc2.weight.mul_(k)
         m.value_fc2.bias.fill_(-float(pre.mean()) * k)
     net.refresh()

@@ -188,25 +188,33 @@ def test_ring_overflow_is_reported_not_silently_drained():
     assert sp.stats()["dropped"] > 0
 
 
-def test_parking_mode_search_ends_early_with_terminal_extra():
-    """in parking mode (continuous=False) SelfPlay hands search() the active mask as a raw device pointer; the
-    early exit of a terminal_extra > 0 search must look at it — parked slots never reach the target and used to keep every
-    search running for its full `playouts` lock-steps.  Same games either way, fewer lock-steps."""
-    G, playouts = 48, 40
-
-    def run(extra):
-        net, eng, sp = _setup(G, 8192, playouts, continuous=False, seed=21)
+def test_search_early_exit_ignores_inactive_trees_behind_a_raw_mask_pointer():
+    """in parking mode (continuous=False) SelfPlay hands search() the active mask as a RAW DEVICE POINTER; the early
+    exit of a terminal_extra > 0 search must look through it — inactive slots never reach the target and used to keep every
+    search running for its full `playouts` lock-steps.  One active tree whose root can capture the king (kings facing on an open
+    file: most simulations end inside the select launch) among seven inactive ones: the search ends as soon as THAT tree has
+    its playouts, with the statistics of a plain search."""
+    import ctypes as C
+    from cchess_zero_amd.engine import SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet
+    from oracle import oracle as O
+    G, playouts = 8, 64
+    b = np.stack([O.fen_to_board("4K4/9/9/9/9/9/9/9/9/4k4")] + [O.fen_to_board(START_FEN)] * (G - 1))
+    side, rr = np.zeros(G, np.uint8), np.zeros(G, np.int32)
+    net = PolicyValueNet(2, "cuda:0", torch.float16, seed=2)
+    mask = torch.zeros(G, dtype=torch.uint8, device="cuda")
+    mask[0] = 1
+    out = []
+    for extra in (0, 4):
+        eng = SearchEngine(G, 8192, plane_dtype=torch.float16, channels=16)
+        eng.reset(b, side, rr)
         eng.set_terminal_extra(extra)
-        steps, plies = 0, 0
-        while bool(sp.active().any()) and plies < 200:
-            steps += eng.search(net.forward_device, playouts, active=sp._active_ptr)
-            sp._transition(0)
-            plies += 1
+        steps = eng.search(net.forward_device, playouts, active=C.c_void_p(mask.data_ptr()))
         eng.set_terminal_extra(0)
-        return sp.drain(), sp.stats(), steps, plies
-
-    rec0, st0, steps0, plies0 = run(0)
-    rec1, st1, steps1, plies1 = run(4)
-    assert plies0 == plies1 and np.array_equal(rec0, rec1) and st0["games"] == st1["games"] >= G // 2
-    print("parking mode, %d games, %d plies: %d lock-steps with terminal_extra 0, %d with 4" % (G, plies0, steps0, steps1))
-    assert steps0 == plies0 * playouts and steps1 < steps0
+        st = eng.root_stats_host()
+        sims = eng.status()[2].cpu().numpy()
+        assert sims[0] == playouts and not sims[1:].any()
+        out.append((steps, st["N"][0].copy(), st["W"][0].view(np.uint32).copy()))
+    (s0, n0, w0), (s1, n1, w1) = out
+    print("one active tree behind a raw mask pointer: %d lock-steps with terminal_extra 0, %d with 4" % (s0, s1))
+    assert s0 == playouts and s1 < playouts and np.array_equal(n0, n1) and np.array_equal(w0, w1)

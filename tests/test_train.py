@@ -87,14 +87,19 @@ def test_train_step_matches_float64_restatement(blocks, lr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blocks,lr", [(2, 0.2), (7, 0.1)])
-def test_train_step_on_device_matches_float64_restatement(blocks, lr):
+@pytest.mark.parametrize("blocks,lr,upd_tol", [(2, 0.2, 2e-3), (7, 0.1, 6e-2)])
+def test_train_step_on_device_matches_float64_restatement(blocks, lr, upd_tol):
     """The same check where the product trains: the module on cuda:0, forward AND backward through ROCm (MIOpen convolutions,
-    fp32), 2 and 7 residual blocks, against the float64 restatement of the TF graph + MomentumOptimizer computed on the host."""
-    _check_train_step(blocks, lr, "cuda:0")
+    fp32), 2 and 7 residual blocks, against the float64 restatement of the TF graph + MomentumOptimizer computed on the host.
+    Loss and gradient norm are held to 2e-5 / 2e-4 at both depths.  Per-tensor weight updates: 2e-3 of the largest update at 2
+    blocks; at 7 blocks MIOpen runs the 3x3 convolutions as fp32 Winograd F(2x3) (miopenSp3AsmConv_v30_3_1_gfx9_fp32_f2x3 in the
+    kernel trace), whose transform rounding, carried through 15 batch-statistic BatchNorms forward and backward, leaves 2e-2 of
+    the largest update on the FIRST conv's kernel after the second step (measured; every other tensor an order below): the
+    tolerance is 3x that — a wrong sign, slot or scale is an O(1) error."""
+    _check_train_step(blocks, lr, "cuda:0", upd_tol)
 
 
-def _check_train_step(blocks, lr, device):
+def _check_train_step(blocks, lr, device, upd_tol=2e-3):
     from cchess_zero_amd.net import PolicyValueModule
     from cchess_zero_amd.train import Trainer
     m = PolicyValueModule(blocks, seed=4)
@@ -123,7 +128,7 @@ def _check_train_step(blocks, lr, device):
             scale = np.abs(d_ref).max()
             # conv biases in front of a batch-statistic BatchNorm have an analytically ZERO data gradient (the mean is
             # subtracted again): in fp32 what remains is cancellation noise, hence the small absolute term
-            assert np.abs(d_got - d_ref).max() <= 2e-3 * scale + 5e-6 * lr, (step, k, np.abs(d_got - d_ref).max(), scale)
+            assert np.abs(d_got - d_ref).max() <= upd_tol * scale + 5e-6 * lr, (step, k, np.abs(d_got - d_ref).max(), scale)
         prev = now
     # the moving statistics are never touched (quirk Q5: the reference never runs the update ops)
     for k, v in m.export_tf_layout().items():
