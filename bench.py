@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
                     help="MFMA operand type of the tower (fp32 accumulate).  fp16 (default): the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output)")
     ap.add_argument("--age-steps", type=int, default=800, help="untimed lock-steps BEFORE --warmup that bring every tree to a representative phase of its search: each tree's first search is cut at its own threshold (uniform in [8, age-steps] simulations), so when the timed region starts the trees are spread over the phases of a playout-long search on subtrees kept from a previous ply — the state of a long run — instead of all standing 25 simulations into a fresh search")
-    ap.add_argument("--steady-steps", type=int, default=800, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
+    ap.add_argument("--steady-steps", type=int, default=2000, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
@@ -506,7 +506,7 @@ def main():
         steady_out = {"steps": args.steady_steps, "seconds": steady[0], "value": s_sims / steady[0], "unit": "sims/s",
                       "ms_per_step": steady[0] / args.steady_steps * 1e3, "net_rows_per_s": s_rows / steady[0],
                       "simulations_per_net_row": s_sims / max(1.0, s_rows), "per_rank_sims_per_s": s_pr,
-                      "note": "a second barrier-bracketed timed region run right after the K contract steps, long enough (>= 2 s) for the driver's 5 s smi sampler to see the GPU busy; same loop, same counters"}
+                      "note": "a second barrier-bracketed timed region run right after the K contract steps, together with the ageing and the K steps more than 7 s of contiguous GPU work, so that a 5 s smi sampler sees the GPU busy; same loop, same counters"}
     flops = flops_per_position(args.blocks) * rows_per_launch
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     if conv_ev:
@@ -615,6 +615,7 @@ def main():
     if rank == 0:
         # the CPU baseline runs after every rank has left the timed regions and the process group (N > 1: the other ranks
         # have exited or are exiting; a shorter sample keeps the multi-GPU line quick)
+        PL.unpin_cpus()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.blocks, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 5.0))
         else:

@@ -157,14 +157,31 @@ def pin_rank_to_cpus(local_rank, local_world, max_per_rank=8):
     threads over all visible CPUs and throttles them together.  Returns the CPU list, or None when affinity cannot be
     set.  The CPUs of a rank are contiguous: rank r gets allowed[r * k : (r + 1) * k], k = min(max_per_rank,
     allowed // local_world)."""
+    global _affinity_before_pin
     try:
         allowed = sorted(os.sched_getaffinity(0))
         k = max(1, min(int(max_per_rank), len(allowed) // max(1, int(local_world))))
         mine = allowed[int(local_rank) * k:(int(local_rank) + 1) * k] or allowed
         os.sched_setaffinity(0, mine)
+        _affinity_before_pin = allowed
         return mine
     except Exception:
         return None
+
+
+_affinity_before_pin = None
+
+
+def unpin_cpus():
+    """Back to the CPU set the process had before pin_rank_to_cpus (bench.py's CPU baseline runs on all of the box's cores
+    after the ranks are done)."""
+    global _affinity_before_pin
+    if _affinity_before_pin:
+        try:
+            os.sched_setaffinity(0, _affinity_before_pin)
+        except Exception:
+            pass
+        _affinity_before_pin = None
 
 
 def gather_records(rec, device=None, group=None):
