@@ -35,7 +35,8 @@ def main():
     print("raw:", {k: "%.4g" % v for k, v in {**a, **b}.items()})
     if len(sys.argv) > 5:   # machine-readable copy for profiles/
         import json
-        out = {"kernel": "k_tower8_c128 (tools/ubench/tower_base %d positions, %d blocks, random bf16 data)" % (B, nb),
+        label = sys.argv[6] if len(sys.argv) > 6 else "tools/ubench/tower_base %d positions, %d blocks, random bf16 data" % (B, nb)
+        out = {"kernel": "k_tower8_c128 (%s)" % label,
                "method": "rocprofv3 --kernel-trace --pmc, two separate passes (tools/pmc_ubench.sh): a = GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SALU "
                          "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES; b = SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM "
                          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles",
