@@ -25,6 +25,7 @@ _u8p, _u16p, _i32p, _f32p, _vp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
 _SIGS = {
     "cz_last_error": (C.c_char_p, []),
     "cz_version": (C.c_int, []),
+    "cz_crc32c": (C.c_uint, [C.c_char_p, C.c_size_t]),
     "cz_tables": (C.c_int, [C.POINTER(C.c_void_p)] * 4),
     "cz_zobrist": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "cz_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -55,6 +55,33 @@ void carve_trees(Carver &c, CzTrees &t, size_t G, size_t words) {
 extern "C" {
 
 const char *cz_last_error(void) { return g_err; }
+
+// CRC-32C (Castagnoli, reflected 0x82F63B78), host code: the checksum of TensorFlow's checkpoint blocks and tensors
+// (cchess_zero_amd/tf_checkpoint.py reads and writes the reference's tf.train.Saver files; pure Python does ~5 MB/s)
+unsigned int cz_crc32c(const void *data, size_t n) {
+    static unsigned int T[8][256];
+    static bool init = false;
+    if (!init) {
+        for (unsigned int i = 0; i < 256; ++i) {
+            unsigned int c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (unsigned int i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) T[s][i] = (T[s - 1][i] >> 8) ^ T[0][T[s - 1][i] & 0xFFu];
+        init = true;
+    }
+    const unsigned char *p = (const unsigned char *)data;
+    unsigned int c = 0xFFFFFFFFu;
+    while (n >= 8) {   // slicing-by-8
+        const unsigned int lo = c ^ ((unsigned int)p[0] | ((unsigned int)p[1] << 8) | ((unsigned int)p[2] << 16) | ((unsigned int)p[3] << 24));
+        c = T[7][lo & 0xFFu] ^ T[6][(lo >> 8) & 0xFFu] ^ T[5][(lo >> 16) & 0xFFu] ^ T[4][lo >> 24] ^
+            T[3][p[4]] ^ T[2][p[5]] ^ T[1][p[6]] ^ T[0][p[7]];
+        p += 8; n -= 8;
+    }
+    while (n--) c = T[0][(c ^ *p++) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
 int cz_version(void) { return 200; }
 
 int cz_tables(const int16_t **lut, const int16_t **unflip, const char **labels, const uint16_t **srcdst) {

@@ -1,4 +1,4 @@
-"""Reader for TensorFlow checkpoints in the V2 ("tensor bundle") format, pure Python + NumPy — no TensorFlow needed.
+"""Reader and writer for TensorFlow checkpoints in the V2 ("tensor bundle") format, pure Python + NumPy — no TensorFlow needed.
 
 The reference saves and restores its weights with tf.train.Saver (policy_value_network.py:148,164-184): files
 `<save_dir>/best_model.ckpt-<step>.index` + `.data-00000-of-00001` and a `checkpoint` state file.  TF >= 0.12 writes
@@ -52,6 +52,15 @@ def _crc_table():
 
 
 def crc32c(data, crc=0):
+    if crc == 0 and len(data) >= 4096:   # long buffers: the library's host-side helper (plain C, ~1 GB/s) when it is there
+        try:
+            import ctypes
+            from . import _lib
+            fn = _lib.lib().cz_crc32c
+            b = bytes(data)
+            return int(fn(ctypes.c_char_p(b), ctypes.c_size_t(len(b)))) & 0xFFFFFFFF
+        except Exception:
+            pass
     t = _crc_table()
     c = crc ^ 0xFFFFFFFF
     for b in bytes(data):
@@ -281,10 +290,11 @@ def list_variables(path):
     return [(k, e["shape"], _DTYPES.get(e["dtype"])) for k, e in sorted(entries.items())]
 
 
-def read_checkpoint(path, verify_crc="small"):
+def read_checkpoint(path, verify_crc=True):
     """-> {variable name: ndarray} of a V2 checkpoint (what tf.train.load_checkpoint(path).get_tensor(name) returns for
-    every name).  verify_crc: True / False / "small" (tensor checksums only up to 1 MB — the pure-Python crc32c does
-    ~5 MB/s; block checksums of the index are always verified)."""
+    every name).  verify_crc: True / False / "small" (tensor checksums only up to 1 MB); block checksums of the index are always
+    verified.  crc32c runs in the HIP library's host helper (cz_crc32c, ~1 GB/s) when the library is built, else in pure
+    Python (~5 MB/s)."""
     prefix = _prefix_of(path)
     header, entries = read_index(prefix + ".index")
     shards = {}
@@ -311,6 +321,105 @@ def read_checkpoint(path, verify_crc="small"):
                 raise CheckpointError("%s: tensor checksum mismatch" % name)
         out[name] = np.frombuffer(raw.tobytes(), dtype=np.dtype(dt).newbyteorder("<")).astype(dt).reshape(e["shape"])
     return out
+
+
+# ---- writer: the weights back in the reference's own format -----------------------------------------------------------------
+_DTYPE_ENUM = {np.dtype(v): k for k, v in _DTYPES.items()}
+
+
+def _vi(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | 0x80 if n else b)
+        if not n:
+            return bytes(out)
+
+
+def _pb_varint(field, v):
+    return _vi(field << 3) + _vi(v if v >= 0 else v + (1 << 64))
+
+
+def _pb_bytes(field, b):
+    return _vi((field << 3) | 2) + _vi(len(b)) + b
+
+
+class _BlockBuilder:
+    """tensorflow/core/lib/io/block_builder.cc: prefix-compressed entries, a restart point every `interval` entries."""
+
+    def __init__(self, interval=16):
+        self.buf, self.restarts, self.n, self.last, self.interval = bytearray(), [0], 0, b"", interval
+
+    def add(self, key, value):
+        shared = 0
+        if self.n % self.interval == 0:
+            if self.n:
+                self.restarts.append(len(self.buf))
+        else:
+            m = min(len(key), len(self.last))
+            while shared < m and key[shared] == self.last[shared]:
+                shared += 1
+        self.buf += _vi(shared) + _vi(len(key) - shared) + _vi(len(value)) + key[shared:] + value
+        self.last, self.n = key, self.n + 1
+
+    def finish(self):
+        return bytes(self.buf) + b"".join(struct.pack("<I", r) for r in self.restarts) + struct.pack("<I", len(self.restarts))
+
+
+def write_checkpoint(prefix, tensors, block_size=4096):
+    """{variable name: ndarray} -> `prefix.index` + `prefix.data-00000-of-00001`, a V2 checkpoint tf.train.Saver.restore /
+    tf.train.load_checkpoint read (one shard, uncompressed blocks, masked crc32c on every block and tensor) — the way back
+    for weights trained here into the reference's own graph (policy_value_network.py:176-184).  Names are written as given:
+    pass net.to_tf_variables(module) for the reference graph's names."""
+    names = sorted(tensors)
+    data = bytearray()
+    header = _pb_varint(1, 1) + _pb_bytes(3, _pb_varint(1, 1))          # num_shards = 1, version { producer: 1 }
+    items = [(b"", header)]
+    for n in names:
+        a = np.asarray(tensors[n], order="C")
+        if a.dtype not in _DTYPE_ENUM:
+            raise CheckpointError("%s: dtype %s cannot be written" % (n, a.dtype))
+        raw = a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes()
+        e = _pb_varint(1, _DTYPE_ENUM[a.dtype]) + _pb_bytes(2, b"".join(_pb_bytes(2, _pb_varint(1, int(d))) for d in a.shape))
+        if len(data):
+            e += _pb_varint(4, len(data))
+        e += _pb_varint(5, len(raw)) + _vi((6 << 3) | 5) + struct.pack("<I", masked_crc32c(raw))
+        items.append((n.encode("utf-8"), e))
+        data += raw
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+    out = bytearray()
+
+    def emit(block):
+        off = len(out)
+        out.extend(block)
+        out.append(0)                                                      # kNoCompression
+        out.extend(struct.pack("<I", masked_crc32c(block + b"\0")))
+        return off, len(block)
+
+    index, blk = _BlockBuilder(interval=1), _BlockBuilder()
+    for key, value in items:
+        blk.add(key, value)
+        if len(blk.buf) >= block_size:
+            off, size = emit(blk.finish())
+            index.add(blk.last, _vi(off) + _vi(size))
+            blk = _BlockBuilder()
+    if blk.n:
+        off, size = emit(blk.finish())
+        index.add(blk.last, _vi(off) + _vi(size))
+    moff, msize = emit(_BlockBuilder().finish())
+    ioff, isize = emit(index.finish())
+    footer = _vi(moff) + _vi(msize) + _vi(ioff) + _vi(isize)
+    out.extend(footer + b"\0" * (40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC))
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+
+
+def write_checkpoint_state(save_dir, prefix_name):
+    """The `checkpoint` state file tf.train.Saver keeps beside its checkpoints (get_checkpoint_state, :165)."""
+    with open(os.path.join(save_dir, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (prefix_name, prefix_name))
 
 
 def latest_checkpoint(save_dir):

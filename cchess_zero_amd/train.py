@@ -107,6 +107,24 @@ class Trainer:
                 raise ValueError("momentum slot of shape %s for a parameter of shape %s" % (tuple(buf.shape), tuple(p.shape)))
             self.opt.state[p]["momentum_buffer"] = buf.contiguous().to(p.device, p.dtype).clone()
 
+    def tf_momentum_slots(self):
+        """The inverse of load_tf_momentum: this optimiser's momentum buffers in the reference's TF layout, keyed like
+        export_tf_layout() (zeros for parameters that have not been stepped yet — a fresh MomentumOptimizer slot)."""
+        m = self.module
+        out = {}
+
+        def buf(p):
+            st = self.opt.state.get(p, {})
+            b = st.get("momentum_buffer")
+            return (b if b is not None else torch.zeros_like(p)).detach().float().cpu()
+        for i, cb in enumerate(m.convbns()):
+            out["conv%d/kernel" % i] = buf(cb.conv.weight).permute(2, 3, 1, 0).contiguous().numpy().copy()
+            out["conv%d/bias" % i] = buf(cb.conv.bias).numpy().copy()
+        for name, fc in (("policy_fc", m.policy_fc), ("value_fc1", m.value_fc1), ("value_fc2", m.value_fc2)):
+            out[name + "/weights"] = buf(fc.weight).t().contiguous().numpy().copy()
+            out[name + "/biases"] = buf(fc.bias).numpy().copy()
+        return out
+
     def state_dict(self):
         """Model, momentum buffers (tf.train.Saver persists the Momentum slot variables) and the step."""
         return {"model": self.module.state_dict(), "optimizer": self.opt.state_dict(), "global_step": int(self.global_step)}

@@ -85,6 +85,9 @@ extern "C" {
 typedef struct cz_ctx cz_ctx;
 
 const char *cz_last_error(void);
+/* host utility: CRC-32C (Castagnoli) of a host buffer — the checksum of the reference's tf.train.Saver checkpoint files
+ * (policy_value_network.py:148,176-184), read and written by cchess_zero_amd/tf_checkpoint.py */
+unsigned int cz_crc32c(const void *data, size_t n);
 int cz_version(void);
 
 /* ---- static tables (host pointers, valid for the process lifetime) --------------------------

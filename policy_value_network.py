@@ -143,6 +143,26 @@ class policy_value_network(object):
                 pass
         return path
 
+    def export_tf_checkpoint(self, in_global_step=None, save_dir=None):
+        """The way back: weights, Momentum slots and global_step written as the reference's own tf.train.Saver would
+        (`<save_dir>/best_model.ckpt-N.index` + `.data-00000-of-00001` + the `checkpoint` state file,
+        policy_value_network.py:176-184), under the reference graph's TF1 variable names — the reference's restore() /
+        train_restore() load it into its TF graph.  Returns the checkpoint prefix."""
+        step = int(self.global_step if in_global_step is None else in_global_step)
+        d = to_tf_variables(self.module, None)
+        d["global_step"] = np.asarray(step, np.int32)
+        tf_names = {k: v for k, v in __import__("cchess_zero_amd.net", fromlist=["tf_variable_names"]).tf_variable_names(self.module.res_block_nums).items()}
+        slots = self.trainer.tf_momentum_slots()
+        for tf_name, ours in tf_names.items():
+            if ours in slots:
+                d[tf_name + "/Momentum"] = slots[ours]
+        out_dir = save_dir or self.save_dir
+        os.makedirs(out_dir, exist_ok=True)
+        name = "best_model.ckpt-%d" % step
+        tf_checkpoint.write_checkpoint(os.path.join(out_dir, name), d)
+        tf_checkpoint.write_checkpoint_state(out_dir, name)
+        return os.path.join(out_dir, name)
+
     def export_tf_variables(self, file=None):
         """The weights under the reference graph's TF1 variable names (optionally written as .npz)."""
         d = to_tf_variables(self.module, self.global_step)

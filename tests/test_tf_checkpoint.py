@@ -160,3 +160,54 @@ def test_facade_restores_a_tf_model_directory(tmp_path):
     # the momentum slots are in the optimiser: a step from here changes the weights by lr * (grad + 0.9 * accum) with accum != 0
     buf = pv2.trainer.opt.state[pv2.module.policy_fc.weight]["momentum_buffer"]
     assert torch.equal(buf.cpu(), torch.from_numpy(v["fully_connected/weights/Momentum"]).t())
+    # and the way back: export_tf_checkpoint writes what the reference's Saver would — every variable, slot and the step
+    # come back bit for bit through the reader, under the same names
+    out_dir = tmp_path / "exported"
+    prefix = pv2.export_tf_checkpoint(save_dir=str(out_dir))
+    assert prefix.endswith("best_model.ckpt-250") and T.latest_checkpoint(str(out_dir)) == prefix
+    back = T.read_checkpoint(prefix)
+    assert sorted(back) == sorted(v)
+    for k in v:
+        assert back[k].dtype == v[k].dtype and np.array_equal(back[k], v[k]), k
+
+
+def test_product_writer_equals_the_independent_writer_byte_for_byte(tmp_path):
+    """cchess_zero_amd.tf_checkpoint.write_checkpoint (the way back into the reference's TF graph) against the test-side
+    writer: two implementations of the same published format must produce the SAME bytes for the same tensors and block size,
+    and the native crc32c helper of the library (cz_crc32c, slicing-by-8) must agree with both pure-Python tables."""
+    v = W.reference_graph_variables(2, np.random.default_rng(8))
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    T.write_checkpoint(a, v, block_size=512)
+    W.write_bundle(b, v, block_size=512)
+    for suffix in (".index", ".data-00000-of-00001"):
+        assert open(a + suffix, "rb").read() == open(b + suffix, "rb").read(), suffix
+    got = T.read_checkpoint(a, verify_crc=True)
+    assert all(np.array_equal(got[k], v[k]) for k in v)
+    blob = np.random.default_rng(1).integers(0, 256, 100003, dtype=np.uint8).tobytes()
+    assert T.crc32c(blob) == W._crc32c(blob)                 # native (len >= 4096) vs the test-side table
+    assert T.crc32c(blob[:1000]) == W._crc32c(blob[:1000])   # pure Python in the package vs the test-side table
+    assert T.crc32c(b"123456789") == 0xE3069283              # the CRC-32C check value
+
+
+def test_trainer_momentum_slots_round_trip():
+    """Trainer.tf_momentum_slots <-> load_tf_momentum: what export_tf_checkpoint writes as `<variable>/Momentum` is what a
+    restore reads back, layouts included; untouched parameters export zero slots like a fresh MomentumOptimizer."""
+    import nethelpers as H
+    from cchess_zero_amd.net import PolicyValueModule
+    from cchess_zero_amd.train import Trainer
+    from test_train import _batch
+    m = PolicyValueModule(1, seed=2)
+    tr = Trainer(m)
+    z = tr.tf_momentum_slots()
+    assert z["conv1/kernel"].shape == (3, 3, 128, 128) and z["policy_fc/weights"].shape == (180, 2086) and not any(a.any() for a in z.values())
+    x, pi, zz = _batch(8, 2)
+    tr.train_step(x, pi, zz, 0.05)
+    s1 = tr.tf_momentum_slots()
+    assert any(a.any() for a in s1.values())
+    m2 = PolicyValueModule(1, seed=2)
+    tr2 = Trainer(m2)
+    tr2.load_tf_momentum(s1)
+    s2 = tr2.tf_momentum_slots()
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+    for p, q in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(tr.opt.state[p]["momentum_buffer"], tr2.opt.state[q]["momentum_buffer"])
