@@ -171,6 +171,7 @@ class SelfPlay:
         self.plies = 0
         self.lock_steps = 0
         self._dropped_seen = 0
+        self.overflow_intervals = 0
 
     # -- one ply of every game ------------------------------------------------------------------------
     def step_ply(self, forward=None, forced=None):
@@ -258,21 +259,32 @@ class SelfPlay:
         check(lib().cz_download(self.eng.ctx.h, buf.ctypes.data_as(C.c_void_p), self._active_ptr, self.eng.G), "cz_download")
         return torch.from_numpy(buf)
 
-    def drain_device(self):
+    def drain_device(self, on_overflow="raise"):
         """-> uint8 [n, REC_BYTES] DEVICE tensor with the records finished since the last drain (synchronises on the
-        cursor and the drop counter).  The returned rows stay valid until the ring wraps over them.  Raises if finished
-        games have been DROPPED since the last drain because the ring was full of undrained rows (cz_selfplay_flush skips
-        such a game but the cursor still advances by its length: the rows returned here would contain stale slots) —
-        drain more often or pass a larger ring_records."""
+        cursor and the drop counter).  The returned rows stay valid until the ring wraps over them.
+        If finished games have been DROPPED since the last drain because the ring was full of undrained rows
+        (cz_selfplay_flush skips such a game but the cursor still advances by its length, so the interval contains slots
+        that were never written), the whole interval is discarded — never handed out — and, with on_overflow = "raise"
+        (default), a RuntimeError says so; on_overflow = "skip" counts it in self.overflow_intervals and returns no rows
+        (a long training run prefers losing one interval of samples to stopping).  Drain more often or pass a larger
+        ring_records to avoid it."""
         self.eng.ctx.bind_stream()
         check(lib().cz_selfplay_stats(self.eng.ctx.h, C.c_void_p(self._stats.data_ptr())), "cz_selfplay_stats")
         dropped = int(self._stats[SP_STATS.index("dropped")].item())
+        c = int(self.cursor.item())
         if dropped > self._dropped_seen:
             n_new = dropped - self._dropped_seen
             self._dropped_seen = dropped
-            raise RuntimeError("self-play record ring overflow: %d records of finished games were dropped since the last drain "
-                               "(ring of %d records; drain more often or raise ring_records)" % (n_new, self.ring.shape[0]))
-        c = int(self.cursor.item())
+            self._read = c
+            self.read_cursor.fill_(c)
+            self.overflow_intervals += 1
+            msg = ("self-play record ring overflow: %d records of finished games were dropped since the last drain "
+                   "(ring of %d records; drain more often or raise ring_records); the interval's records are discarded"
+                   % (n_new, self.ring.shape[0]))
+            if on_overflow == "raise":
+                raise RuntimeError(msg)
+            print("WARNING:", msg)
+            return self.ring[:0]
         r, R = self._read, self.ring.shape[0]
         n = min(c - r, R)
         if n <= 0:

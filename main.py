@@ -511,7 +511,9 @@ class cchess_main(object):
                           seed=base_seed + 7919 * rank, continuous=True,
                           # the evaluation cache pays from a few hundred playouts per move on (in-tree repeat rate 1 % at 100
                           # playouts, 4 % at 400, 12 % at 1600; the lookup costs the select launch 10-25 us)
-                          eval_cache=self.playout_counts >= 400)
+                          eval_cache=self.playout_counts >= 400,
+                          # a drain interval can end every game of every slot in the worst case: room for ~160 plies per slot
+                          ring_records=max(65536, 160 * G))
             b0 = np.tile(state_to_board(START_STATE), (G, 1))
             sp.start(b0, np.zeros(G, np.uint8), np.zeros(G, np.int32))
             self._sp, self._batch_eng = sp, eng
@@ -530,7 +532,7 @@ class cchess_main(object):
             n = 8 if max_plies is None else max(1, min(8, max_plies - plies))
             sp.run_async(n * steps_per_ply, every=every, terminal_extra=4)
             plies += n
-            chunks.append(sp.drain_device().clone())     # raises if the ring overflowed (records would be missing)
+            chunks.append(sp.drain_device(on_overflow="skip").clone())   # an overflowed interval is dropped with a warning, never handed out
             st = sp.stats()
             if st["games"] - before["games"] >= target or (max_plies is not None and plies >= max_plies):
                 break
