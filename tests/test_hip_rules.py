@@ -17,7 +17,11 @@ def _u16(t):
     return t.cpu().numpy().view(np.uint16)
 
 
-def test_movegen_golden(rules, rules_golden):
+@pytest.mark.parametrize("kernel", ["wave", "lane"])
+def test_movegen_golden(rules, rules_golden, kernel, monkeypatch):
+    """Ordered move lists, counts and 2086-bit masks of 4 381 reference positions; `kernel`: four positions per wave
+    (k_movegen, small batches) or one position per lane (k_movegen_tp, the default from 4 096 positions on)."""
+    monkeypatch.setenv("CCHESS_MOVEGEN", kernel)
     g = rules_golden
     moves, count, mask = rules.movegen(g["boards"], g["side"])
     moves, count, mask = _u16(moves), _u16(count), mask.cpu().numpy().view(np.uint32)
@@ -66,10 +70,12 @@ def test_planes_golden(rules, rules_golden):
     assert torch.equal(ph[..., :14].float().cpu(), torch.from_numpy(p32)) and float(ph[..., 14:].abs().sum()) == 0.0
 
 
-def test_rules_vs_oracle_large_corpus(rules):
+@pytest.mark.parametrize("kernel", ["wave", "lane"])
+def test_rules_vs_oracle_large_corpus(rules, kernel, monkeypatch):
     """Seeded random playouts driven entirely on the GPU (movegen -> pick -> apply), every position
     cross-checked against the C oracle: ordered moves, next board, hash, planes."""
     from oracle import oracle as O
+    monkeypatch.setenv("CCHESS_MOVEGEN", kernel)
     rng = np.random.default_rng(1234)
     G = 2048
     boards = torch.from_numpy(np.tile(O.fen_to_board(O.START_FEN), (G, 1))).cuda()
@@ -109,3 +115,34 @@ def test_rules_edge_sizes(rules):
     b = O.fen_to_board(O.START_FEN)[None]
     m, c, k = rules.movegen(b, np.zeros(1, np.uint8))
     assert int(_u16(c)[0]) == 44
+
+
+@pytest.mark.parametrize("G", [1, 63, 64, 65, 130, 4097])
+def test_movegen_lane_kernel_ragged_sizes_and_alignment(rules, rules_golden, G, monkeypatch):
+    """k_movegen_tp on batch sizes around its 64-position groups, with the boards at an even and at an ODD byte address
+    (the ABI promises byte alignment only: the odd case takes the byte-load path), list and mask or list only — against
+    the golden lists; rows beyond the batch are not touched."""
+    from cchess_zero_amd._lib import check, lib
+    from cchess_zero_amd.engine import _ptr
+    monkeypatch.setenv("CCHESS_MOVEGEN", "lane")
+    g = rules_golden
+    idx = (np.arange(G) * 37) % len(g["boards"])
+    for off in (0, 1):
+        raw = torch.zeros(G * 90 + 2, dtype=torch.uint8, device="cuda")
+        raw[off:off + G * 90] = torch.from_numpy(g["boards"][idx].reshape(-1)).cuda()
+        boards = raw[off:off + G * 90]
+        side = torch.from_numpy(g["side"][idx]).cuda()
+        moves = torch.full((G + 2, 128), 0x1234, dtype=torch.int16, device="cuda")
+        count = torch.full((G + 2,), 0x1234, dtype=torch.int16, device="cuda")
+        mask = torch.full((G + 2, 66), 0x55, dtype=torch.int32, device="cuda")
+        for want_mask in (True, False):
+            check(lib().cz_movegen(rules.ctx.h, _ptr(boards), _ptr(side), G, _ptr(moves), _ptr(count), _ptr(mask) if want_mask else None), "cz_movegen")
+            mv, ct = _u16(moves), _u16(count)
+            assert np.array_equal(ct[:G], g["counts"][idx]) and np.array_equal(mv[:G], g["moves"][idx])
+            assert (mv[G:] == 0x1234).all() and (ct[G:] == 0x1234).all()
+        mk = mask.cpu().numpy().view(np.uint32)
+        exp = np.zeros((G, 66), np.uint32)
+        for i in range(G):
+            for l in g["moves"][idx[i], :g["counts"][idx[i]]]:
+                exp[i, l >> 5] |= np.uint32(1) << np.uint32(l & 31)
+        assert np.array_equal(mk[:G], exp) and (mk[G:] == 0x55).all()
