@@ -21,26 +21,6 @@ extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, 
 
 static constexpr int kDefaultVariant = 1;
 
-// Grid of the 8-wave trunk kernel: ONE PERSISTENT workgroup per CU looping over the batches of 4 positions (a workgroup
-// owns its CU: 154 KB of LDS, every VGPR, so there is nothing to gain from more); CCHESS_TOWER_PERSIST=0 launches one
-// workgroup per batch instead (round 1-2 behaviour).  Measured, interleaved on one box: 2 272 -> 2 258 us per launch in the
-// tower ubench (+0.6 %), 2 291 -> 2 282 us in the bench (+0.4 %): the CU no longer retires a workgroup, re-allocates its LDS
-// and dispatches eight fresh waves 7 times per launch — ~1.3 us each, most of which the power governor takes back.
-static int t8_grid(cz_ctx *c, int B) {
-    using namespace czconv;
-    const int batches = (B + T8_P - 1) / T8_P;
-    static const int persist = [] { const char *e = getenv("CCHESS_TOWER_PERSIST"); return e ? atoi(e) : 1; }();
-    if (persist <= 0) return batches;
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t p;
-        if (hipGetDeviceProperties(&p, c->device) == hipSuccess) cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    const int g = cus * persist;
-    return batches < g ? batches : g;
-}
-
 static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
                         const float *head_b, float *head_out, int B, int nblocks, const void *planes = nullptr,
                         const void *w0 = nullptr, const float *b0 = nullptr, bool f16 = false) {
@@ -78,7 +58,7 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
                                (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                                (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
     } else if (f16) {   // fp16 operands: the 8-wave kernel (or 2x above)
-        const int grid = t8_grid(c, B);
+        const int grid = (B + T8_P - 1) / T8_P;
         hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
@@ -88,7 +68,7 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks);
     } else if (variant == 1) {
-        const int grid = t8_grid(c, B);
+        const int grid = (B + T8_P - 1) / T8_P;
         hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);

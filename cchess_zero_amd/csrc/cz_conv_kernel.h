@@ -642,18 +642,12 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, khalf = lane >> 5;
+    const int pos0 = blockIdx.x * P;
     if (bcount) {   // compact batches: only the first *bcount rows are live this step (whole workgroups beyond them leave)
         const int live = *bcount;
         B = live < B ? live : B;
     }
-    // Grid-stride over the batches of P positions: launched with one workgroup per batch the loop runs once; launched
-    // PERSISTENT (one workgroup per CU, cz_conv.hip) a workgroup goes on to its next batch without the CU having to retire
-    // it, allocate 154 KB of LDS and dispatch eight fresh waves (measured: see DESIGN.md 4.2).
-#pragma unroll 1
-    for (int pos0 = blockIdx.x * P; pos0 < B; pos0 += gridDim.x * P) {
-    // opaque copies of the parameter pointers: everything loaded through them is loop-invariant over the batches, and hoisted
-    // out of this loop it would stay live through the whole tower (the kernel sits at its 256-register budget)
-    asm volatile("" : "+s"(wpk), "+s"(bias), "+s"(head_w), "+s"(head_b), "+s"(w0), "+s"(b0));
+    if (pos0 >= B) return;
     const int npos = (B - pos0) < P ? (B - pos0) : P;
     const int nrows = npos * 90;
     const int nslabs = nlayers * Geo::SLABS_PER_LAYER;
@@ -694,24 +688,19 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     // first-layer weights: requested before the wait below so that their latency overlaps the planes / ring prologue
     bf16x8 wf[9][CV_CT];
     if (planes != nullptr) {
-        // (opaque copy of the pointer: in the batch loop these loads are loop-invariant, and hoisted out of it their 72
-        // registers would stay live through the whole tower — the kernel would spill)
-        const uint16_t *w0l = w0;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < CV_CT; ++j)
-                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0l + ((size_t)((t * 2 + (lane >> 5)) * 128 + (wave & 1) * 64 + j * 32 + (lane & 31)) << 3));
+                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + (lane >> 5)) * 128 + (wave & 1) * 64 + j * 32 + (lane & 31)) << 3));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int rowb[CV_RT], tapmask[CV_RT];
-    int l31o = l31;   // opaque per batch: the per-lane geometry below (and the 27 first-layer addresses derived from it) is
-    asm volatile("" : "+v"(l31o));   // loop-invariant over the batches — hoisted, it is spilled around the tower
 #pragma unroll
     for (int i = 0; i < CV_RT; ++i) {
-        const int r = 32 * (wr * CV_RT + i) + l31o;
+        const int r = 32 * (wr * CV_RT + i) + l31;
         const int pix = r % 90, h = pix / 10, w = pix - h * 10;
         rowb[i] = r * CV_ROWB;
         int m = 0;
@@ -934,8 +923,6 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             o[2] = fmaxf(acc2 + head_b[2], 0.f);
         }
     }
-    __syncthreads();   // the next batch's prologue overwrites U, the zero row and the weight ring
-    }   // batches
 }
 #undef T8_SLAB
 #undef T8_SLAB_ARGS

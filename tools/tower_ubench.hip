@@ -12,7 +12,6 @@ int main(int argc, char **argv) {
     const int iters = argc > 3 ? atoi(argv[3]) : 10;
     const int variant = argc > 4 ? atoi(argv[4]) : 8;   // 4 = 2 positions / 4 waves, 8 = 4 positions / 8 waves, 1 = 4 positions, one per wave, 2 = two workgroups of 2 positions per CU
     const int zero = argc > 5 ? atoi(argv[5]) : 0;      // 1 = all-zero activations and weights (power experiment)
-    const int persist = argc > 6 ? atoi(argv[6]) : 0;   // variant 8 only: n persistent workgroups per CU looping over the batches (0: one workgroup per batch)
     const size_t n = (size_t)B * 90 * 128, nw = (size_t)2 * nblocks * 9 * 128 * 128;
     uint16_t *in, *out, *w; float *bias;
     CK(hipMalloc(&in, n * 2)); CK(hipMalloc(&out, n * 2)); CK(hipMalloc(&w, nw * 2)); CK(hipMalloc(&bias, 2 * nblocks * 128 * 4));
@@ -29,11 +28,7 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerp_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
-    int grid = (variant == 4 || variant == 2) ? (B + TW_P - 1) / TW_P : (B + T8_P - 1) / T8_P;
-    if (persist > 0 && variant == 8) {
-        hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
-        if (prop.multiProcessorCount * persist < grid) grid = prop.multiProcessorCount * persist;
-    }
+    const int grid = (variant == 4 || variant == 2) ? (B + TW_P - 1) / TW_P : (B + T8_P - 1) / T8_P;
 #define LAUNCH() do { if (variant == 4) hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); \
                       else if (variant == 2) hipLaunchKernelGGL((k_tower8_c128<false, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks, (const int *)nullptr); \
                       else if (variant == 1) hipLaunchKernelGGL(k_towerp_c128, dim3(grid), dim3(TP_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); \
@@ -46,7 +41,6 @@ int main(int argc, char **argv) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * nblocks * 2.0 * B * 90 * 1152 * 128 / (us * 1e-6) / 1e12;
-    printf("grid %d  ", grid);
     printf("tower variant=%dw B=%d blocks=%d : %9.1f us/launch (%7.1f us/layer) %7.1f TF/s\n", variant, B, nblocks, us, us / (2 * nblocks), tf);
     return 0;
 }
