@@ -350,8 +350,14 @@ def main():
     steps_since_reset = [0]
     graph = [None]   # the steady-state step (4 launches, static arguments) captured as one HIP graph
 
+    trace = [] if os.environ.get("BENCH_TRACE_STEPS") else None   # debugging: one HIP event per timed step -> stderr
+
     def run(nsteps, timed):
         for i in range(nsteps):
+            if trace is not None and timed and len(trace) < 64:
+                e_ = torch.cuda.Event(enable_timing=True)
+                e_.record()
+                trace.append(e_)
             # every 8th timed step runs eagerly so that HIP events can bracket the launches on their stream
             if graph[0] is not None and not (timed and step_no[0] % 8 == 0):
                 step_no[0] += 1
@@ -419,6 +425,22 @@ def main():
             graph[0] = None
             torch.cuda.synchronize()
     count_sims = (lambda: sp.stats()["sims"]) if sp else (lambda: int(banked.item()) + int(eng.status()[2].sum().item()))
+    # the first HIP events of a process cost a millisecond of lazy initialisation: create, record and read a few here, untimed,
+    # so that the first sampled step of a short timed region (the driver's --steps 20) does not pay for it
+    _warm = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    for e_ in _warm:
+        e_.record()
+    torch.cuda.synchronize()
+    _warm[0].elapsed_time(_warm[-1])
+    # ... and the first use of a torch op loads its code object (tens of ms): the counters read at the edges of the timed
+    # region are read once here, then a few untimed steps bring the clocks back up — an idle GPU needs ~6 steps to ramp
+    # (measured per step after a 50 ms gap: 2.63 2.86 2.71 2.58 2.48 2.43 ms against 2.34), which a 20-step region would
+    # otherwise carry as a 3 % deficit
+    count_sims()
+    if sp:
+        run_plies(8, False)
+    else:
+        run(8, False)
 
     def timed_region(nsteps):
         """barrier + synchronize, EXACTLY nsteps lock-steps, synchronize + barrier: -> (max-over-ranks seconds, this rank's
@@ -449,6 +471,9 @@ def main():
         return dtm, mine, count_sims() - sims0, rows, rpl
 
     dt, my_dt, my_sims, my_rows, rows_per_launch = timed_region(args.steps)
+    if trace:
+        print("per-step GPU ms of the timed region:", " ".join("%.3f" % trace[i].elapsed_time(trace[i + 1]) for i in range(len(trace) - 1)), file=sys.stderr)
+        trace = None
     steady = None
     if args.steady_steps > 0:
         steady = timed_region(args.steady_steps)
