@@ -437,6 +437,9 @@ def main():
     # (measured per step after a 50 ms gap: 2.63 2.86 2.71 2.58 2.48 2.43 ms against 2.34), which a 20-step region would
     # otherwise carry as a 3 % deficit
     count_sims()
+    if dist_on:   # the first barrier / all-reduce of a process group sets the communicator up (hundreds of ms over RCCL)
+        dist.barrier()
+        PL.max_over_ranks(0.0, cdev)
     if sp:
         run_plies(8, False)
     else:
