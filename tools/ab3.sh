@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Record of a round-3 experiment: the grid-stride / persistent trunk kernel it compares lives in git history, commits 3f397c6 ..
+# the commit that reverted it; on the current tree CCHESS_TOWER_PERSIST has no effect.)
 # Runs ON THE GPU BOX: interleaved A/B/C of the trunk launch shapes through the bench (4 rounds):
 #   r02   = the round-2 trunk kernel (first-layer weights prefetched into registers, one workgroup per batch)   [tools/ab/lib_r02_trunk.so]
 #   grid  = this round's kernel (first-layer weights staged in LDS), one workgroup per batch                      [CCHESS_TOWER_PERSIST=0]
