@@ -349,6 +349,10 @@ SELFPLAY_CASES = [
     dict(name="sp_pos12", playout=12, mode="pos", salt=303, seed=13),
     # GameBoard.reload patched to start at restrict_round 59: the 60-ply no-capture tie (main.py:1542-1545) is reached
     dict(name="sp_tie", playout=10, mode="pos", salt=404, seed=14, rr0=59),
+    # a game at a few hundred playouts per move: visit counts in the hundreds, re-rooted subtrees that already hold most
+    # of the next search's visits (the root starts each search with N well above 0), deeper trees carried across plies
+    dict(name="sp_pos200", playout=200, mode="pos", salt=505, seed=15),
+    dict(name="sp_signed160", playout=160, mode="signed", salt=606, seed=16),
 ]
 
 
