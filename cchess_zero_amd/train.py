@@ -13,6 +13,8 @@ collectives of different ranks stop matching: the mini-batch is drawn with a gen
 ranks hold the same gathered buffer), each rank trains on its slice of it, gradients are averaged, and the KL that drives
 the early stop and the learning-rate adaptation is all-reduced before it is looked at.
 """
+import contextlib
+import os
 import random
 import time
 
@@ -28,11 +30,33 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+@contextlib.contextmanager
+def deterministic_convolutions(on=True):
+    """Restrict MIOpen to its deterministic convolution kernels for the calls made inside (torch hands the flag to MIOpen as
+    MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC at every convolution call, forward and backward).  Measured on MI355X, round 3
+    (tools/train_step_time.py, tools/train_algo_probe.sh, tests/test_train.py): left to itself MIOpen runs this net's 3x3
+    layers as fp32 implicit-GEMM kernels whose weight-gradient variant reduces split-K partial sums with atomics
+    (igemm_wrw_gtcx35_nhwc_fp32_*_gkgs) — 15 ms per 7-block step at batch 512, results that differ in the last bits from run
+    to run; restricted, it falls back to its naive kernels with float64 accumulation (naive_conv_ab_nonpacked_*_float_double_
+    float): bit-identical from run to run and the closest to the float64 restatement, but 1.2 s per step.  Hence opt-in
+    (Trainer(deterministic=True) or CCHESS_TRAIN_DETERMINISTIC=1): for debugging and for the parity test, not for training."""
+    if not on:
+        yield
+        return
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        yield
+    finally:
+        torch.backends.cudnn.deterministic = prev
+
+
 class Trainer:
     """One optimiser over a PolicyValueModule.  Not tied to a device: tensors follow the module's parameters."""
 
-    def __init__(self, module, c_l2=0.0001, momentum=0.9, global_norm=100.0):
+    def __init__(self, module, c_l2=0.0001, momentum=0.9, global_norm=100.0, deterministic=None):
         self.module = module
+        self.deterministic = (os.environ.get("CCHESS_TRAIN_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
         self.c_l2, self.momentum, self.global_norm = float(c_l2), float(momentum), float(global_norm)
         self.opt = torch.optim.SGD(module.parameters(), lr=0.0, momentum=self.momentum, nesterov=True)
         self.global_step = 0
@@ -67,8 +91,9 @@ class Trainer:
             g["lr"] = float(learning_rate)
         self.module.train()
         self.opt.zero_grad(set_to_none=True)
-        loss, accuracy = self.loss(positions, probs, winners, training=True)
-        loss.backward()
+        with deterministic_convolutions(self.deterministic):
+            loss, accuracy = self.loss(positions, probs, winners, training=True)
+            loss.backward()
         allreduce_gradients(self.module)                                       # no-op without a process group
         grads = [p.grad for p in self.module.parameters() if p.grad is not None]
         # tf.clip_by_global_norm: t * clip_norm / max(global_norm, clip_norm)
