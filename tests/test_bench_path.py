@@ -185,8 +185,9 @@ def test_fused_step_configs2_full_length_1600_playouts_vs_oracle():
 # predicted 0.94 / 0.064 for bf16.  With a peaked, trained-like net PUCT amplifies the 0.9 % logit noise of a 15-layer
 # bf16 tower (0.1 % for fp16) into a different most-visited move for a few trees in a hundred — a property of 16-bit
 # inference, not of the kernels, whose arithmetic the two tests above pin exactly.  The thresholds sit just below the
-# measured levels: a numerically worse kernel fails.
-_AGREE = {"bf16": (torch.bfloat16, 0.93, 0.10), "fp16": (torch.float16, 0.98, 0.025)}
+# measured levels (10-15 trees of 1024: the fp32 side runs MIOpen's convolutions, whose choice of kernel — and with it the
+# last bits of the fp32 logits — is not the same on every box): a numerically worse kernel fails.
+_AGREE = {"bf16": (torch.bfloat16, 0.93, 0.10), "fp16": (torch.float16, 0.975, 0.025)}
 
 
 @pytest.mark.parametrize("dname", ["bf16", "fp16"])
