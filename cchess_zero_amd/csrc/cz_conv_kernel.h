@@ -624,6 +624,21 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// Measurement only (tools/tower_ubench.hip built with -DCZ_T8_TRACE=1|2; never defined in the library): lane 0 of every wave
+// writes the shader clock at fixed points of every layer — 0 layer top, 1 operands of the first k-step requested, 2 main loop
+// drained (in front of the "all reads of U done" barrier), 3 epilogue stored and published; with CZ_T8_TRACE=2 also 4..12 after
+// each tap (this waits for the scalar unit inside the software-pipelined loop: perturbs it, read as an upper bound).
+#if defined(CZ_T8_TRACE)
+__device__ unsigned long long *cz_t8_trace_buf;   // [workgroup][wave][layer][16]
+#define CZ_T8_STAMP(K)                                                                                               \
+    do {                                                                                                             \
+        const unsigned long long ts_ = __builtin_readcyclecounter();                                                 \
+        if (lane == 0) cz_t8_trace_buf[(((size_t)blockIdx.x * (P * 2) + wave_u) * nlayers + layer) * 16 + (K)] = ts_; \
+    } while (0)
+#else
+#define CZ_T8_STAMP(K)
+#endif
+
 template <bool F16, int P>
 __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__restrict__ in,
                                                                const uint16_t *__restrict__ wpk,
@@ -844,6 +859,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
         f32x16 acc[CV_RT][CV_CT];
+        CZ_T8_STAMP(0);
         refresh_rb();
         if (!(layer & 1)) {   // first conv of a block: remember x, start from the bias
 #pragma unroll
@@ -863,6 +879,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT);
             TW_LOADSET(0, 0, 512, f0, ab, key, vb);   // waited for by the first k-step itself
         }
+        CZ_T8_STAMP(1);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             if constexpr (P == 4) {        // two 16 KB slabs per tap
@@ -878,14 +895,22 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             }
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+#if defined(CZ_T8_TRACE) && CZ_T8_TRACE >= 2
+            CZ_T8_STAMP(4 + tap);
+#endif
         }
         // the last k-step prefetched garbage for a non-existent next slab; drain it, let the MFMAs retire, and make
         // sure every wave is done reading U before anyone overwrites it in place
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        CZ_T8_STAMP(2);
         __syncthreads();
+#if defined(CZ_T8_TRACE)
+        CZ_T8_STAMP(13);   // through the barrier: 13 - 2 = this wave's wait for the slowest wave of the workgroup
+#endif
         refresh_rb();
         store_layer(acc);
         __syncthreads();
+        CZ_T8_STAMP(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (out) {
