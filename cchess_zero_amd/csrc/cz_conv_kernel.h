@@ -954,6 +954,327 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
 #undef T8_RUN
 
 // =================================================================================================
+// k_towersk_c128 ("sk", opt-in: CCHESS_TOWER_VARIANT=sk): k_tower8_c128 with its two half-workgroups a fixed number of slabs
+// apart.  tools/tower_trace.hip: 13.4 % of a layer of k_tower8_c128 is the layer boundary (epilogue, accumulator
+// initialisation: ~540 VALU instructions per wave) with the MFMA pipe idle, because the weight ring's per-slab barrier keeps
+// all eight waves in lock-step and both waves of a SIMD reach the boundary together.  Here
+//   * waves 0-3 (half A) own positions 0-1 (rows 0..179), waves 4-7 (half B) positions 2-3 (rows 180..359): six 32-row
+//     tiles per half, the last 12 lanes of each half dead — a tap never leaves its position, so the halves share no row;
+//   * each SIMD hosts one wave of each half; B runs the same program SKEW = 4 barriers behind A (it starts with four bare
+//     barriers, A ends with four), so A's layer boundary falls under B's slabs 32..35 and B's under A's slabs 1..4;
+//   * the ring is 8 slots of 8 KB (32 input channels of a tap, one barrier per slab): a slab stays until B has read it,
+//     SKEW + 4 slots; only A's waves feed it (two 1 KB pieces per wave and slab), B finds its slabs published by the
+//     barriers it shares with A;
+//   * the layer-boundary barriers are the same s_barrier (every wave must execute the same number): three per layer and
+//     half — reads of U done | first two tile rows stored | all stored and visible.
+// Arithmetic per output element is that of k_tower8_c128 (same taps, same k order, same rounding): bit-identical outputs.
+// =================================================================================================
+struct SkGeo {
+    static constexpr int P = 4, ROWS = 360, THREADS = 512, HALF_ROWS = 180, SKEW = 4, NBUF = 8;
+    static constexpr int SLAB_BYTES = 32 * 128 * 2, SLAB_SHIFT = 13, SLABS_PER_LAYER = 36;
+    static constexpr int ZERO_OFF = ROWS * CV_ROWB;
+    static constexpr int W_OFF = ZERO_OFF + CV_ROWB;
+    static constexpr int LDS_BYTES = W_OFF + NBUF * SLAB_BYTES;   // 157,952
+    static constexpr int PLANES_OFF = W_OFF + 3 * SLAB_BYTES;     // 11.5 KB over ring slots 3-4 (first written by the DMA of slabs 3, 4: issued in slabs 0, 1)
+    static constexpr int HEADW_OFF = LDS_BYTES;
+    static constexpr int LDS_TOTAL = LDS_BYTES + 3 * 128 * 4;
+};
+constexpr int SK_P = 4, SK_THREADS = SkGeo::THREADS, SK_LDS_BYTES = SkGeo::LDS_TOTAL;
+
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void k_towersk_c128(const uint16_t *__restrict__ in,
+                                                         const uint16_t *__restrict__ wpk,
+                                                         const float *__restrict__ bias,
+                                                         uint16_t *__restrict__ out,
+                                                         const float *__restrict__ head_w,
+                                                         const float *__restrict__ head_b,
+                                                         float *__restrict__ head_out,
+                                                         const uint16_t *__restrict__ planes,
+                                                         const uint16_t *__restrict__ w0,
+                                                         const float *__restrict__ b0,
+                                                         int B, int nlayers,
+                                                         const int *__restrict__ bcount) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Geo = SkGeo;
+    constexpr int P = Geo::P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int pos0 = blockIdx.x * P;
+    if (bcount) {
+        const int live = *bcount;
+        B = live < B ? live : B;
+    }
+    if (pos0 >= B) return;
+    const int npos = (B - pos0) < P ? (B - pos0) : P;
+    const int nrows = npos * 90;
+    const int nslabs = nlayers * Geo::SLABS_PER_LAYER;
+    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int isa = __builtin_amdgcn_readfirstlane(wave_u < 4 ? 1 : 0);   // half A feeds the ring and runs ahead (an SGPR: the slab asm branches on it)
+    const unsigned voff0 = ((unsigned)tid & 255u) << 4, voff1 = voff0 + 4096u;   // A's lane offsets inside an 8 KB slab
+    // row r of the [360][128] activation matrix owned by lane l31 of this wave's tile i; dead past the half's 180 rows
+    auto row_of = [&](int i, bool &live) {
+        const int lr = 32 * ((wr & 1) * CV_RT + i) + l31;
+        live = lr < Geo::HALF_ROWS;
+        return (wr >> 1) * Geo::HALF_ROWS + lr;
+    };
+
+    auto dma_slab = [&](int slab) {   // prologue only (half A); the loop issues its DMAs from the slab asm
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * Geo::SLAB_BYTES;
+        unsigned char *dst = smem + Geo::W_OFF + ((unsigned)slab & 7u) * Geo::SLAB_BYTES + ((wave_u & 3) << 10);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff0),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff1),
+                                         (__attribute__((address_space(3))) void *)(dst + 4096), 16, 0, 0);
+    };
+    if (isa)
+        for (int q = 0; q < 3; ++q) dma_slab(q < nslabs ? q : nslabs - 1);
+    if (planes == nullptr) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < Geo::ROWS * 16; idx += Geo::THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < nrows) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
+        }
+    } else {
+        const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
+        for (int idx = tid; idx < Geo::ROWS * 2; idx += Geo::THREADS) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < nrows * 2) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + Geo::PLANES_OFF + (idx << 4)) = v;
+        }
+    }
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + Geo::ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    if (head_out && tid < 3 * 128 / 4)
+        reinterpret_cast<float4 *>(smem + Geo::HEADW_OFF)[tid] = reinterpret_cast<const float4 *>(head_w)[tid];
+    bf16x8 wf[9][CV_CT];
+    if (planes != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + (lane >> 5)) * 128 + (wave & 1) * 64 + j * 32 + (lane & 31)) << 3));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int rowb[CV_RT], tapmask[CV_RT];
+#pragma unroll
+    for (int i = 0; i < CV_RT; ++i) {
+        bool live;
+        const int r = row_of(i, live);
+        const int pix = r % 90, h = pix / 10, w = pix - h * 10;
+        rowb[i] = r * CV_ROWB;
+        int m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
+            if (live && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+        }
+        tapmask[i] = m;
+    }
+    auto tap_addr = [&](int tap, int (&ab)[CV_RT], int (&key)[CV_RT]) {
+        const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : Geo::ZERO_OFF;
+            ab[i] = a;
+            key[i] = (((rowb[i] + delta) >> 8) & 15) ^ khalf;   // see k_tower8_c128
+        }
+    };
+    const int vb0 = Geo::W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);
+    int keep;
+
+    int rb[CV_RT];
+    auto refresh_rb = [&]() {
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            bool live;
+            const int r = row_of(i, live);
+            rb[i] = (live ? r : 0) * CV_ROWB;
+            asm volatile("" : "+v"(rb[i]));
+        }
+    };
+    auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
+        row_of(i, live);
+        const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
+        return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
+    };
+    uint2 xreg[CV_RT][CV_CT][4];
+    auto init_acc = [&](f32x16 (&acc)[CV_RT][CV_CT], const float *bl, bool add_x) {
+#pragma unroll
+        for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4 *>(bl + wc * 64 + j * 32 + 8 * q + 4 * khalf);
+#pragma unroll
+                for (int i = 0; i < CV_RT; ++i) {
+                    float a0 = bq.x, a1 = bq.y, a2 = bq.z, a3 = bq.w;
+                    if (add_x) {
+                        const uint2 x = xreg[i][j][q];
+                        const f32x2 xl = unpack_pair<F16>(x.x), xh = unpack_pair<F16>(x.y);
+                        a0 += xl[0]; a1 += xl[1]; a2 += xh[0]; a3 += xh[1];
+                    }
+                    acc[i][j][4 * q + 0] = a0; acc[i][j][4 * q + 1] = a1; acc[i][j][4 * q + 2] = a2; acc[i][j][4 * q + 3] = a3;
+                }
+            }
+    };
+    auto store_rows = [&](f32x16 (&acc)[CV_RT][CV_CT], int i) {   // ReLU -> 16 bit -> U in place, tile row i (see k_tower8_c128)
+#pragma unroll
+        for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool live;
+                uint2 *cell = cell_ptr(i, j, q, live);
+                const s16x2 z = {0, 0};
+                const s16x2 rl = __builtin_elementwise_max(
+                    __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]})), z);
+                const s16x2 rh = __builtin_elementwise_max(
+                    __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]})), z);
+                if (live) *cell = make_uint2(__builtin_bit_cast(uint32_t, rl), __builtin_bit_cast(uint32_t, rh));
+            }
+    };
+    // the one barrier of this kernel: every wave executes the same number of them, wherever it is in its program
+    auto tick = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    if (planes != nullptr) {   // first layer: conv3x3(14 -> 128) + BN + ReLU, one k-step per tap; both halves together
+        f32x16 acc[CV_RT][CV_CT];
+        init_acc(acc, b0, false);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
+            bf16x8 af[CV_RT];
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) {
+                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : Geo::ZERO_OFF;
+                af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CV_CT; ++j)
+                    acc[i][j] = mfma_32x32x16<F16>(wf[t][j], af[i], acc[i][j]);
+        }
+        refresh_rb();
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) store_rows(acc, i);
+        __syncthreads();
+    }
+
+#define SK_SLAB(ASMSTR, NAB, NKEY)                                                                               \
+        asm volatile(ASMSTR                                                                                      \
+            : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),          \
+              [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),                                                        \
+              [f0a0] "+v"(f0.a[0]), [f0a1] "+v"(f0.a[1]), [f0a2] "+v"(f0.a[2]), [f0b0] "+v"(f0.b[0]), [f0b1] "+v"(f0.b[1]), \
+              [f1a0] "=&v"(f1.a[0]), [f1a1] "=&v"(f1.a[1]), [f1a2] "=&v"(f1.a[2]), [f1b0] "=&v"(f1.b[0]), [f1b1] "=&v"(f1.b[1]), \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [keep] "=&s"(keep)                                     \
+            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),          \
+              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
+              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
+              [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst), [wv] "s"(wave_u)                              \
+            : "memory", "scc")
+#define SK_RUN(BF, HF, NAB, NKEY)                                                                               \
+        {                                                                                                       \
+            const int vb = vb0 + (((unsigned)g & 7u) << Geo::SLAB_SHIFT), vbn = vb0 + ((((unsigned)g + 1u) & 7u) << Geo::SLAB_SHIFT); \
+            const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                 \
+            const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * Geo::SLAB_BYTES; \
+            const int ldst = Geo::W_OFF + ((((unsigned)g + 3u) & 7u) << Geo::SLAB_SHIFT) + ((wave_u & 3) << 10); \
+            if constexpr (F16) { SK_SLAB(HF, NAB, NKEY); } else { SK_SLAB(BF, NAB, NKEY); }                     \
+            ++g;                                                                                                \
+        }
+
+    int g = 0;
+    if (!isa)
+        for (int s = 0; s < Geo::SKEW; ++s) tick();   // half B starts SKEW barriers late
+#pragma unroll 1
+    for (int layer = 0; layer < nlayers; ++layer) {
+        f32x16 acc[CV_RT][CV_CT];
+        CZ_T8_STAMP(0);
+        refresh_rb();
+        if (!(layer & 1)) {   // first conv of a block: remember x, start from the bias
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { bool live; xreg[i][j][q] = *cell_ptr(i, j, q, live); }
+            init_acc(acc, bias + layer * 128, false);
+        } else {
+            init_acc(acc, bias + layer * 128, true);
+        }
+        int ab[CV_RT], key[CV_RT], nab[CV_RT], nkey[CV_RT], t0, t1, t2;
+        TwFrag f0, f1;
+        tap_addr(0, ab, key);
+        {
+            const int vb = vb0 + (((unsigned)g & 7u) << Geo::SLAB_SHIFT);
+            TW_LOADSET(0, 0, 512, f0, ab, key, vb);   // waited for by the first k-step itself
+        }
+        CZ_T8_STAMP(1);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            SK_RUN(TWS_SLAB_ASM_Q0, TWSF_SLAB_ASM_Q0, ab, key)
+            SK_RUN(TWS_SLAB_ASM_Q1, TWSF_SLAB_ASM_Q1, ab, key)
+            SK_RUN(TWS_SLAB_ASM_Q2, TWSF_SLAB_ASM_Q2, ab, key)
+            tap_addr(tap + 1, nab, nkey);
+            SK_RUN(TWS_SLAB_ASM_Q3, TWSF_SLAB_ASM_Q3, nab, nkey)
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+        }
+        // drain the garbage prefetch of a non-existent next slab, let the MFMAs retire
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        CZ_T8_STAMP(2);
+        tick();               // every wave of this half is done reading U (the other half never touches these rows)
+#if defined(CZ_T8_TRACE)
+        CZ_T8_STAMP(13);
+#endif
+        refresh_rb();
+        store_rows(acc, 0);
+        store_rows(acc, 1);
+        tick();
+        store_rows(acc, 2);
+        tick();               // (waits for lgkmcnt(0) first) this half's new U is complete and visible
+        CZ_T8_STAMP(3);
+    }
+    if (isa)
+        for (int s = 0; s < Geo::SKEW; ++s) tick();   // half A waits for B's last SKEW barriers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (out) {
+        uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < nrows * 16; idx += Geo::THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(r * CV_ROWB, c));
+        }
+    }
+    if (head_out) {   // as in k_tower8_c128: one thread per board cell, all three head channels, fixed summation order
+        const float *hw = reinterpret_cast<const float *>(smem + Geo::HEADW_OFF);
+        for (int r = tid; r < nrows; r += Geo::THREADS) {
+            const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c) {
+                const int p = c ^ key;
+                const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
+                const f32x2 e0 = unpack_pair<F16>(v.x), e1 = unpack_pair<F16>(v.y), e2 = unpack_pair<F16>(v.z), e3 = unpack_pair<F16>(v.w);
+                const float *w0 = hw + c * 8, *w1 = hw + 128 + c * 8, *w2 = hw + 256 + c * 8;
+                acc0 += e0[0] * w0[0] + e0[1] * w0[1] + e1[0] * w0[2] + e1[1] * w0[3]
+                      + e2[0] * w0[4] + e2[1] * w0[5] + e3[0] * w0[6] + e3[1] * w0[7];
+                acc1 += e0[0] * w1[0] + e0[1] * w1[1] + e1[0] * w1[2] + e1[1] * w1[3]
+                      + e2[0] * w1[4] + e2[1] * w1[5] + e3[0] * w1[6] + e3[1] * w1[7];
+                acc2 += e0[0] * w2[0] + e0[1] * w2[1] + e1[0] * w2[2] + e1[1] * w2[3]
+                      + e2[0] * w2[4] + e2[1] * w2[5] + e3[0] * w2[6] + e3[1] * w2[7];
+            }
+            float *o = head_out + ((size_t)pos0 * 90 + r) * 3;
+            o[0] = fmaxf(acc0 + head_b[0], 0.f);
+            o[1] = fmaxf(acc1 + head_b[1], 0.f);
+            o[2] = fmaxf(acc2 + head_b[2], 0.f);
+        }
+    }
+}
+#undef SK_SLAB
+#undef SK_RUN
+
+// =================================================================================================
 // k_towerp_c128: the one-launch net trunk with ONE POSITION PER WAVE (four waves, four positions per workgroup).
 //
 // k_tower8_c128 is co-limited by LDS bandwidth: with 3 cell tiles x 2 channel tiles per wave every 6 MFMAs need

@@ -15,4 +15,8 @@ for blocks, n in ((1, 1), (2, 3), (3, 37), (7, 130)):
     gen = torch.Generator().manual_seed(blocks * 1000 + n)
     x = (torch.rand((n, 9, 10, 14), generator=gen) < 0.1).float().cuda()
     res["%d_%d" % (blocks, n)] = net._hip_net_forward(x).cpu()
+net = PolicyValueNet(7, "cuda:0", torch.float16, seed=6, backend="hip")   # the default engine's operand type
+gen = torch.Generator().manual_seed(7130)
+x = (torch.rand((130, 9, 10, 14), generator=gen) < 0.1).float().cuda()
+res["f16_7_130"] = net._hip_net_forward(x).cpu()
 torch.save(res, out)

@@ -115,6 +115,25 @@ def slabQ(hs):
     return L
 
 
+def slabSK(hs):
+    """Skewed half-workgroup variant (k_towersk_c128): 4 positions / 8 waves, 8 KB slabs in an 8-slot ring.  Waves 0-3 (half A,
+    positions 0-1) run SKEW slabs ahead of waves 4-7 (half B, positions 2-3) on the same slab sequence, so that one half's
+    layer boundary (VALU) falls under the other half's MFMAs.  Only half A feeds the ring (its four waves move the whole 8 KB
+    slab, two 1 KB pieces each, like the 2-position variant); half B skips the DMA with a scalar branch on its wave index %[wv] and finds its
+    slabs published by the barriers it shares with A."""
+    nab, nkey = ("nab", "nkey") if hs == 3 else ("ab", "key")
+    L = ["s_mov_b32 %[keep], m0"]
+    L += kstep2("f0", "f1", hs * 4 + 2, 4096, 4608, "ab", "key", "vb")
+    L += ["s_waitcnt vmcnt(2)", "s_barrier"]
+    dma = [["s_cmp_gt_u32 %[wv], 3", "s_cbranch_scc1 1f", "s_mov_b32 m0, %[ldst]", "s_nop 0",
+            "global_load_lds_dwordx4 %[voff0], %[sbase]", "1:"], [],
+           ["s_cmp_gt_u32 %[wv], 3", "s_cbranch_scc1 2f", "s_add_u32 m0, %[ldst], 0x1000", "s_nop 0",
+            "global_load_lds_dwordx4 %[voff1], %[sbase]", "2:"], [], [], []]
+    L += kstep2("f1", "f0", ((hs + 1) % 4) * 4, 0, 512, nab, nkey, "vbn", dma)
+    L += ["s_mov_b32 m0, %[keep]"]
+    return L
+
+
 ACCP = [["p%d%d" % (i, j) for j in range(4)] for i in range(3)]
 
 
@@ -192,6 +211,9 @@ def main():
     txt += "\n// two-workgroups-per-CU variant (2 positions / 4 waves, 8 KB slabs), bf16 and fp16\n"
     for hs in range(4):
         txt += emit("TW2_SLAB_ASM_Q%d" % hs, slabQ(hs)) + "\n" + emit("TW2F_SLAB_ASM_Q%d" % hs, f16(slabQ(hs))) + "\n"
+    txt += "\n// skewed half-workgroup variant (4 positions / 8 waves, 8 KB slabs, 8-slot ring fed by waves 0-3), bf16 and fp16\n"
+    for hs in range(4):
+        txt += emit("TWS_SLAB_ASM_Q%d" % hs, slabSK(hs)) + "\n" + emit("TWSF_SLAB_ASM_Q%d" % hs, f16(slabSK(hs))) + "\n"
     txt += "\n// position-per-wave variant (4 waves, 3 cell tiles x 4 channel tiles each, two fragment sets)\n"
     txt += emit("TWP_SLAB_ASM_H0", slabP(0)) + "\n" + emit("TWP_SLAB_ASM_H1", slabP(1))
     txt += "\n" + emit("TWP_SLAB_ASM_FIRST", slabP(0, first=True))

@@ -9,5 +9,6 @@ if [ "$1" = build ]; then
 else
   for dt in 1 0; do ./ubench/tower_trace1 8192 7 $dt; done
   ./ubench/tower_trace2 8192 7 1
+  ./ubench/tower_trace1 8192 7 1 300 1     # the skewed variant
   ./ubench/tower_base 8192 7 20 8
 fi
