@@ -36,12 +36,15 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
         c->tower_attr_set = true;
     }
     // CCHESS_TOWER_VARIANT: "4w" = 2 positions / 4 waves (k_tower_c128), "8w" = 4 positions / 8 waves
     // (k_tower8_c128), "pw" = 4 positions, one per wave (k_towerp_c128), "2x" = two workgroups of 2 positions / 4 waves
     // per CU (k_tower8_c128<.., 2>), "sk" = 4 positions / 8 waves with the two half-workgroups four slabs apart
-    // (k_towersk_c128); default: see kDefaultVariant
+    // (k_towersk_c128), "d" = 4 positions / 8 waves, weight fragments straight from global memory, no ring (k_towerd_c128);
+    // default: see kDefaultVariant
     static const int variant = [] {
         const char *e = getenv("CCHESS_TOWER_VARIANT");
         if (e && e[0] == '4') return 0;
@@ -49,9 +52,20 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
         if (e && e[0] == 'p') return 2;
         if (e && e[0] == '2') return 3;
         if (e && e[0] == 's') return 4;
+        if (e && e[0] == 'd') return 5;
         return kDefaultVariant;
     }();
-    if (variant == 4) {
+    if (variant == 5) {
+        const int grid = (B + TD_P - 1) / TD_P;
+        if (f16)
+            hipLaunchKernelGGL((k_towerd_c128<true>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, c->stream, (const uint16_t *)in,
+                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
+                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
+        else
+            hipLaunchKernelGGL((k_towerd_c128<false>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, c->stream, (const uint16_t *)in,
+                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
+                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
+    } else if (variant == 4) {
         const int grid = (B + SK_P - 1) / SK_P;
         if (f16)
             hipLaunchKernelGGL((k_towersk_c128<true>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, c->stream, (const uint16_t *)in,

@@ -1275,6 +1275,317 @@ __global__ __launch_bounds__(512, 2) void k_towersk_c128(const uint16_t *__restr
 #undef SK_RUN
 
 // =================================================================================================
+// k_towerd_c128 ("d", opt-in: CCHESS_TOWER_VARIANT=d): k_tower8_c128 without the weight ring.  Every wave loads the two weight
+// fragments of a k-step straight from global memory into registers (16 bytes per lane and fragment, 512 contiguous bytes per
+// half-wave in the packed layout [layer][tap][8-channel chunk][128 out][8]), two k-steps ahead, three register sets in
+// rotation; the four waves that share a channel half read the same lines within a few k-steps of each other, so all but the
+// first find them in the CU's vector L1.  No LDS-DMA, no per-slab barrier (the only barriers left are the two per layer), the
+// LDS pipe serves 3 instead of 5 fragment reads per 6 MFMAs, 64 KB of LDS stay free.  Same tiles, same k order, same rounding
+// as k_tower8_c128: bit-identical outputs.  One asm macro per k-step (tools/gen_tower_asm.py, kstepD); the rotation period of
+// the register sets is 24 k-steps = three taps.
+// =================================================================================================
+struct DGeo {
+    static constexpr int P = 4, ROWS = 360, THREADS = 512;
+    static constexpr int KSTEP_BYTES = 16 * 128 * 2, KSTEPS_PER_LAYER = 72;
+    static constexpr int ZERO_OFF = ROWS * CV_ROWB;
+    static constexpr int PLANES_OFF = ZERO_OFF + CV_ROWB;          // the input planes (32 B per cell), first layer only
+    static constexpr int HEADW_OFF = PLANES_OFF + ROWS * 32;
+    static constexpr int LDS_TOTAL = HEADW_OFF + 3 * 128 * 4;      // 105,472
+};
+constexpr int TD_P = 4, TD_THREADS = DGeo::THREADS, TD_LDS_BYTES = DGeo::LDS_TOTAL;
+struct TdA { bf16x8 a[CV_RT]; };
+struct TdW { bf16x8 b[CV_CT]; };
+
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void k_towerd_c128(const uint16_t *__restrict__ in,
+                                                        const uint16_t *__restrict__ wpk,
+                                                        const float *__restrict__ bias,
+                                                        uint16_t *__restrict__ out,
+                                                        const float *__restrict__ head_w,
+                                                        const float *__restrict__ head_b,
+                                                        float *__restrict__ head_out,
+                                                        const uint16_t *__restrict__ planes,
+                                                        const uint16_t *__restrict__ w0,
+                                                        const float *__restrict__ b0,
+                                                        int B, int nlayers,
+                                                        const int *__restrict__ bcount) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Geo = DGeo;
+    constexpr int P = Geo::P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int pos0 = blockIdx.x * P;
+    if (bcount) {
+        const int live = *bcount;
+        B = live < B ? live : B;
+    }
+    if (pos0 >= B) return;
+    const int npos = (B - pos0) < P ? (B - pos0) : P;
+    const int nrows = npos * 90;
+    const int total_k = nlayers * Geo::KSTEPS_PER_LAYER;
+    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this lane's 16 bytes inside a k-step's 4 KB of packed weights: chunk khalf, output channel wc*64 + l31 (+32: offset 512)
+    const unsigned voff = (unsigned)khalf * 2048u + (((unsigned)wc * 64u + (unsigned)l31) << 4);
+    auto kstep_ptr = [&](int k) {
+        return reinterpret_cast<const unsigned char *>(wpk) + (size_t)(k < total_k ? k : total_k - 1) * Geo::KSTEP_BYTES;
+    };
+    TdA A0, A1;
+    TdW W0, W1, W2;
+    {   // the weight pipeline is filled once: k-steps 0 and 1 (it never drains between layers: the layers are contiguous)
+        const unsigned char *p0 = kstep_ptr(0), *p1 = kstep_ptr(1);
+        asm volatile("global_load_dwordx4 %[w0b0], %[voff], %[p0]\n\t"
+                     "global_load_dwordx4 %[w0b1], %[voff], %[p0] offset:512\n\t"
+                     "global_load_dwordx4 %[w1b0], %[voff], %[p1]\n\t"
+                     "global_load_dwordx4 %[w1b1], %[voff], %[p1] offset:512\n\t"
+                     : [w0b0] "=&v"(W0.b[0]), [w0b1] "=&v"(W0.b[1]), [w1b0] "=&v"(W1.b[0]), [w1b1] "=&v"(W1.b[1])
+                     : [voff] "v"(voff), [p0] "s"(p0), [p1] "s"(p1)
+                     : "memory");
+        W2.b[0] = W2.b[1] = bf16x8{}; A0.a[0] = A0.a[1] = A0.a[2] = bf16x8{}; A1 = A0;   // defined values for the read-write asm operands below
+    }
+    if (planes == nullptr) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(in + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < Geo::ROWS * 16; idx += Geo::THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < nrows) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
+        }
+    } else {
+        const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
+        for (int idx = tid; idx < Geo::ROWS * 2; idx += Geo::THREADS) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < nrows * 2) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + Geo::PLANES_OFF + (idx << 4)) = v;
+        }
+    }
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + Geo::ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    if (head_out && tid < 3 * 128 / 4)
+        reinterpret_cast<float4 *>(smem + Geo::HEADW_OFF)[tid] = reinterpret_cast<const float4 *>(head_w)[tid];
+    bf16x8 wf[9][CV_CT];
+    if (planes != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+                wf[t][j] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)((t * 2 + (lane >> 5)) * 128 + (wave & 1) * 64 + j * 32 + (lane & 31)) << 3));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int rowb[CV_RT], tapmask[CV_RT];
+#pragma unroll
+    for (int i = 0; i < CV_RT; ++i) {
+        const int r = 32 * (wr * CV_RT + i) + l31;
+        const int pix = r % 90, h = pix / 10, w = pix - h * 10;
+        rowb[i] = r * CV_ROWB;
+        int m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
+            if (r < Geo::ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+        }
+        tapmask[i] = m;
+    }
+    auto tap_addr = [&](int tap, int (&ab)[CV_RT], int (&key)[CV_RT]) {   // tap 9 (past the last): every lane reads the zero row
+        const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : Geo::ZERO_OFF;
+            ab[i] = a;
+            key[i] = (((rowb[i] + delta) >> 8) & 15) ^ khalf;   // see k_tower8_c128
+        }
+    };
+    int rb[CV_RT];
+    auto refresh_rb = [&]() {
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int r = 32 * (wr * CV_RT + i) + l31;
+            rb[i] = (r < Geo::ROWS ? r : 0) * CV_ROWB;
+            asm volatile("" : "+v"(rb[i]));
+        }
+    };
+    auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
+        live = 32 * (wr * CV_RT + i) + l31 < Geo::ROWS;
+        const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
+        return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
+    };
+    uint2 xreg[CV_RT][CV_CT][4];
+    auto init_acc = [&](f32x16 (&acc)[CV_RT][CV_CT], const float *bl, bool add_x) {
+#pragma unroll
+        for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4 *>(bl + wc * 64 + j * 32 + 8 * q + 4 * khalf);
+#pragma unroll
+                for (int i = 0; i < CV_RT; ++i) {
+                    float a0 = bq.x, a1 = bq.y, a2 = bq.z, a3 = bq.w;
+                    if (add_x) {
+                        const uint2 x = xreg[i][j][q];
+                        const f32x2 xl = unpack_pair<F16>(x.x), xh = unpack_pair<F16>(x.y);
+                        a0 += xl[0]; a1 += xl[1]; a2 += xh[0]; a3 += xh[1];
+                    }
+                    acc[i][j][4 * q + 0] = a0; acc[i][j][4 * q + 1] = a1; acc[i][j][4 * q + 2] = a2; acc[i][j][4 * q + 3] = a3;
+                }
+            }
+    };
+    auto store_layer = [&](f32x16 (&acc)[CV_RT][CV_CT]) {   // ReLU -> 16 bit -> U in place (see k_tower8_c128)
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bool live;
+                    uint2 *cell = cell_ptr(i, j, q, live);
+                    const s16x2 z = {0, 0};
+                    const s16x2 rl = __builtin_elementwise_max(
+                        __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]})), z);
+                    const s16x2 rh = __builtin_elementwise_max(
+                        __builtin_bit_cast(s16x2, pack_pair<F16>(f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]})), z);
+                    if (live) *cell = make_uint2(__builtin_bit_cast(uint32_t, rl), __builtin_bit_cast(uint32_t, rh));
+                }
+    };
+    // workgroup barrier that leaves the weight loads in flight (__syncthreads() would wait for vmcnt(0))
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    if (planes != nullptr) {   // first layer: conv3x3(14 -> 128) + BN + ReLU, one k-step per tap
+        f32x16 acc[CV_RT][CV_CT];
+        init_acc(acc, b0, false);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
+            bf16x8 af[CV_RT];
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) {
+                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : Geo::ZERO_OFF;
+                af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CV_CT; ++j)
+                    acc[i][j] = mfma_32x32x16<F16>(wf[t][j], af[i], acc[i][j]);
+        }
+        refresh_rb();
+        store_layer(acc);
+        lds_barrier();
+    }
+
+#define TD_STEP(ASMSTR, KOFF)                                                                                    \
+        {                                                                                                        \
+            const unsigned char *wn = kstep_ptr(gk + (KOFF) + 2);                                                \
+            asm volatile(ASMSTR                                                                                  \
+                : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),      \
+                  [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),                                                    \
+                  [A0a0] "+v"(A0.a[0]), [A0a1] "+v"(A0.a[1]), [A0a2] "+v"(A0.a[2]),                                 \
+                  [A1a0] "+v"(A1.a[0]), [A1a1] "+v"(A1.a[1]), [A1a2] "+v"(A1.a[2]),                                 \
+                  [W0b0] "+v"(W0.b[0]), [W0b1] "+v"(W0.b[1]), [W1b0] "+v"(W1.b[0]), [W1b1] "+v"(W1.b[1]),            \
+                  [W2b0] "+v"(W2.b[0]), [W2b1] "+v"(W2.b[1]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)         \
+                : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),      \
+                  [key2] "v"(key[2]), [nab0] "v"(nab[0]), [nab1] "v"(nab[1]), [nab2] "v"(nab[2]), [nkey0] "v"(nkey[0]), \
+                  [nkey1] "v"(nkey[1]), [nkey2] "v"(nkey[2]), [voff] "v"(voff), [wn] "s"(wn)                          \
+                : "memory");                                                                                     \
+        }
+#define TD_K(K) if constexpr (F16) { TD_STEP(TWDF_KSTEP_##K, K) } else { TD_STEP(TWD_KSTEP_##K, K) }
+    int gk = 0;   // global k-step index of the current group of three taps
+#pragma unroll 1
+    for (int layer = 0; layer < nlayers; ++layer) {
+        f32x16 acc[CV_RT][CV_CT];
+        CZ_T8_STAMP(0);
+        refresh_rb();
+        if (!(layer & 1)) {   // first conv of a block: remember x, start from the bias
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CV_CT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { bool live; xreg[i][j][q] = *cell_ptr(i, j, q, live); }
+            init_acc(acc, bias + layer * 128, false);
+        } else {
+            init_acc(acc, bias + layer * 128, true);
+        }
+        int ab[CV_RT], key[CV_RT], nab[CV_RT], nkey[CV_RT], t0, t1, t2;
+        tap_addr(0, ab, key);
+        asm volatile(   // the activation fragments of the layer's first k-step
+            "v_xor_b32 %[t0], 0, %[k0]\n\t"
+            "v_xor_b32 %[t1], 0, %[k1]\n\t"
+            "v_xor_b32 %[t2], 0, %[k2]\n\t"
+            "v_lshl_add_u32 %[t0], %[t0], 4, %[b0]\n\t"
+            "v_lshl_add_u32 %[t1], %[t1], 4, %[b1]\n\t"
+            "v_lshl_add_u32 %[t2], %[t2], 4, %[b2]\n\t"
+            "ds_read_b128 %[xa0], %[t0]\n\t"
+            "ds_read_b128 %[xa1], %[t1]\n\t"
+            "ds_read_b128 %[xa2], %[t2]\n\t"
+            : [xa0] "=&v"(A0.a[0]), [xa1] "=&v"(A0.a[1]), [xa2] "=&v"(A0.a[2]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+            : [k0] "v"(key[0]), [k1] "v"(key[1]), [k2] "v"(key[2]), [b0] "v"(ab[0]), [b1] "v"(ab[1]), [b2] "v"(ab[2])
+            : "memory");
+        CZ_T8_STAMP(1);
+#pragma unroll 1
+        for (int t3 = 0; t3 < 3; ++t3) {   // three taps = 24 k-steps = one period of the register rotation
+            tap_addr(3 * t3 + 1, nab, nkey);
+            TD_K(0) TD_K(1) TD_K(2) TD_K(3) TD_K(4) TD_K(5) TD_K(6) TD_K(7)
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+            tap_addr(3 * t3 + 2, nab, nkey);
+            TD_K(8) TD_K(9) TD_K(10) TD_K(11) TD_K(12) TD_K(13) TD_K(14) TD_K(15)
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+            tap_addr(3 * t3 + 3, nab, nkey);
+            TD_K(16) TD_K(17) TD_K(18) TD_K(19) TD_K(20) TD_K(21) TD_K(22) TD_K(23)
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+            gk += 24;
+        }
+        // the last k-step requested activation fragments for a tap that does not exist: drain them, let the MFMAs retire
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        CZ_T8_STAMP(2);
+        lds_barrier();        // every wave is done reading U before anyone overwrites it in place
+#if defined(CZ_T8_TRACE)
+        CZ_T8_STAMP(13);
+#endif
+        refresh_rb();
+        store_layer(acc);
+        lds_barrier();
+        CZ_T8_STAMP(3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight fragments requested past the last k-step
+    if (out) {
+        uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < nrows * 16; idx += Geo::THREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(r * CV_ROWB, c));
+        }
+    }
+    if (head_out) {   // as in k_tower8_c128
+        const float *hw = reinterpret_cast<const float *>(smem + Geo::HEADW_OFF);
+        for (int r = tid; r < nrows; r += Geo::THREADS) {
+            const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c) {
+                const int p = c ^ key;
+                const uint4 v = *reinterpret_cast<const uint4 *>(smem + rowoff + (p << 4));
+                const f32x2 e0 = unpack_pair<F16>(v.x), e1 = unpack_pair<F16>(v.y), e2 = unpack_pair<F16>(v.z), e3 = unpack_pair<F16>(v.w);
+                const float *w0 = hw + c * 8, *w1 = hw + 128 + c * 8, *w2 = hw + 256 + c * 8;
+                acc0 += e0[0] * w0[0] + e0[1] * w0[1] + e1[0] * w0[2] + e1[1] * w0[3]
+                      + e2[0] * w0[4] + e2[1] * w0[5] + e3[0] * w0[6] + e3[1] * w0[7];
+                acc1 += e0[0] * w1[0] + e0[1] * w1[1] + e1[0] * w1[2] + e1[1] * w1[3]
+                      + e2[0] * w1[4] + e2[1] * w1[5] + e3[0] * w1[6] + e3[1] * w1[7];
+                acc2 += e0[0] * w2[0] + e0[1] * w2[1] + e1[0] * w2[2] + e1[1] * w2[3]
+                      + e2[0] * w2[4] + e2[1] * w2[5] + e3[0] * w2[6] + e3[1] * w2[7];
+            }
+            float *o = head_out + ((size_t)pos0 * 90 + r) * 3;
+            o[0] = fmaxf(acc0 + head_b[0], 0.f);
+            o[1] = fmaxf(acc1 + head_b[1], 0.f);
+            o[2] = fmaxf(acc2 + head_b[2], 0.f);
+        }
+    }
+}
+#undef TD_STEP
+#undef TD_K
+
+// =================================================================================================
 // k_towerp_c128: the one-launch net trunk with ONE POSITION PER WAVE (four waves, four positions per workgroup).
 //
 // k_tower8_c128 is co-limited by LDS bandwidth: with 3 cell tiles x 2 channel tiles per wave every 6 MFMAs need

@@ -307,29 +307,29 @@ def test_hip_fc_heads_vs_fp64(B):
 
 @pytest.mark.gpu
 def test_tower_variants_agree(tmp_path):
-    """The fused-tower kernels (CCHESS_TOWER_VARIANT = 4w | 8w | pw | 2x | sk) on identical inputs.  They add bias and
+    """The fused-tower kernels (CCHESS_TOWER_VARIANT = 4w | 8w | pw | 2x | sk | d) on identical inputs.  They add bias and
     residual at different points of the fp32 accumulation (8w: both before the MFMA chain; 4w: bias before, residual
     after; pw: both after), so they are held to bf16 noise against each other: 2e-2 of the largest head activation
-    after up to 14 layers, and much less for the shallow cases.  sk (the half-workgroups four slabs apart) runs 8w's
-    arithmetic on another schedule: bit-identical, bf16 and fp16."""
+    after up to 14 layers, and much less for the shallow cases.  sk (the half-workgroups four slabs apart) and d (weight
+    fragments straight from global memory, no LDS ring) run 8w's arithmetic on another schedule: bit-identical, bf16 and fp16."""
     import subprocess
     import sys
     helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variant_helper.py")
     outs = {}
-    for v in ("4w", "8w", "pw", "2x", "sk"):
+    for v in ("4w", "8w", "pw", "2x", "sk", "d"):
         f = str(tmp_path / ("z_%s.pt" % v))
         env = dict(os.environ, CCHESS_TOWER_VARIANT=v)
         subprocess.run([sys.executable, helper, f], check=True, env=env, timeout=300, stdin=subprocess.DEVNULL)
         outs[v] = torch.load(f)
     for k in outs["8w"]:
         ref = outs["8w"][k]
-        for v in ("4w", "pw", "2x", "sk"):
+        for v in ("4w", "pw", "2x", "sk", "d"):
             d = float((outs[v][k] - ref).abs().max())
             print("variant %s vs 8w, case %s: max|d| %.3g (max|z| %.3g)" % (v, k, d, float(ref.abs().max())))
             assert d <= 2e-2 * float(ref.abs().max()) + 1e-6, (v, k, d)
             if k == "1_1":
                 assert d <= 1e-3 * float(ref.abs().max()), (v, k, d)
-            if v == "sk":
+            if v in ("sk", "d"):
                 assert torch.equal(outs[v][k], ref), (v, k, d)
 
 

@@ -134,6 +134,38 @@ def slabSK(hs):
     return L
 
 
+def kstepD(k):
+    """Ring-free variant (k_towerd_c128): the weight fragments come straight from global memory (L1 / L2) into registers, so
+    there is no LDS weight ring, no DMA and no per-slab barrier.  One macro per k-step, k = 0..23 (three taps = the period of
+    the register rotation: activation fragments A0/A1 are requested from LDS one k-step ahead, weight fragments W0/W1/W2 from
+    global two k-steps ahead).  k-step k computes on A[k%2], W[k%3], requests A[(k+1)%2] for k+1 (the next tap's row addresses
+    when k is a tap's last k-step) and W[(k+2)%3] for k+2 (%[wn] = that k-step's 4 KB of the packed weights)."""
+    a, an, w, wn = "A%d" % (k % 2), "A%d" % ((k + 1) % 2), "W%d" % (k % 3), "W%d" % ((k + 2) % 3)
+    kk = k % 8
+    ab, key = ("nab", "nkey") if kk == 7 else ("ab", "key")
+    ca = ((kk + 1) % 8) * 2
+    m = lambda i, j: "v_mfma_f32_32x32x16_bf16 %%[%s], %%[%sb%d], %%[%sa%d], %%[%s]" % (ACC[i][j], w, j, a, i, ACC[i][j])
+    L = ["s_waitcnt lgkmcnt(0)", "s_waitcnt vmcnt(2)"]
+    L.append("v_xor_b32 %%[t0], %d, %%[%s0]" % (ca, key))
+    L.append(m(0, 0))
+    L.append("v_xor_b32 %%[t1], %d, %%[%s1]" % (ca, key))
+    L.append("v_xor_b32 %%[t2], %d, %%[%s2]" % (ca, key))
+    L.append("v_lshl_add_u32 %%[t0], %%[t0], 4, %%[%s0]" % ab)
+    L.append("v_lshl_add_u32 %%[t1], %%[t1], 4, %%[%s1]" % ab)
+    L.append("v_lshl_add_u32 %%[t2], %%[t2], 4, %%[%s2]" % ab)
+    L.append(m(0, 1))
+    L.append("ds_read_b128 %%[%sa0], %%[t0]" % an)
+    L.append("ds_read_b128 %%[%sa1], %%[t1]" % an)
+    L.append(m(1, 0))
+    L.append("ds_read_b128 %%[%sa2], %%[t2]" % an)
+    L.append("global_load_dwordx4 %%[%sb0], %%[voff], %%[wn]" % wn)
+    L.append(m(1, 1))
+    L.append("global_load_dwordx4 %%[%sb1], %%[voff], %%[wn] offset:512" % wn)
+    L.append(m(2, 0))
+    L.append(m(2, 1))
+    return L
+
+
 ACCP = [["p%d%d" % (i, j) for j in range(4)] for i in range(3)]
 
 
@@ -214,6 +246,9 @@ def main():
     txt += "\n// skewed half-workgroup variant (4 positions / 8 waves, 8 KB slabs, 8-slot ring fed by waves 0-3), bf16 and fp16\n"
     for hs in range(4):
         txt += emit("TWS_SLAB_ASM_Q%d" % hs, slabSK(hs)) + "\n" + emit("TWSF_SLAB_ASM_Q%d" % hs, f16(slabSK(hs))) + "\n"
+    txt += "\n// ring-free variant: weight fragments from global memory, one macro per k-step of the 24-k-step rotation period, bf16 and fp16\n"
+    for k in range(24):
+        txt += emit("TWD_KSTEP_%d" % k, kstepD(k)) + "\n" + emit("TWDF_KSTEP_%d" % k, f16(kstepD(k))) + "\n"
     txt += "\n// position-per-wave variant (4 waves, 3 cell tiles x 4 channel tiles each, two fragment sets)\n"
     txt += emit("TWP_SLAB_ASM_H0", slabP(0)) + "\n" + emit("TWP_SLAB_ASM_H1", slabP(1))
     txt += "\n" + emit("TWP_SLAB_ASM_FIRST", slabP(0, first=True))

@@ -1,7 +1,7 @@
 // tools/tower_sk_check.hip — k_towersk_c128 (half-workgroups four slabs apart) against k_tower8_c128: bit-equality of the trunk
 // output and of the head-conv output on the same data (both entry paths: 128-channel input, and input planes through the
 // first layer), then alternating timings of the two kernels on that data (Glorot-sized weights, half-zero activations: the
-// activations stay finite, unlike tools/tower_ubench.hip's).  args: B blocks fp16(0|1) iters
+// activations stay finite, unlike tools/tower_ubench.hip's).  args: B blocks fp16(0|1) iters variant(1 = k_towersk_c128, 2 = k_towerd_c128: weight fragments from global memory, no ring)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,7 +17,7 @@ static uint16_t to16(float f, int f16) {
 }
 int main(int argc, char **argv) {
     using namespace czconv;
-    const int B = argc > 1 ? atoi(argv[1]) : 8192, nblocks = argc > 2 ? atoi(argv[2]) : 7, f16 = argc > 3 ? atoi(argv[3]) : 1, iters = argc > 4 ? atoi(argv[4]) : 20;
+    const int B = argc > 1 ? atoi(argv[1]) : 8192, nblocks = argc > 2 ? atoi(argv[2]) : 7, f16 = argc > 3 ? atoi(argv[3]) : 1, iters = argc > 4 ? atoi(argv[4]) : 20, var = argc > 5 ? atoi(argv[5]) : 1;
     const int nl = 2 * nblocks;
     const size_t n = (size_t)B * 90 * 128, nw = (size_t)nl * 9 * 128 * 128, np = (size_t)B * 90 * 16, nw0 = 9 * 2 * 128 * 8;
     uint16_t *in, *pl, *w, *w0, *out[2]; float *bias, *b0, *hw, *hb, *ho[2];
@@ -42,12 +42,18 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
+    const char *vname = var == 2 ? "k_towerd_c128 " : "k_towersk_c128";
     const int grid = (B + 3) / 4;
     auto launch = [&](int which, bool planes_path) {
         const uint16_t *i_ = planes_path ? nullptr : in, *p_ = planes_path ? pl : nullptr;
         if (which == 0) {
             if (f16) hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, i_, w, bias, out[0], hw, hb, ho[0], p_, w0, b0, B, nl, nullptr);
             else hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, i_, w, bias, out[0], hw, hb, ho[0], p_, w0, b0, B, nl, nullptr);
+        } else if (var == 2) {
+            if (f16) hipLaunchKernelGGL((k_towerd_c128<true>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, 0, i_, w, bias, out[1], hw, hb, ho[1], p_, w0, b0, B, nl, nullptr);
+            else hipLaunchKernelGGL((k_towerd_c128<false>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, 0, i_, w, bias, out[1], hw, hb, ho[1], p_, w0, b0, B, nl, nullptr);
         } else {
             if (f16) hipLaunchKernelGGL((k_towersk_c128<true>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, 0, i_, w, bias, out[1], hw, hb, ho[1], p_, w0, b0, B, nl, nullptr);
             else hipLaunchKernelGGL((k_towersk_c128<false>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, 0, i_, w, bias, out[1], hw, hb, ho[1], p_, w0, b0, B, nl, nullptr);
@@ -78,7 +84,7 @@ int main(int argc, char **argv) {
             for (int i = 0; i < iters; ++i) launch(k, true);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("%s: %8.1f us per launch\n", k ? "k_towersk_c128" : "k_tower8_c128 ", ms * 1e3 / iters);
+            printf("%s: %8.1f us per launch\n", k ? vname : "k_tower8_c128 ", ms * 1e3 / iters);
         }
     printf(bad ? "MISMATCH\n" : "bit-identical\n");
     return bad != 0;

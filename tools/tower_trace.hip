@@ -1,7 +1,7 @@
 // tools/tower_trace.hip — where the cycles of a layer of k_tower8_c128 go.  Built twice by tools/tower_trace.sh
 // (-DCZ_T8_TRACE=1: four stamps per layer at points where the wave waits for its scalar/LDS counters anyway; =2: plus one per
 // tap, which perturbs the software pipeline) and run at the benchmark's batch; prints per-layer means over all workgroups and
-// waves, in shader-clock ticks and as a share of the layer.  args: B blocks fp16(0|1) warm_launches kernel(0 = k_tower8_c128, 1 = k_towersk_c128)
+// waves, in shader-clock ticks and as a share of the layer.  args: B blocks fp16(0|1) warm_launches kernel(0 = k_tower8_c128, 1 = k_towersk_c128, 2 = k_towerd_c128)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,8 +32,12 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
     auto launch = [&] {
-        if (sk && f16) hipLaunchKernelGGL((k_towersk_c128<true>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, nl, nullptr);
+        if (sk == 2 && f16) hipLaunchKernelGGL((k_towerd_c128<true>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, nl, nullptr);
+        else if (sk == 2) hipLaunchKernelGGL((k_towerd_c128<false>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, nl, nullptr);
+        else if (sk && f16) hipLaunchKernelGGL((k_towersk_c128<true>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, nl, nullptr);
         else if (sk) hipLaunchKernelGGL((k_towersk_c128<false>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, nl, nullptr);
         else if (f16) hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, nl, nullptr);
         else hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, nl, nullptr);
@@ -52,7 +56,7 @@ int main(int argc, char **argv) {
     wgdur /= grid;
     const double rounds = (double)grid / 256.0;
     printf("%s, trace level %d, %s, B=%d, %d layers: kernel %.1f us; a workgroup spends %.0f ticks in its %d layers; %.1f rounds of workgroups "
-           "=> >= %.2f ticks/ns if a round were nothing but its layers\n", sk ? "k_towersk_c128" : "k_tower8_c128", (int)CZ_T8_TRACE, f16 ? "fp16" : "bf16", B, nl, ms * 1e3, wgdur, nl,
+           "=> >= %.2f ticks/ns if a round were nothing but its layers\n", sk == 2 ? "k_towerd_c128" : sk ? "k_towersk_c128" : "k_tower8_c128", (int)CZ_T8_TRACE, f16 ? "fp16" : "bf16", B, nl, ms * 1e3, wgdur, nl,
            rounds, wgdur * rounds / (ms * 1e6));
     // per layer (layers 1.. : layer 0 has no predecessor stamp), means over workgroups and waves
     double top = 0, loop = 0, wait = 0, epi = 0, gap = 0, layer = 0, skew = 0; size_t cnt = 0, cntg = 0;
