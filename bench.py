@@ -548,7 +548,13 @@ def main():
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "us_per_launch": conv_ms * 1e3, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops,
-                "net_forward_ms_per_step": net_ms, "net_forward_tflops": flops / (net_ms * 1e-3) / 1e12}
+                "net_forward_ms_per_step": net_ms, "net_forward_tflops": flops / (net_ms * 1e-3) / 1e12,
+                # context, not a live measurement: what back-to-back MFMAs with operands in registers sustain on this chip
+                # under its power limit (tools/mfma_peak.hip, profiles/r03f_mfma_peak_f16.log), and that three schedules of
+                # this kernel whose cycle counts differ by 7 % run within 1.5 % of each other in time
+                "power_limited_reference": {"bare_mfma_tflops_random_data": {"bf16": 1734.0, "fp16": 1709.0}[args.dtype] if args.dtype in ("bf16", "fp16") else None,
+                                            "bare_mfma_tflops_half_zero_data": {"bf16": 1908.0, "fp16": 1884.0}[args.dtype] if args.dtype in ("bf16", "fp16") else None,
+                                            "source": "profiles/r03f_mfma_peak_f16.log; DESIGN.md 8: the kernel is bounded by energy per position, not by issue slots"}}
     else:
         achieved = flops / (net_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "net forward via torch/MIOpen (conv tower + heads), all launches of one step",
