@@ -84,3 +84,14 @@ def test_hot_kernels_use_no_scratch(tmp_path):
                 checked += 1
     # 4 trunk instantiations; 4 select + 2 select_k + 3 expand + 2 expand_k + advance + root_stats; 2 heads; 3 rules; 3 self-play
     assert checked >= 4 + 13 + 2 + 3 + 3, checked
+
+
+def test_generated_slab_asm_is_in_sync(tmp_path):
+    """cchess_zero_amd/csrc/cz_tower_slab_asm.inc is generated (tools/gen_tower_asm.py: the hand-scheduled slab / k-step bodies of
+    every trunk kernel variant): the committed file must be what the generator writes."""
+    import subprocess
+    import sys
+    out = str(tmp_path / "slab.inc")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tower_asm.py"), out], check=True, stdout=subprocess.DEVNULL,
+                   env={k: v for k, v in os.environ.items() if k != "CZ_TP_EXP"})
+    assert open(out).read() == open(os.path.join(ROOT, "cchess_zero_amd", "csrc", "cz_tower_slab_asm.inc")).read()

@@ -231,8 +231,9 @@ def emit(name, lines):
 
 
 def main():
+    import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    dst = os.path.join(os.path.dirname(here), "cchess_zero_amd", "csrc", "cz_tower_slab_asm.inc")
+    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(here), "cchess_zero_amd", "csrc", "cz_tower_slab_asm.inc")
     txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
     txt += emit("TW_SLAB_ASM_H0", slab(0)) + "\n" + emit("TW_SLAB_ASM_H1", slab(1))
     txt += "\n// 8-wave / 4-position variant (two fragment sets, 2 DMA pieces per wave)\n"
