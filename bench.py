@@ -39,7 +39,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense peaks, same guide
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp16x2": 2500.0, "bf16x2": 2500.0}  # dense peaks, same guide (x2: the strict engine, 16-bit MFMAs)
 
 START = np.array([3, 5, 4, 2, 1, 2, 4, 5, 3] + [0] * 9 + [0, 7, 0, 0, 0, 0, 0, 7, 0] + [6, 0, 6, 0, 6, 0, 6, 0, 6] + [0] * 18 +
                  [13, 0, 13, 0, 13, 0, 13, 0, 13] + [0, 14, 0, 0, 0, 0, 0, 14, 0] + [0] * 9 + [10, 12, 11, 9, 8, 9, 11, 12, 10], np.uint8)
@@ -203,8 +203,8 @@ def main():
     ap.add_argument("--games", type=int, default=8192, help="game trees per GPU")
     ap.add_argument("--playout", type=int, default=1600)
     ap.add_argument("--blocks", type=int, default=7)
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
-                    help="MFMA operand type of the tower (fp32 accumulate).  fp16 (default): the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output)")
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp16x2", "bf16x2", "strict"],
+                    help="MFMA operand type of the tower (fp32 accumulate).  fp16 (default): the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output).  fp16x2 (= strict) / bf16x2: the STRICT engine, every weight and stored activation as hi + lo halves of that type and three MFMAs per product (k_trunk_split_c128): north_star's 1e-3 against fp32 also on trained-like weights and at 19 blocks, at a third of the rate")
     ap.add_argument("--age-steps", type=int, default=800, help="untimed lock-steps BEFORE --warmup that bring every tree to a representative phase of its search: each tree's first search is cut at its own threshold (uniform in [8, age-steps] simulations), so when the timed region starts the trees are spread over the phases of a playout-long search on subtrees kept from a previous ply — the state of a long run — instead of all standing 25 simulations into a fresh search")
     ap.add_argument("--steady-steps", type=int, default=2000, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="testing only: initialise the process group and run every collective even with a world of 1 (RCCL API check on one GPU)")
     ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
     args = ap.parse_args()
+    if args.dtype == "strict":
+        args.dtype = "fp16x2"
+    split = args.dtype.endswith("x2")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -267,17 +270,17 @@ def main():
         torch.set_num_threads(max(1, min(4, len(cpus) if cpus else 2)))
 
     G, playout = args.games, args.playout
-    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp16x2": torch.float16, "bf16x2": torch.bfloat16}[args.dtype]
     cap = args.nodes_per_tree or default_nodes_per_tree(playout)
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
     # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
-    fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16")
+    fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16", "fp16x2", "bf16x2")
     K = max(1, args.search_threads)
     if args.selfplay and K != 1:
         ap.error("--selfplay runs one simulation in flight per tree")
     eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx, width=K)
-    net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
+    net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split=split)
     if args.full_policy_fc:
         net.fuse_policy_fc = False
     fused_fc = net.fused_search and K == 1
@@ -499,7 +502,7 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed
     # rocprofv3 --pmc measurement of the same launch shape is attached when the configuration matches.
-    tower_kernel = "k_tower_c128" if os.environ.get("CCHESS_TOWER_VARIANT", "") == "4w" else "k_tower8_c128"
+    tower_kernel = "k_trunk_split_c128" if split else "k_tower8_c128"
     traffic, traffic_src = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -634,7 +637,7 @@ def main():
                   "as_benchmarked_glorot": net_error(net, xs)}
             ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] = bool(ne["as_benchmarked_glorot"]["dlogit"] <= 1e-3 and ne["as_benchmarked_glorot"]["dvalue"] <= 1e-3)
             out["net_error"] = ne
-            net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx)
+            net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split=split)
             trained_like_(net_t, xs[:96])
             ne["trained_like"] = net_error(net_t, xs)
         except Exception as e:

@@ -1,6 +1,7 @@
 // cz_conv.hip — C-ABI wrapper of the fused MFMA conv3x3 kernel (device code: cz_conv_kernel.h).
 #include "cz_internal.h"
 #include "cz_conv_kernel.h"
+#include "cz_trunk_split.h"
 #include <stdlib.h>
 
 extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, const void *residual,
@@ -19,8 +20,6 @@ extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, 
     return CZ_OK;
 }
 
-static constexpr int kDefaultVariant = 1;
-
 static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
                         const float *head_b, float *head_out, int B, int nblocks, const void *planes = nullptr,
                         const void *w0 = nullptr, const float *b0 = nullptr, bool f16 = false) {
@@ -28,84 +27,19 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
     using namespace czconv;
     if (B == 0) return CZ_OK;
     if (!c->tower_attr_set) {
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerp_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towersk_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
-        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerd_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS_BYTES));
         c->tower_attr_set = true;
     }
-    // CCHESS_TOWER_VARIANT: "4w" = 2 positions / 4 waves (k_tower_c128), "8w" = 4 positions / 8 waves
-    // (k_tower8_c128), "pw" = 4 positions, one per wave (k_towerp_c128), "2x" = two workgroups of 2 positions / 4 waves
-    // per CU (k_tower8_c128<.., 2>), "sk" = 4 positions / 8 waves with the two half-workgroups four slabs apart
-    // (k_towersk_c128), "d" = 4 positions / 8 waves, weight fragments straight from global memory, no ring (k_towerd_c128);
-    // default: see kDefaultVariant
-    static const int variant = [] {
-        const char *e = getenv("CCHESS_TOWER_VARIANT");
-        if (e && e[0] == '4') return 0;
-        if (e && e[0] == '8') return 1;
-        if (e && e[0] == 'p') return 2;
-        if (e && e[0] == '2') return 3;
-        if (e && e[0] == 's') return 4;
-        if (e && e[0] == 'd') return 5;
-        return kDefaultVariant;
-    }();
-    if (variant == 5) {
-        const int grid = (B + TD_P - 1) / TD_P;
-        if (f16)
-            hipLaunchKernelGGL((k_towerd_c128<true>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, c->stream, (const uint16_t *)in,
-                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-        else
-            hipLaunchKernelGGL((k_towerd_c128<false>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, c->stream, (const uint16_t *)in,
-                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-    } else if (variant == 4) {
-        const int grid = (B + SK_P - 1) / SK_P;
-        if (f16)
-            hipLaunchKernelGGL((k_towersk_c128<true>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, c->stream, (const uint16_t *)in,
-                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-        else
-            hipLaunchKernelGGL((k_towersk_c128<false>), dim3(grid), dim3(SK_THREADS), SK_LDS_BYTES, c->stream, (const uint16_t *)in,
-                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-    } else if (variant == 3) {
-        const int grid = (B + T2_P - 1) / T2_P;
-        if (f16)
-            hipLaunchKernelGGL((k_tower8_c128<true, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
-                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-        else
-            hipLaunchKernelGGL((k_tower8_c128<false, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, c->stream, (const uint16_t *)in,
-                               (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                               (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-    } else if (f16) {   // fp16 operands: the 8-wave kernel (or 2x above)
-        const int grid = (B + T8_P - 1) / T8_P;
+    const int grid = (B + T8_P - 1) / T8_P;
+    if (f16)
         hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-    } else if (variant == 0) {
-        const int grid = (B + TW_P - 1) / TW_P;
-        hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, c->stream, (const uint16_t *)in,
-                           (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                           (const uint16_t *)w0, b0, B, 2 * nblocks);
-    } else if (variant == 1) {
-        const int grid = (B + T8_P - 1) / T8_P;
+    else
         hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
                            (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
-    } else {
-        const int grid = (B + TP_P - 1) / TP_P;
-        hipLaunchKernelGGL(k_towerp_c128, dim3(grid), dim3(TP_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
-                           (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                           (const uint16_t *)w0, b0, B, 2 * nblocks);
-    }
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
@@ -138,4 +72,32 @@ extern "C" int cz_net_trunk_f16(cz_ctx *c, const void *planes16, const void *w0,
                "cz_net_trunk_f16: null argument / nblocks < 1");
     CZ_REQUIRE(!head_out || (head_w && head_b), "cz_net_trunk_f16: head_out needs head_w and head_b");
     return launch_tower(c, nullptr, wpk, bias, trunk_out, head_w, head_b, head_out, B, nblocks, planes16, w0, b0, true);
+}
+
+extern "C" int cz_net_trunk_split(cz_ctx *c, const void *planes16, const void *w0, const float *b0, const void *wpk,
+                                  const float *bias, float *trunk_out, const float *head_w, const float *head_b,
+                                  float *head_out, int B, int nblocks, int halves_dtype) {
+    using namespace czconv;
+    CZ_REQUIRE(c && planes16 && w0 && b0 && wpk && bias && B >= 0 && nblocks >= 1 && (trunk_out || head_out),
+               "cz_net_trunk_split: null argument / nblocks < 1");
+    CZ_REQUIRE(!head_out || (head_w && head_b), "cz_net_trunk_split: head_out needs head_w and head_b");
+    CZ_REQUIRE(halves_dtype == CZ_F16 || halves_dtype == CZ_BF16, "cz_net_trunk_split: halves_dtype must be CZ_F16 or CZ_BF16");
+    if (head_w && (reinterpret_cast<uintptr_t>(head_w) & 15u)) { cz_set_error("cz_net_trunk_split: head_w must be 16-byte aligned"); return CZ_EINVAL; }
+    if (B == 0) return CZ_OK;
+    if (!c->split_attr_set) {
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trunk_split_c128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS_BYTES));
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trunk_split_c128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS_BYTES));
+        c->split_attr_set = true;
+    }
+    const int grid = (B + XS_P - 1) / XS_P;
+    if (halves_dtype == CZ_F16)
+        hipLaunchKernelGGL((k_trunk_split_c128<true>), dim3(grid), dim3(XS_THREADS), XS_LDS_BYTES, c->stream, (const uint16_t *)wpk, bias,
+                           trunk_out, head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks,
+                           c->batch_count);
+    else
+        hipLaunchKernelGGL((k_trunk_split_c128<false>), dim3(grid), dim3(XS_THREADS), XS_LDS_BYTES, c->stream, (const uint16_t *)wpk, bias,
+                           trunk_out, head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks,
+                           c->batch_count);
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
 }

@@ -209,17 +209,23 @@ class PolicyValueNet:
     accumulate on MFMA), heads in fp32.  forward_device() is the device-to-device path the search
     loop uses; forward() has the reference signature (policy_value_network.forward)."""
 
-    def __init__(self, res_block_nums=7, device="cuda:0", dtype=torch.float16, seed=0, module=None, backend="auto", ctx=None):
+    def __init__(self, res_block_nums=7, device="cuda:0", dtype=torch.float16, seed=0, module=None, backend="auto", ctx=None,
+                 split=False):
         """backend: "hip"       = first conv + residual tower + head convs in ONE fused MFMA launch (cz_net_trunk_bf16 /
-                                  cz_net_trunk_f16), FC heads in cz_fc_heads_f32; dtype bf16 or fp16,
+                                  cz_net_trunk_f16; split=True: cz_net_trunk_split), FC heads in cz_fc_heads_f32; dtype bf16 or fp16,
                     "hip-layer" = one fused conv launch per layer, cz_conv3x3_c128_bf16 (bf16 only),
                     "torch"     = tower convs by torch/MIOpen (any dtype; the fp32 parity path),
                     "auto"      = hip for fp16 / bf16 on a GPU, else torch.
         dtype: fp16 is the default — the same MFMA rate as bf16 on gfx950 with 11 instead of 8 mantissa bits per stored
         activation: 7 blocks stay within north_star's 1e-3 of the fp32 graph on TF-default weights (|dlogit| 1.2e-4) and
-        within 1.1e-3 of the largest logit on peaked, trained-like weights (bf16: 9e-3; tests/test_net.py)."""
+        within 1.1e-3 of the largest logit on peaked, trained-like weights (bf16: 9e-3; tests/test_net.py).
+        split: the STRICT engine (k_trunk_split_c128): every weight and every stored activation is carried as hi + lo, two
+        values of `dtype` (22 significant bits for fp16, 16 for bf16), three MFMAs per product — north_star's 1e-3 against
+        the fp32 graph also on peaked, trained-like weights and at 19 blocks (measured 2e-5 / 1e-4), at a third of the
+        16-bit engine's rate.  hip backend only."""
         self.device = torch.device(device)
         self.dtype = dtype
+        self.split = bool(split)
         self.module = (module or PolicyValueModule(res_block_nums, seed)).to(self.device)
         self.res_block_nums = self.module.res_block_nums
         if backend == "auto":
@@ -228,6 +234,8 @@ class PolicyValueNet:
             raise ValueError("the fused hip backend computes in bf16 or fp16 (fp32 accumulate); use backend='torch' for %s" % dtype)
         if backend == "hip-layer" and dtype != torch.bfloat16:
             raise ValueError("the per-layer hip backend computes in bf16; use backend='hip' or 'torch' for %s" % dtype)
+        if self.split and backend != "hip":
+            raise ValueError("split=True (the strict engine) is a kernel of the fused hip backend")
         self.backend = backend
         self._ctx = ctx
         self._bufs = None
@@ -264,6 +272,22 @@ class PolicyValueNet:
             layers = [x for blk in self.hip_blocks for x in blk]
             self.hip_tower_w = torch.stack([w for w, _ in layers]).contiguous() if layers else torch.zeros((0,), dtype=hdt, device=self.device)
             self.hip_tower_b = torch.stack([b for _, b in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.float32, device=self.device)
+            if self.split:
+                # strict engine: w = hi + lo, two values of hdt.  Tower layer: [tap][32-channel quarter of the tap = one 16 KB
+                # slab][hi, lo][ci/8 within the quarter][co][ci%8]; first layer: [tap][hi, lo][ci/8][co][ci%8]
+                def halves(w):
+                    hi = w.to(hdt)
+                    return hi, (w - hi.float()).to(hdt)
+
+                def split_pack(cb):
+                    w, _ = cb.folded()
+                    t = w.permute(2, 3, 1, 0).reshape(9, 4, 4, 8, FILTERS).permute(0, 1, 2, 4, 3)   # [tap][quarter][ci8][co][ci%8]
+                    hi, lo = halves(t)
+                    return torch.stack([hi, lo], dim=2).contiguous()                                 # [9][4][2][4][128][8]
+                sl = [split_pack(cb) for blk in m.blocks for cb in blk]
+                self.hip_split_w = torch.stack(sl).contiguous() if sl else torch.zeros((0,), dtype=hdt, device=self.device)
+                hi0, lo0 = halves(w0p.reshape(9, 2, 8, FILTERS).permute(0, 1, 3, 2))
+                self.hip_split_w0 = torch.stack([hi0, lo0], dim=1).contiguous()                      # [9][2][2][128][8]
         # heads: 1x1 convs as fp32 matmuls over [B*90,128]
         wp, bp = m.policy_conv.folded()
         wv, bv = m.value_conv.folded()
@@ -332,17 +356,26 @@ class PolicyValueNet:
         else:
             p16 = torch.zeros((B, 9, 10, 16), dtype=hdt, device=self.device)
             p16[..., :14] = planes[..., :14].to(hdt)
-        z = torch.empty((B, 90, FILTERS), dtype=hdt, device=self.device) if trunk else torch.empty((B, 90, 3), dtype=torch.float32, device=self.device)
+        tdt = torch.float32 if self.split else hdt     # the strict engine hands the trunk out as fp32 = hi + lo
+        z = torch.empty((B, 90, FILTERS), dtype=tdt, device=self.device) if trunk else torch.empty((B, 90, 3), dtype=torch.float32, device=self.device)
         self._hip_ctx().bind_stream()
         ev = None
         if self.conv_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        check(fn(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_w0.data_ptr()),
-                 C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_tower_w.data_ptr()),
-                 C.c_void_p(self.hip_tower_b.data_ptr()), C.c_void_p(z.data_ptr()) if trunk else None,
-                 C.c_void_p(self.head_w_rows.data_ptr()), C.c_void_p(self.head_b.data_ptr()),
-                 None if trunk else C.c_void_p(z.data_ptr()), B, self.res_block_nums), "cz_net_trunk")
+        if self.split:
+            check(lib().cz_net_trunk_split(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_split_w0.data_ptr()),
+                                           C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_split_w.data_ptr()),
+                                           C.c_void_p(self.hip_tower_b.data_ptr()), C.c_void_p(z.data_ptr()) if trunk else None,
+                                           C.c_void_p(self.head_w_rows.data_ptr()), C.c_void_p(self.head_b.data_ptr()),
+                                           None if trunk else C.c_void_p(z.data_ptr()), B, self.res_block_nums,
+                                           2 if hdt == torch.float16 else 1), "cz_net_trunk_split")
+        else:
+            check(fn(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_w0.data_ptr()),
+                     C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_tower_w.data_ptr()),
+                     C.c_void_p(self.hip_tower_b.data_ptr()), C.c_void_p(z.data_ptr()) if trunk else None,
+                     C.c_void_p(self.head_w_rows.data_ptr()), C.c_void_p(self.head_b.data_ptr()),
+                     None if trunk else C.c_void_p(z.data_ptr()), B, self.res_block_nums), "cz_net_trunk")
         if ev is not None:
             ev[1].record()
             self.conv_events.append(ev)
@@ -424,8 +457,8 @@ class PolicyValueNet:
     @torch.no_grad()
     def tower(self, planes):
         """planes [B,9,10,C>=14] (NHWC, any float dtype) -> trunk activations [B,128,9,10] channels_last."""
-        if self.backend == "hip" and self.dtype == torch.float16 and self.res_block_nums >= 1:
-            t = self._hip_net_forward(planes, trunk=True)   # fp16: the fused kernel is the only hip route
+        if self.backend == "hip" and (self.dtype == torch.float16 or self.split) and self.res_block_nums >= 1:
+            t = self._hip_net_forward(planes, trunk=True)   # fp16 / strict: the fused kernel is the only hip route
             return t.reshape(t.shape[0], 9, 10, FILTERS).permute(0, 3, 1, 2)
         h = self.first_conv(planes)
         if self.backend == "hip":

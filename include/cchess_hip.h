@@ -325,6 +325,20 @@ int cz_net_trunk_f16(cz_ctx *, const void *planes16, const void *w0, const float
                      const float *bias, void *trunk_out, const float *head_w, const float *head_b,
                      float *head_out, int B, int nblocks);
 
+/* The STRICT-precision form of cz_net_trunk_*: every weight and every stored activation is carried as hi + lo, two values
+ * of `halves_dtype` (CZ_F16: 22 significant bits, CZ_BF16: 16), and every product is three MFMAs (hi*hi + hi*lo + lo*hi,
+ * fp32 accumulate) — the engine that meets north_star's "policy/value outputs within 1e-3 of fp32" for the reference's
+ * fp32 sess.run (policy_value_network.py:202-214) also on trained (peaked) weights and at 19 blocks, at a third of the
+ * 16-bit kernels' rate.
+ *   planes16 : [B][90][16] of halves_dtype (0/1 planes are exact: the same buffer cz_search_select writes)
+ *   w0   : [9 taps][hi, lo][2 = ci/8][128 co][8 = ci%8], b0 [128] f32
+ *   wpk  : [2*nblocks][9 taps][4 = 32-channel quarter of the tap][hi, lo][4 = ci/8][128 co][8] (16 KB per quarter: one
+ *          LDS-DMA slab), bias [2*nblocks][128] f32; BN folded; hi = rn(w), lo = rn(w - hi) (net.py packs it)
+ *   trunk_out : [B][90][128] FLOAT32 (hi + lo) or NULL; head_w / head_b / head_out as cz_net_trunk_bf16. */
+int cz_net_trunk_split(cz_ctx *, const void *planes16, const void *w0, const float *b0, const void *wpk,
+                       const float *bias, float *trunk_out, const float *head_w, const float *head_b,
+                       float *head_out, int B, int nblocks, int halves_dtype);
+
 /* The three fully connected layers behind the head convolutions (policy_value_network.py:62-63,72-74): policy FC
  * 180 -> 2086 (raw logits) and value FC 90 -> 256, ReLU, FC 256 -> 1, tanh, from the head conv outputs
  * z [B][90][3] f32 as cz_net_trunk_bf16 / cz_tower_heads_c128_bf16 leave them (flatten order (h,w,c)).

@@ -27,10 +27,11 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "net_errors.json")
     res = {}
     x = H.positions(64, 2)
-    for dtype, dname in ((torch.bfloat16, "bf16"), (torch.float16, "fp16"), (torch.float32, "fp32")):
+    for dtype, dname, split in ((torch.bfloat16, "bf16", False), (torch.float16, "fp16", False), (torch.float32, "fp32", False),
+                                (torch.float16, "fp16x2", True), (torch.bfloat16, "bf16x2", True)):
         for blocks in (2, 7, 19):
             for wname, wfn in H.WEIGHT_SETS.items():
-                net = PolicyValueNet(blocks, "cuda:0", dtype, seed=1)
+                net = PolicyValueNet(blocks, "cuda:0", dtype, seed=1, split=split)
                 wfn(net)
                 logits, v = net.forward(x)
                 ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, blocks)

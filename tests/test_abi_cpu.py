@@ -64,7 +64,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     from cchess_zero_amd import build
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cchess_zero_amd", "csrc")
     flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
-    hot = {"cz_conv.hip": ["k_tower8_c128"], "cz_search.hip": ["k_select", "k_expand_backup", "k_advance", "k_root_stats"],
+    hot = {"cz_conv.hip": ["k_tower8_c128", "k_trunk_split_c128"], "cz_search.hip": ["k_select", "k_expand_backup", "k_advance", "k_root_stats"],
            "cz_heads.hip": ["k_policy_fc", "k_value_fc"], "cz_rules.hip": ["k_movegen", "k_encode_planes"],
            "cz_selfplay.hip": ["k_sp_choose", "k_sp_adjudicate", "k_sp_flush"]}
 
@@ -82,16 +82,15 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             if any(n in m.group(1) for n in names):   # k_select also matches k_select_k, k_expand_backup the _k variant
                 assert int(m.group(2)) == 0, "%s uses %s bytes of scratch" % (m.group(1), m.group(2))
                 checked += 1
-    # 4 trunk instantiations; 4 select + 2 select_k + 3 expand + 2 expand_k + advance + root_stats; 2 heads; 3 rules; 3 self-play
+    # 2 + 2 trunk instantiations; 4 select + 2 select_k + 3 expand + 2 expand_k + advance + root_stats; 2 heads; 3 rules; 3 self-play
     assert checked >= 4 + 13 + 2 + 3 + 3, checked
 
 
 def test_generated_slab_asm_is_in_sync(tmp_path):
-    """cchess_zero_amd/csrc/cz_tower_slab_asm.inc is generated (tools/gen_tower_asm.py: the hand-scheduled slab / k-step bodies of
-    every trunk kernel variant): the committed file must be what the generator writes."""
+    """cchess_zero_amd/csrc/cz_tower_slab_asm.inc and cz_trunk_split_asm.inc are generated (tools/gen_tower_asm.py: the
+    hand-scheduled slab bodies of the two trunk kernels): the committed files must be what the generator writes."""
     import subprocess
     import sys
-    out = str(tmp_path / "slab.inc")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tower_asm.py"), out], check=True, stdout=subprocess.DEVNULL,
-                   env={k: v for k, v in os.environ.items() if k != "CZ_TP_EXP"})
-    assert open(out).read() == open(os.path.join(ROOT, "cchess_zero_amd", "csrc", "cz_tower_slab_asm.inc")).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tower_asm.py"), str(tmp_path)], check=True, stdout=subprocess.DEVNULL)
+    for f in ("cz_tower_slab_asm.inc", "cz_trunk_split_asm.inc"):
+        assert open(str(tmp_path / f)).read() == open(os.path.join(ROOT, "cchess_zero_amd", "csrc", f)).read(), f

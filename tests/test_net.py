@@ -305,32 +305,88 @@ def test_hip_fc_heads_vs_fp64(B):
     assert float((logits - l32).abs().max()) < 5e-4 * float(l32.abs().max()) and float((value - v32).abs().max()) < 1e-5
 
 
+# The STRICT engine (split=True, k_trunk_split_c128: hi + lo halves, three MFMAs per product) is held to north_star's contract
+# as written — ABSOLUTE 1e-3 on raw logits and on the value against the fp32 restatement of the reference graph — on every
+# weight set, including the peaked trained-like one (|logit| ~ 10) and 19 blocks, where a 16-bit tower is 15x .. 50x off.
+# Emulated on the CPU (tools/precision_decomposition.py; against the fp64 graph): fp16 halves 1.8e-5 / 1.3e-5 at 7 blocks and
+# 4e-5 / 1e-4 at 19 (trained-like), bf16 halves 1.8e-4 / 1.3e-4 and 4.8e-4 / 4.1e-4.
+STRICT_CASES = [("fp16", 2, "glorot"), ("fp16", 7, "glorot"), ("fp16", 3, "structured"), ("fp16", 7, "trained_like"),
+                ("fp16", 19, "glorot"), ("fp16", 19, "trained_like"), ("bf16", 7, "trained_like"), ("bf16", 19, "trained_like")]
+
+
 @pytest.mark.gpu
-def test_tower_variants_agree(tmp_path):
-    """The fused-tower kernels (CCHESS_TOWER_VARIANT = 4w | 8w | pw | 2x | sk | d) on identical inputs.  They add bias and
-    residual at different points of the fp32 accumulation (8w: both before the MFMA chain; 4w: bias before, residual
-    after; pw: both after), so they are held to bf16 noise against each other: 2e-2 of the largest head activation
-    after up to 14 layers, and much less for the shallow cases.  sk (the half-workgroups four slabs apart) and d (weight
-    fragments straight from global memory, no LDS ring) run 8w's arithmetic on another schedule: bit-identical, bf16 and fp16."""
-    import subprocess
-    import sys
-    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variant_helper.py")
-    outs = {}
-    for v in ("4w", "8w", "pw", "2x", "sk", "d"):
-        f = str(tmp_path / ("z_%s.pt" % v))
-        env = dict(os.environ, CCHESS_TOWER_VARIANT=v)
-        subprocess.run([sys.executable, helper, f], check=True, env=env, timeout=300, stdin=subprocess.DEVNULL)
-        outs[v] = torch.load(f)
-    for k in outs["8w"]:
-        ref = outs["8w"][k]
-        for v in ("4w", "pw", "2x", "sk", "d"):
-            d = float((outs[v][k] - ref).abs().max())
-            print("variant %s vs 8w, case %s: max|d| %.3g (max|z| %.3g)" % (v, k, d, float(ref.abs().max())))
-            assert d <= 2e-2 * float(ref.abs().max()) + 1e-6, (v, k, d)
-            if k == "1_1":
-                assert d <= 1e-3 * float(ref.abs().max()), (v, k, d)
-            if v in ("sk", "d"):
-                assert torch.equal(outs[v][k], ref), (v, k, d)
+@pytest.mark.parametrize("dname,blocks,wset", STRICT_CASES)
+def test_strict_engine_meets_1e3_absolute(dname, blocks, wset):
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(blocks, "cuda:0", {"bf16": torch.bfloat16, "fp16": torch.float16}[dname], seed=1, split=True)
+    assert net.backend == "hip" and net.split and net.fused_search
+    H.WEIGHT_SETS[wset](net)
+    x = _positions(64, 2)
+    logits, v = net.forward(x)
+    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, blocks)
+    e = H.errors(logits, v, ln, vn)
+    print("strict %sx2 %d-block %s: max|logit| %.3g  dlogit %.3g (rel %.3g)  dprob %.3g  dvalue %.3g  argmax agreement %.3f" %
+          (dname, blocks, wset, e["max_abs_logit"], e["dlogit"], e["dlogit_rel"], e["dprob"], e["dvalue"], e["argmax_agree"]))
+    assert np.isfinite(logits).all() and np.isfinite(v).all()
+    assert e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3     # north_star: "policy/value outputs match within 1e-3 fp32"
+    if dname == "fp16":                                   # and the fp16-halves engine with a decade to spare
+        assert e["dlogit"] <= 2e-4 and e["dvalue"] <= 2.5e-4
+    assert e["argmax_agree"] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_strict_engine_rows_are_independent_and_routes_agree(dt):
+    """k_trunk_split_c128: (i) a position's outputs do not depend on its row in the batch, on the batch size (ragged last
+    workgroup: 2 positions per workgroup) or on the device-side row count of the compact path; (ii) zero-copy 16-channel planes
+    in the operand type == repacked f32 planes; (iii) the fp32 trunk output (hi + lo) through torch's fp32 head convs and FCs
+    agrees with the fused heads to fp32 summation-order noise."""
+    import ctypes as C
+    from cchess_zero_amd._lib import check, lib
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(3, "cuda:0", dt, seed=4, split=True)
+    H.structured_(net)
+    x = torch.from_numpy(_positions(37, 5)).cuda()
+    l_all, v_all = net.forward_device(x)
+    for idx in ([0], [36], [5, 0, 36], list(range(36, -1, -1))):
+        li, vi = net.forward_device(x[idx])
+        assert torch.equal(li, l_all[idx]) and torch.equal(vi, v_all[idx]), idx
+    x16 = torch.zeros((37, 9, 10, 16), dtype=dt, device="cuda")
+    x16[..., :14] = x.to(dt)
+    l2, v2 = net.forward_device(x16)
+    assert torch.equal(l2, l_all) and torch.equal(v2, v_all)
+    # compact path: only the first *n_rows rows are computed, and they are the same bits
+    n = torch.tensor([11], dtype=torch.int32, device="cuda")
+    z_full = net._hip_net_forward(x16)
+    check(lib().cz_set_batch_count(net._hip_ctx().h, C.c_void_p(n.data_ptr())), "cz_set_batch_count")
+    try:
+        z_part = torch.full_like(z_full, float("nan"))
+        z_tmp = net._hip_net_forward(x16)
+        z_part[:11] = z_tmp[:11]
+    finally:
+        check(lib().cz_set_batch_count(net._hip_ctx().h, None), "cz_set_batch_count")
+    assert torch.equal(z_part[:11], z_full[:11])
+    # trunk route
+    l3, v3 = net.heads(net.tower(x))
+    dl, dv = float((l_all - l3).abs().max()), float((v_all - v3).abs().max())
+    print("strict %s trunk route vs fused heads: max|dlogit| %.3g (max|logit| %.3g) max|dvalue| %.3g" % (dt, dl, float(l3.abs().max()), dv))
+    assert dl <= 2e-5 * float(l3.abs().max()) + 1e-6 and dv <= 2e-6
+
+
+@pytest.mark.gpu
+def test_fp16_engines_do_not_overflow_to_inf():
+    """a checkpoint whose activations exceed 65504 must not put inf / NaN into the priors.  The fp16 kernels clamp
+    at the largest finite half on the store (k_tower8_c128: packed min after the packed max; k_trunk_split_c128: v_med3 before
+    the split); with the first layer's bias at 1e5 every activation of the net saturates and the outputs stay finite."""
+    from cchess_zero_amd.net import PolicyValueNet
+    x = torch.from_numpy(_positions(6, 3)).cuda()
+    for split in (False, True):
+        net = PolicyValueNet(2, "cuda:0", torch.float16, seed=2, split=split)
+        with torch.no_grad():
+            net.module.conv_in.conv.bias.fill_(1.0e5)
+        net.refresh()
+        logits, v = net.forward_device(x)
+        assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(v).all()), split
 
 
 @pytest.mark.gpu

@@ -1,4 +1,4 @@
-// tools/tower_trace.hip — where the cycles of a layer of k_tower8_c128 go.  Built twice by tools/tower_trace.sh
+// tools/experiments/tower_trace.hip — where the cycles of a layer of k_tower8_c128 go.  Built twice by tools/tower_trace.sh
 // (-DCZ_T8_TRACE=1: four stamps per layer at points where the wave waits for its scalar/LDS counters anyway; =2: plus one per
 // tap, which perturbs the software pipeline) and run at the benchmark's batch; prints per-layer means over all workgroups and
 // waves, in shader-clock ticks and as a share of the layer.  args: B blocks fp16(0|1) warm_launches kernel(0 = k_tower8_c128, 1 = k_towersk_c128, 2 = k_towerd_c128)
@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
-#include "../cchess_zero_amd/csrc/cz_conv_kernel.h"
+#include "cz_trunk_experiments.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 typedef unsigned long long u64;
 int main(int argc, char **argv) {

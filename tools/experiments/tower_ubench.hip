@@ -1,16 +1,16 @@
-// tools/tower_ubench.hip — stand-alone timing of the fused tower kernel (k_tower_c128).
+// tools/experiments/tower_ubench.hip — stand-alone timing of the fused tower kernel (k_tower_c128).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "../cchess_zero_amd/csrc/cz_conv_kernel.h"
+#include "cz_trunk_experiments.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 int main(int argc, char **argv) {
     using namespace czconv;
     const int B = argc > 1 ? atoi(argv[1]) : 8192;
     const int nblocks = argc > 2 ? atoi(argv[2]) : 7;
     const int iters = argc > 3 ? atoi(argv[3]) : 10;
-    const int variant = argc > 4 ? atoi(argv[4]) : 8;   // 4 = 2 positions / 4 waves, 8 = 4 positions / 8 waves, 1 = 4 positions, one per wave, 2 = two workgroups of 2 positions per CU
+    const int variant = argc > 4 ? atoi(argv[4]) : 8;   // 4 = 2 positions / 4 waves, 8 = 4 positions / 8 waves, 1 = 4 positions, one per wave
     const int zero = argc > 5 ? atoi(argv[5]) : 0;      // 1 = all-zero activations and weights (power experiment)
     const size_t n = (size_t)B * 90 * 128, nw = (size_t)2 * nblocks * 9 * 128 * 128;
     uint16_t *in, *out, *w; float *bias;
@@ -27,10 +27,8 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower_c128), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_towerp_c128), hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tower8_c128<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES));
-    const int grid = (variant == 4 || variant == 2) ? (B + TW_P - 1) / TW_P : (B + T8_P - 1) / T8_P;
+    const int grid = variant == 4 ? (B + TW_P - 1) / TW_P : (B + T8_P - 1) / T8_P;
 #define LAUNCH() do { if (variant == 4) hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); \
-                      else if (variant == 2) hipLaunchKernelGGL((k_tower8_c128<false, 2>), dim3(grid), dim3(T2_THREADS), T2_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks, (const int *)nullptr); \
                       else if (variant == 1) hipLaunchKernelGGL(k_towerp_c128, dim3(grid), dim3(TP_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); \
                       else hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks, (const int *)nullptr); } while (0)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -1,13 +1,13 @@
-// tools/tower_sk_check.hip — k_towersk_c128 (half-workgroups four slabs apart) against k_tower8_c128: bit-equality of the trunk
+// tools/experiments/variants_check.hip — k_towersk_c128 (half-workgroups four slabs apart) against k_tower8_c128: bit-equality of the trunk
 // output and of the head-conv output on the same data (both entry paths: 128-channel input, and input planes through the
 // first layer), then alternating timings of the two kernels on that data (Glorot-sized weights, half-zero activations: the
-// activations stay finite, unlike tools/tower_ubench.hip's).  args: B blocks fp16(0|1) iters variant(1 = k_towersk_c128, 2 = k_towerd_c128: weight fragments from global memory, no ring)
+// activations stay finite, unlike tools/experiments/tower_ubench.hip's).  args: B blocks fp16(0|1) iters variant(1 = k_towersk_c128, 2 = k_towerd_c128: weight fragments from global memory, no ring)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../cchess_zero_amd/csrc/cz_conv_kernel.h"
+#include "cz_trunk_experiments.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 static unsigned rs = 12345;
 static float urand() { rs = rs * 1664525u + 1013904223u; return (float)(rs >> 8) * (1.0f / 16777216.0f); }
