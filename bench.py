@@ -207,6 +207,7 @@ def main():
                     help="MFMA operand type of the tower (fp32 accumulate).  fp16 (default): the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output).  fp16x2 (= strict) / bf16x2: the STRICT engine, every weight and stored activation as hi + lo halves of that type and three MFMAs per product (k_trunk_split_c128): north_star's 1e-3 against fp32 also on trained-like weights and at 19 blocks, at a third of the rate")
     ap.add_argument("--age-steps", type=int, default=800, help="untimed lock-steps BEFORE --warmup that bring every tree to a representative phase of its search: each tree's first search is cut at its own threshold (uniform in [8, age-steps] simulations), so when the timed region starts the trees are spread over the phases of a playout-long search on subtrees kept from a previous ply — the state of a long run — instead of all standing 25 simulations into a fresh search")
     ap.add_argument("--steady-steps", type=int, default=2000, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
+    ap.add_argument("--strict-steps", type=int, default=240, help="lock-steps of a third timed region in which the SAME trees are searched with the strict engine (k_trunk_split_c128, fp16 hi + lo halves, 1e-3 of fp32 on every weight set) — the strict_engine block of the output; 0 = off; ignored when --dtype already names a strict engine")
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
@@ -295,19 +296,22 @@ def main():
     conv_ev = []   # (start, end) events around single launches of the dominant kernel (recorded inside the net)
     step_no = [0]
 
+    cur = {"net": net, "conv_ev": conv_ev, "ev": ev}   # the strict leg swaps the engine under the same loop
+
     def one_step(mode, timed):
         # HIP events around the launches of every 8th timed step (recorded on the stream the kernels are launched on)
         sample = timed and step_no[0] % 8 == 0
-        net.conv_events = conv_ev if sample else None
+        n_ = cur["net"]
+        n_.conv_events = cur["conv_ev"] if sample else None
         step_no[0] += 1
         if not sample:
-            eng.step(net.forward_device, mode=mode)
+            eng.step(n_.forward_device, mode=mode)
             return
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
-        eng.step(net.forward_device, mode=mode, pre_net=e[1].record, tap=lambda *a: e[2].record())
+        eng.step(n_.forward_device, mode=mode, pre_net=e[1].record, tap=lambda *a: e[2].record())
         e[3].record()
-        ev.append(e)
+        cur["ev"].append(e)
 
     gather_ok = None   # N > 1: result of the (untimed) record all-gather
     banked = torch.zeros(1, dtype=torch.int64, device=dev)   # simulations of the searches closed by an advance
@@ -481,8 +485,44 @@ def main():
         print("per-step GPU ms of the timed region:", " ".join("%.3f" % trace[i].elapsed_time(trace[i + 1]) for i in range(len(trace) - 1)), file=sys.stderr)
         trace = None
     steady = None
+    telemetry, clock = None, None
     if args.steady_steps > 0:
+        # the long leg is the one the headline is taken from; while it runs, a host thread samples the device's socket power
+        # and shader clock (hwmon) and the trunk kernel stamps its own workgroups in both clocks (cz_set_clock_probe)
+        from cchess_zero_amd.telemetry import ClockProbe, GpuSampler
+        sampler, probe = None, None
+        try:
+            sampler = GpuSampler(local_rank).start()
+            if fused:
+                probe = ClockProbe(ctx, (G * K + 1) // 2 + 1)
+                probe.arm()
+        except Exception as e:
+            print("bench: telemetry unavailable (%r)" % (e,), file=sys.stderr)
         steady = timed_region(args.steady_steps)
+        try:
+            if sampler is not None:
+                telemetry = sampler.stop()
+            if probe is not None:
+                probe.disarm()                       # the last launch of the leg
+                for _ in range(5):                   # and five more, eight steps apart, right behind it
+                    probe.arm()
+                    (run_plies if sp else run)(8, False)
+                    probe.disarm()
+                clock = probe.mean()
+        except Exception as e:
+            print("bench: telemetry read-out failed (%r)" % (e,), file=sys.stderr)
+    strict_leg = None
+    if args.strict_steps > 0 and fused and not split and not sp and net.backend == "hip":
+        # the same trees, the same loop, the strict engine: weights shared with the benchmarked net
+        net_s = PolicyValueNet(args.blocks, dev, torch.float16, backend="hip", ctx=ctx, split=True, module=net.module)
+        if tdt != torch.float16:   # the planes buffer is written in the benchmarked engine's type: the strict leg needs fp16 planes
+            net_s = PolicyValueNet(args.blocks, dev, tdt, backend="hip", ctx=ctx, split=True, module=net.module)
+        net_s.fuse_policy_fc = net.fuse_policy_fc
+        cur.update(net=net_s, conv_ev=[], ev=[])
+        run(8, False)
+        leg = timed_region(args.strict_steps)
+        strict_leg = (leg, cur["conv_ev"], net_s)
+        cur.update(net=net, conv_ev=conv_ev, ev=ev)
     if dist_on:
         # outside the timed regions: the record exchange of the self-play loop (all-gather of packed (s, pi, z) records,
         # device-resident end to end; both the sized and the fixed-capacity form) on a ragged token batch, so every N>1 run
@@ -540,24 +580,68 @@ def main():
                       "note": "a second barrier-bracketed timed region run right after the K contract steps, together with the ageing and the K steps more than 7 s of contiguous GPU work, so that a 5 s smi sampler sees the GPU busy; same loop, same counters"}
     flops = flops_per_position(args.blocks) * rows_per_launch
     peak = MFMA_PEAK_TFLOPS[args.dtype]
+    # what ONE launch of the fused trunk kernel computes per position, algorithmically (2 x MACs, SAME-padding taps
+    # counted densely): first conv + 2 * blocks tower convs + the two head 1x1 convs — everything but the three FC layers
+    trunk_flops_per_pos = flops_per_position(args.blocks) - 2 * (180 * 2086 + 90 * 256 + 256)
+
+    def mfma_probe():
+        """The box's own practical MFMA ceiling, measured now (cz_probe_mfma_peak, ~30 ms per launch)."""
+        import ctypes as C
+        from cchess_zero_amd._lib import check, lib
+        out_ = {}
+        code = 2 if tdt == torch.float16 else 1
+        for name, data in (("dense_random_operands", 0), ("half_zero_operands", 2)):
+            tf, ms_ = C.c_double(), C.c_double()
+            check(lib().cz_probe_mfma_peak(ctx.h, code, data, 4000, C.byref(tf), C.byref(ms_)), "cz_probe_mfma_peak")
+            out_[name] = {"tflops": tf.value, "ms": ms_.value}
+        out_["what"] = ("back-to-back v_mfma_f32_32x32x16_%s on register operands, 2 waves per SIMD, every CU, measured in this run right "
+                        "after the timed regions (cz_probe_mfma_peak): what the MFMA pipes sustain on this box under its power governor" % ("f16" if code == 2 else "bf16"))
+        return out_
+
+    def trunk_roofline(conv_ms_, n_launches, issued_factor, kernel_name, clock_, telemetry_):
+        nl_ = 2 * args.blocks
+        conv_flops_ = float(trunk_flops_per_pos) * rows_per_launch
+        ach = conv_flops_ / (conv_ms_ * 1e-3) / 1e12
+        r = {"bound": "mfma", "kernel": kernel_name,
+             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+             "us_per_launch": conv_ms_ * 1e3, "launches_timed": n_launches, "flops_per_launch": conv_flops_,
+             "flops_per_position": trunk_flops_per_pos, "conv_layers_per_launch": nl_ + 3,
+             "mfma_flops_issued_per_algorithmic_flop": issued_factor}
+        if clock_:
+            r["effective_clock_GHz"] = clock_["effective_clock_GHz"]
+            r["nominal_clock_GHz"] = 2.4
+            r["clock_scaled_peak"] = peak * clock_["effective_clock_GHz"] / 2.4
+            r["frac_of_clock_scaled_peak"] = ach / r["clock_scaled_peak"]
+            r["mfma_issue_frac_of_clock_scaled_peak"] = ach * issued_factor / r["clock_scaled_peak"]
+            r["clock_probe"] = clock_
+        if telemetry_:
+            r["power_W"] = telemetry_.get("power_W")
+            r["sclk_MHz_driver"] = telemetry_.get("sclk_MHz")
+            r["telemetry"] = telemetry_
+        return r
+    mfma_peak_measured = None
+    if fused and rank == 0:
+        try:
+            mfma_peak_measured = mfma_probe()
+        except Exception as e:
+            mfma_peak_measured = {"error": repr(e)}
     if conv_ev:
         # dominant kernel: the fused trunk (one launch = first conv + all tower layers + head convs over the whole batch)
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
-        nl = 2 * args.blocks if net.backend == "hip" else 1   # fused tower: one launch = all 2*blocks conv layers
-        conv_flops = 2.0 * rows_per_launch * 90 * 1152 * 128 * nl
-        kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv3x3+BN(+residual)+ReLU layers counted, LDS-resident activations, %s MFMA, fp32 acc)" % (nl, args.dtype)
-                 if net.backend == "hip" else "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)")
-        roof = {"bound": "mfma", "kernel": kname,
-                "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "us_per_launch": conv_ms * 1e3, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops,
-                "net_forward_ms_per_step": net_ms, "net_forward_tflops": flops / (net_ms * 1e-3) / 1e12,
-                # context, not a live measurement: what back-to-back MFMAs with operands in registers sustain on this chip
-                # under its power limit (tools/mfma_peak.hip, profiles/r03f_mfma_peak_f16.log), and that three schedules of
-                # this kernel whose cycle counts differ by 7 % run within 1.5 % of each other in time
-                "power_limited_reference": {"bare_mfma_tflops_random_data": {"bf16": 1734.0, "fp16": 1709.0}[args.dtype] if args.dtype in ("bf16", "fp16") else None,
-                                            "bare_mfma_tflops_half_zero_data": {"bf16": 1908.0, "fp16": 1884.0}[args.dtype] if args.dtype in ("bf16", "fp16") else None,
-                                            "source": "profiles/r03f_mfma_peak_f16.log; DESIGN.md 8: the kernel is bounded by energy per position, not by issue slots"}}
+        if net.backend == "hip":
+            kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv layers, LDS-resident activations, %s MFMA, fp32 acc)" % (2 * args.blocks + 3, args.dtype))
+            roof = trunk_roofline(conv_ms, len(conv_ev), 3.0 if split else 1.0, kname, clock, telemetry)
+            roof["net_forward_ms_per_step"] = net_ms
+            roof["net_forward_tflops"] = flops / (net_ms * 1e-3) / 1e12
+            roof["mfma_peak_measured"] = mfma_peak_measured
+            if mfma_peak_measured and "dense_random_operands" in mfma_peak_measured:
+                roof["frac_of_measured_mfma_peak_half_zero"] = roof["achieved"] * roof["mfma_flops_issued_per_algorithmic_flop"] / mfma_peak_measured["half_zero_operands"]["tflops"]
+        else:
+            conv_flops = 2.0 * rows_per_launch * 90 * 1152 * 128
+            roof = {"bound": "mfma", "kernel": "k_conv3x3_c128 (fused conv3x3+BN+residual+ReLU, bf16 MFMA, fp32 acc)",
+                    "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                    "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "us_per_launch": conv_ms * 1e3, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops}
     else:
         achieved = flops / (net_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "net forward via torch/MIOpen (conv tower + heads), all launches of one step",
@@ -620,11 +704,31 @@ def main():
                            "game_generations": s["games"] / float(G), "timed_gather": bool(args.timed_gather and dist_on),
                            "gathers": gather_stats["gathers"], "gathered_records": gather_stats["records"],
                            "gather_seconds_rank0": gather_stats["seconds"]}
+    strict_out = None
+    if strict_leg is not None:
+        leg, s_ev, net_s = strict_leg
+        s_sims, s_rows, s_pr = totals(leg)
+        strict_out = {"engine": "k_trunk_split_c128: every weight and stored activation as fp16 hi + lo halves, three MFMAs per product (bench.py --dtype strict times it on its own)" if net_s.dtype == torch.float16 else "k_trunk_split_c128, bf16 halves",
+                      "steps": args.strict_steps, "seconds": leg[0], "value": s_sims / leg[0], "unit": "sims/s",
+                      "ms_per_step": leg[0] / args.strict_steps * 1e3, "net_rows_per_s": s_rows / leg[0], "per_rank_sims_per_s": s_pr,
+                      "meets_target_1e6_sims_per_s_per_gpu": bool(s_sims / leg[0] / world >= 1e6),
+                      "note": "third barrier-bracketed timed region: the same trees and loop with the strict engine swapped in (same weights)"}
+        if s_ev:
+            s_ms = float(np.mean([a.elapsed_time(b) for a, b in s_ev]))
+            strict_out["roofline"] = trunk_roofline(s_ms, len(s_ev), 3.0, "k_trunk_split_c128", None, None)
+    # headline: the LONG leg (steady_state) when it ran — the K contract steps (the driver's K = 20 is 47 ms) read a percent
+    # or two off it and are kept as contract_steps
+    contract = {"steps": args.steps, "seconds": dt, "value": total_sims / dt, "ms_per_step": dt / args.steps * 1e3,
+                "note": "the EXACTLY-K-steps region of the bench contract (barrier + synchronize on both sides, max over ranks)"}
+    head_val, head_ms, head_src = total_sims / dt, dt / args.steps * 1e3, "contract_steps"
+    if steady_out is not None:
+        head_val, head_ms, head_src = steady_out["value"], steady_out["ms_per_step"], "steady_state"
     out = {
         "metric": "MCTS simulations/sec (whole node), playout=%d, %d-block net" % (playout, args.blocks),
-        "value": total_sims / dt, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic", "steady_state": steady_out, "net_error": None, "config": cfg,
+        "value": head_val, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head_ms, "value_source": head_src, "contract_steps": contract,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic", "steady_state": steady_out, "strict_engine": strict_out, "net_error": None, "config": cfg,
         "roofline": roof, "roofline_tree": tree_roof, "roofline_rules": None,
     }
     if rank == 0:
@@ -640,6 +744,14 @@ def main():
             net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split=split)
             trained_like_(net_t, xs[:96])
             ne["trained_like"] = net_error(net_t, xs)
+            ne["meets_1e-3_abs_logit_and_value_trained_like"] = bool(ne["trained_like"]["dlogit"] <= 1e-3 and ne["trained_like"]["dvalue"] <= 1e-3)
+            if strict_leg is not None:
+                net_s = strict_leg[2]
+                se = {"as_benchmarked_glorot": net_error(net_s, xs)}
+                net_ts = PolicyValueNet(args.blocks, dev, net_s.dtype, backend="hip", ctx=ctx, split=True, module=net_t.module)
+                se["trained_like"] = net_error(net_ts, xs)
+                se["meets_1e-3_abs_logit_and_value"] = bool(max(se[k][q] for k in ("as_benchmarked_glorot", "trained_like") for q in ("dlogit", "dvalue")) <= 1e-3)
+                out["strict_engine"]["net_error"] = se
         except Exception as e:
             out["net_error"] = {"error": repr(e)}
         try:

@@ -51,6 +51,9 @@ _SIGS = {
     "cz_search_expand_backup_fc": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, C.c_int]),
     "cz_search_select_compact": (C.c_int, [C.c_void_p, C.c_int, _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "cz_set_batch_count": (C.c_int, [C.c_void_p, _vp]),
+    "cz_probe_mfma_peak": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "cz_set_clock_probe": (C.c_int, [C.c_void_p, _vp, C.c_int]),
+    "cz_clock_probe_last_grid": (C.c_int, [C.c_void_p]),
     "cz_search_eval_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "cz_search_set_width": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_set_sim_target": (C.c_int, [C.c_void_p, C.c_int]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcchess_hip.so")
-SOURCES = ["cz_api.hip", "cz_tables.hip", "cz_rules.hip", "cz_search.hip", "cz_selfplay.hip", "cz_conv.hip", "cz_heads.hip"]
+SOURCES = ["cz_api.hip", "cz_tables.hip", "cz_rules.hip", "cz_search.hip", "cz_selfplay.hip", "cz_conv.hip", "cz_heads.hip", "cz_probe.hip"]
 # -ffp-contract=off and correctly rounded f32 divide: the tree statistics are bit-exact
 # restatements of the reference's float32/float64 arithmetic.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -20,6 +20,13 @@ extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, 
     return CZ_OK;
 }
 
+// cz_set_clock_probe: the trunk kernels stamp every workgroup's start / end in both clocks when the buffer holds the grid
+static unsigned long long *clock_probe(cz_ctx *c, int grid) {
+    if (!c->clock_probe || grid > c->clock_probe_wgs) return nullptr;
+    c->clock_probe_last_grid = grid;
+    return c->clock_probe;
+}
+
 static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float *bias, void *out, const float *head_w,
                         const float *head_b, float *head_out, int B, int nblocks, const void *planes = nullptr,
                         const void *w0 = nullptr, const float *b0 = nullptr, bool f16 = false) {
@@ -35,11 +42,11 @@ static int launch_tower(cz_ctx *c, const void *in, const void *wpk, const float 
     if (f16)
         hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                           (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
+                           (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count, clock_probe(c, grid));
     else
         hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, c->stream, (const uint16_t *)in,
                            (const uint16_t *)wpk, bias, (uint16_t *)out, head_w, head_b, head_out, (const uint16_t *)planes,
-                           (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count);
+                           (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count, clock_probe(c, grid));
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
@@ -93,11 +100,21 @@ extern "C" int cz_net_trunk_split(cz_ctx *c, const void *planes16, const void *w
     if (halves_dtype == CZ_F16)
         hipLaunchKernelGGL((k_trunk_split_c128<true>), dim3(grid), dim3(XS_THREADS), XS_LDS_BYTES, c->stream, (const uint16_t *)wpk, bias,
                            trunk_out, head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks,
-                           c->batch_count);
+                           c->batch_count, clock_probe(c, grid));
     else
         hipLaunchKernelGGL((k_trunk_split_c128<false>), dim3(grid), dim3(XS_THREADS), XS_LDS_BYTES, c->stream, (const uint16_t *)wpk, bias,
                            trunk_out, head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks,
-                           c->batch_count);
+                           c->batch_count, clock_probe(c, grid));
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
+
+extern "C" int cz_set_clock_probe(cz_ctx *c, unsigned long long *buf_dev, int max_workgroups) {
+    CZ_REQUIRE(c && max_workgroups >= 0, "cz_set_clock_probe: null context");
+    c->clock_probe = buf_dev;
+    c->clock_probe_wgs = buf_dev ? max_workgroups : 0;
+    c->clock_probe_last_grid = 0;
+    return CZ_OK;
+}
+
+extern "C" int cz_clock_probe_last_grid(cz_ctx *c) { return c ? c->clock_probe_last_grid : 0; }

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
                                                               const uint16_t *__restrict__ w0,
                                                               const float *__restrict__ b0,
                                                               int B, int nlayers,
-                                                              const int *__restrict__ bcount) {   // device row count or NULL
+                                                              const int *__restrict__ bcount,    // device row count or NULL
+                                                              unsigned long long *__restrict__ clk) {   // clock probe [grid][4] or NULL (cz_set_clock_probe)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Geo = XSGeo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -119,6 +120,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
         B = live < B ? live : B;
     }
     if (pos0 >= B) return;
+    // measurement hook (bench.py roofline.effective_clock_GHz): workgroup lifetime in shader-clock cycles (s_memtime) and in
+    // the constant 100 MHz reference clock (s_memrealtime); four scalar registers, one uniform branch when the probe is off
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int npos = (B - pos0) < Geo::P ? (B - pos0) : Geo::P;
     const int nrows = npos * 90;
     const int nslabs = nlayers * Geo::SLABS_PER_LAYER;
@@ -322,6 +327,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
         refresh_rb();
         store_layer(acc);
         __syncthreads();
+    }
+    if (clk && tid == 0) {   // the layers are done; the epilogue below (trunk dump / head convs) is ~1 % of the workgroup's life
+        clk[blockIdx.x * 4 + 0] = clk_c0; clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
+        clk[blockIdx.x * 4 + 2] = clk_r0; clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (out) {   // trunk activations as fp32 = hi + lo, 8 channels per thread and step

@@ -339,6 +339,20 @@ int cz_net_trunk_split(cz_ctx *, const void *planes16, const void *w0, const flo
                        const float *bias, float *trunk_out, const float *head_w, const float *head_b,
                        float *head_out, int B, int nblocks, int halves_dtype);
 
+/* Measurement hook for bench.py (roofline.effective_clock_GHz): while buf_dev is set, every workgroup w of the following
+ * cz_net_trunk_* launches (grids up to max_workgroups) writes buf_dev[4w .. 4w+3] = {shader-clock cycle counter at its start,
+ * at the end of its last layer, 100 MHz reference clock at the same two points}: cycles / (ticks * 10 ns) is the clock the
+ * kernel really ran at under the chip's power governor.  NULL switches it off (the default; one uniform branch per
+ * workgroup).  cz_clock_probe_last_grid: workgroups of the last probed launch. */
+int cz_set_clock_probe(cz_ctx *, unsigned long long *buf_dev, int max_workgroups);
+int cz_clock_probe_last_grid(cz_ctx *);
+
+/* Measurement: back-to-back v_mfma_f32_32x32x16 (dtype CZ_BF16 | CZ_F16) on register operands, two waves per SIMD, every CU:
+ * the practical MFMA ceiling of this chip under its power governor, measured in the bench run itself (tools/mfma_peak.hip
+ * is the stand-alone form).  data: 0 dense random operands, 1 zeros, 2 random with half the elements zero; iters x 48
+ * MFMAs per wave.  *tflops, *ms: dense-equivalent TFLOP/s and duration of the (second) launch.  Synchronises the stream. */
+int cz_probe_mfma_peak(cz_ctx *, int dtype, int data, int iters, double *tflops, double *ms);
+
 /* The three fully connected layers behind the head convolutions (policy_value_network.py:62-63,72-74): policy FC
  * 180 -> 2086 (raw logits) and value FC 90 -> 256, ReLU, FC 256 -> 1, tanh, from the head conv outputs
  * z [B][90][3] f32 as cz_net_trunk_bf16 / cz_tower_heads_c128_bf16 leave them (flatten order (h,w,c)).

@@ -33,3 +33,25 @@ if sp:
 print("  sims per net row %s  terminal_extra %s  eval_cache %s  net rows/s %s" % (d["config"].get("simulations_per_net_row"), d["config"].get("terminal_extra"), d["config"].get("eval_cache"), d["config"].get("net_rows_per_s")))
 print("  per rank:", d["config"].get("per_rank_sims_per_s"), "backend", d["config"].get("dist_backend"), "gather", d["config"].get("record_gather"),
       "status", d["config"].get("status_bits"))
+cs = d.get("contract_steps")
+if cs:
+    print("  value from %s; contract steps: %.0f sims/s over %d steps (%.3f ms/step)" % (d.get("value_source"), cs["value"], cs["steps"], cs["ms_per_step"]))
+if "effective_clock_GHz" in r:
+    print("  trunk clock %.3f GHz (in-kernel stamps, %d launches), clock-scaled peak %.0f TF -> frac %.3f (MFMA issue %.3f); power %s W, driver sclk %s MHz (%s samples)" % (
+        r["effective_clock_GHz"], r["clock_probe"]["launches_probed"], r["clock_scaled_peak"], r["frac_of_clock_scaled_peak"], r["mfma_issue_frac_of_clock_scaled_peak"],
+        r.get("power_W"), r.get("sclk_MHz_driver"), (r.get("telemetry") or {}).get("samples")))
+mp = r.get("mfma_peak_measured")
+if mp and "dense_random_operands" in mp:
+    print("  measured MFMA ceiling of this box: %.0f TF dense random, %.0f TF half zeros" % (mp["dense_random_operands"]["tflops"], mp["half_zero_operands"]["tflops"]))
+elif mp:
+    print("  mfma_peak_measured:", mp)
+se = d.get("strict_engine")
+if se:
+    print("  strict engine: %.0f sims/s over %d steps (%.3f ms/step), target met: %s" % (se["value"], se["steps"], se["ms_per_step"], se["meets_target_1e6_sims_per_s_per_gpu"]))
+    if "roofline" in se:
+        print("    trunk %.1f us, %.0f TF algorithmic (frac %.3f)" % (se["roofline"]["us_per_launch"], se["roofline"]["achieved"], se["roofline"]["frac"]))
+    for k, e in (se.get("net_error") or {}).items():
+        if isinstance(e, dict):
+            print("    net_error %-22s dlogit %.3g dvalue %.3g argmax %.3f" % (k, e["dlogit"], e["dvalue"], e["argmax_agree"]))
+        else:
+            print("    %s: %s" % (k, e))
