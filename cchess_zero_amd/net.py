@@ -508,6 +508,30 @@ class PolicyValueNet:
                                     vp(logits), vp(value), B), "cz_fc_heads_f32")
         return logits, value
 
+    @torch.no_grad()
+    def range_check(self, planes_nhwc=None, raise_on_nonfinite=True):
+        """After new weights (restore()): evaluate the start position (or the given planes) and look at what the engine makes
+        of them.  The fp16 kernels saturate at 65504 instead of producing inf (k_tower8_c128: packed min on the store;
+        k_trunk_split_c128: clamp before the split), so a checkpoint with huge activations cannot poison the priors with
+        NaN — but a saturated tower is no longer the reference's function: warn when the trunk comes within a factor of two
+        of the half range (use precision "bf16x2" / "fp32" for such weights), raise when an output is not finite.
+        -> {"max_activation", "finite"}."""
+        import warnings
+        if planes_nhwc is None:
+            x = torch.zeros((1, 9, 10, 14), dtype=torch.float32, device=self.device)
+            x[0, 0, 4, 0] = 1.0   # any plane pattern will do; the check is about the weights' scale
+            x[0, 8, 4, 7] = 1.0
+        else:
+            x = torch.as_tensor(np.asarray(planes_nhwc, dtype=np.float32)).to(self.device)
+        logits, v = self.forward_device(x)
+        finite = bool(torch.isfinite(logits).all()) and bool(torch.isfinite(v).all())
+        peak = float(self.tower(x).float().abs().max())
+        if self.dtype == torch.float16 and peak > 32752.0:
+            warnings.warn("trunk activations reach %.3g: the fp16 engine saturates at 65504; use precision 'bf16x2' or 'fp32' for these weights" % peak)
+        if not finite and raise_on_nonfinite:
+            raise FloatingPointError("the net's outputs are not finite for these weights (peak trunk activation %.3g)" % peak)
+        return {"max_activation": peak, "finite": finite}
+
     @property
     def fused_search(self):
         """True when the search loop may skip the full policy FC (SearchEngine.step -> expand_backup_fc)."""

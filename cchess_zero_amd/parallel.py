@@ -63,23 +63,40 @@ class RecordExchange:
         self.carry = torch.zeros((0, REC_BYTES), dtype=torch.uint8, device=self.device)
         self.exchanges = 0
         self._last = None
+        # buffers are allocated once: the send block, and TWO receive blocks used alternately, so that the tensor handed out
+        # by one exchange stays valid until the exchange after the next (the consumer looks at it whenever it wants)
+        self._send = torch.zeros((self.capacity + 1, REC_BYTES), dtype=torch.uint8, device=self.device)
+        self._out = [torch.empty((self.world, self.capacity + 1, REC_BYTES), dtype=torch.uint8, device=self.device) for _ in range(2)]
 
     def exchange(self, rec):
-        """rec: uint8 [n, REC_BYTES] on the collective's device (n is known on the host: it is a tensor shape)."""
+        """rec: uint8 [n, REC_BYTES] on the collective's device (n is known on the host: it is a tensor shape).  Returns the
+        gathered [world, capacity + 1, REC_BYTES] block (row 0 of each rank: its count); valid until the next-but-one call."""
         rec = rec.reshape(-1, REC_BYTES)
         if self.carry.shape[0]:
             rec = torch.cat([self.carry, rec], 0)
         n = min(rec.shape[0], self.capacity)
-        send = torch.zeros((self.capacity + 1, REC_BYTES), dtype=torch.uint8, device=self.device)
-        send[0, :8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(self.device, non_blocking=True)
+        send = self._send
+        send[0, :8].view(torch.int64).fill_(n)          # a fill kernel with a scalar argument: no host-to-device copy
         if n:
             send[1:1 + n] = rec[:n]
         self.carry = rec[n:].clone() if rec.shape[0] > n else rec[:0]
-        out = torch.empty((self.world, self.capacity + 1, REC_BYTES), dtype=torch.uint8, device=self.device)
+        out = self._out[self.exchanges & 1]
         dist.all_gather_into_tensor(out.view(self.world * (self.capacity + 1), REC_BYTES), send, group=self.group)
         self.exchanges += 1
         self._last = out
         return out
+
+    def flush(self):
+        """Drain what the capacity held back: exchanges of empty shards until no rank has rows pending (the ranks agree on that
+        with one all-reduce per round — this is for the END of a run, outside any timed region).  Returns the gathered blocks
+        (clones).  A consumer that stops calling exchange() must call this, or the carried rows are lost."""
+        outs = []
+        while True:
+            t = torch.tensor([self.pending()], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            if int(t.item()) == 0:
+                return outs
+            outs.append(self.exchange(self.carry[:0]).clone())
 
     def pending(self):
         """Records held back because the last shard exceeded the capacity (sent by the next exchange)."""

@@ -633,6 +633,9 @@ if __name__ == '__main__':
     # additions (not in the reference): size of the lock-step game pool per GPU, bounded runs for scripts
     parser.add_argument('--games', default=256, type=int, help='parallel self-play games per GPU')
     parser.add_argument('--max_batches', default=None, type=int, help='stop after this many self-play batches')
+    parser.add_argument('--net_precision', default=None, choices=['strict', 'fp16', 'bf16', 'bf16x2', 'fp32'], type=str,
+                        help='net engine (policy_value_network.PRECISIONS): strict (default) = fp16 hi+lo halves, within 1e-3 of '
+                             'the reference fp32 graph on any weights; fp16 = 2.8x faster, 1e-3 only relative to the logit scale')
     args = parser.parse_args()
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # launched by torch.distributed.run: one rank per GPU
@@ -643,12 +646,30 @@ if __name__ == '__main__':
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from cchess_zero_amd import parallel as _pl
-        _pl.pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))   # own CPUs per rank
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("CCHESS_ALL_ON_DEVICE0"):   # tests: the N>1 code path on a one-GPU box (with CCHESS_DIST_BACKEND=gloo)
+            local_rank = 0
+            torch.cuda.set_device(0)
+        cpus = _pl.pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))   # own CPUs per rank
+        torch.set_num_threads(max(1, min(4, len(cpus) if cpus else 2)))   # the intra-op pools were sized for the whole box
+        if os.environ.get("CCHESS_DIST_BACKEND", "nccl") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.net_precision:
+        os.environ["CCHESS_NET_PRECISION"] = args.net_precision
 
     if args.mode == 'train':
         train_main = cchess_main(args.train_playout, args.batch_size, True, args.search_threads, args.processor, args.num_gpus,
                                  args.res_block_nums, args.human_color, games=args.games)
         train_main.run(args.max_batches)
+        if os.environ.get("CCHESS_WEIGHT_DIGEST_DIR"):   # tests: every rank leaves a digest of its replica (they must be equal)
+            import hashlib
+            import torch
+            h = hashlib.sha256()
+            for k_, v_ in sorted(train_main.policy_value_netowrk.module.state_dict().items()):
+                h.update(k_.encode())
+                h.update(v_.detach().cpu().numpy().tobytes())
+            with open(os.path.join(os.environ["CCHESS_WEIGHT_DIGEST_DIR"], "rank%s.txt" % os.environ.get("RANK", "0")), "w") as f:
+                f.write("%s %d %d\n" % (h.hexdigest(), train_main.global_step, len(train_main.data_buffer)))
     elif args.mode == 'play':
         _play_headless(args)

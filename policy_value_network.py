@@ -27,11 +27,27 @@ from cchess_zero_amd.train import Trainer
 
 
 class policy_value_network(object):
-    def __init__(self, res_block_nums=7, device=None, dtype=torch.float16, save_dir="./models", seed=0):
-        """dtype: the tower's MFMA operand type.  fp16 (default) keeps forward() within the 1e-3 the hot path is specified
-        to (policy_value_network.py:202-214 is fp32 TF): |dlogit| 1.2e-4 on TF-default weights, 1.1e-3 of the largest
-        logit on peaked weights, 7 blocks; torch.float32 selects the torch/MIOpen fp32 engine (1e-7 .. 3e-5), bf16 the
-        same MFMA rate at 8x the error (tests/test_net.py)."""
+    PRECISIONS = {"strict": (torch.float16, True), "fp16x2": (torch.float16, True), "bf16x2": (torch.bfloat16, True),
+                  "fp16": (torch.float16, False), "bf16": (torch.bfloat16, False), "fp32": (torch.float32, False)}
+
+    def __init__(self, res_block_nums=7, device=None, dtype=None, save_dir="./models", seed=0, precision=None):
+        """precision (or the environment's CCHESS_NET_PRECISION; default "strict"): which engine evaluates the net.
+          "strict" (= "fp16x2")  every weight and stored activation as fp16 hi + lo halves, three MFMAs per product
+                                 (k_trunk_split_c128): forward() within 1e-3 ABSOLUTE of the reference's fp32 sess.run
+                                 (policy_value_network.py:202-214) on every weight set tested, trained-like peaked weights
+                                 and 19 blocks included (measured 7e-5 / 2e-4) — the drop-in default; 1.28 M simulations/s;
+          "fp16"                 one fp16 per operand (k_tower8_c128): 2.8x the rate (3.6 M simulations/s), 1.2e-4 on
+                                 TF-default weights, 1.3e-2 absolute (1.1e-3 of the largest logit) on peaked weights;
+          "bf16"                 the same rate + 3 %, 8x the error;   "bf16x2": strict with bf16 halves (2e-4 / 7e-4);
+          "fp32"                 torch/MIOpen fp32 (1e-7 .. 3e-5), not a kernel of this library.
+        dtype (older callers): a torch dtype selects the one-value-per-operand engine of that type."""
+        if dtype is not None:
+            split = False
+        else:
+            name = precision or os.environ.get("CCHESS_NET_PRECISION", "strict")
+            if name not in self.PRECISIONS:
+                raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+            dtype, split = self.PRECISIONS[name]
         if not torch.cuda.is_available():
             raise RuntimeError("policy_value_network needs an MI355X (HIP) device; the cchess_hip path has no CPU fallback")
         self.save_dir = save_dir
@@ -43,7 +59,7 @@ class policy_value_network(object):
         self.global_norm = 100
         self.max_to_keep = 5
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-        self.net = PolicyValueNet(res_block_nums, self.device, dtype, seed=seed)
+        self.net = PolicyValueNet(res_block_nums, self.device, dtype, seed=seed, split=split)
         self.module = self.net.module
         self.trainer = Trainer(self.module, self.c_l2, self.momentum, self.global_norm)
         self.train_restore()
@@ -124,6 +140,7 @@ class policy_value_network(object):
         else:
             self.trainer.load_state_dict(torch.load(file, map_location=self.device))
         self.net.refresh()
+        self.net.range_check()   # restored weights: finite outputs, activations inside the fp16 range (else it says so)
 
     def save(self, in_global_step):
         os.makedirs(self.save_dir, exist_ok=True)

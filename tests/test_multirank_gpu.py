@@ -1,0 +1,99 @@
+"""The N > 1 code path ON THE GPU BOX: the driver's 8-GPU launch must not be the first time this code runs
+against a device.  One MI355X is available to the tests, so two ranks share cuda:0 and talk over gloo (RCCL cannot put two
+ranks on one device); RCCL itself is exercised with a world of one (--force-dist): communicator set-up, all_gather_into_tensor /
+all_reduce / barrier on device tensors.  What the tests pin is the plumbing that does not depend on the transport: rank
+sharding of the games, the barrier + max-over-ranks timing, the fixed-capacity record exchange inside the timed region,
+the data-parallel policy update (policy_value_network_gpus.py:216-250: gradient averaging; main.py:1240: data_buffer.extend of
+every rank's games) leaving every replica with identical weights."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _keep_logs(name, p):
+    """A failing child's full output goes where the GPU session's scratch is merged back from (pytest truncates long messages)."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out", "testlogs")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".txt"), "w") as f:
+            f.write("rc %s\n==== stdout\n%s\n==== stderr\n%s\n" % (p.returncode, p.stdout, p.stderr))
+    except Exception:
+        pass
+
+
+def _bench(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, env=env,
+                       timeout=timeout, stdin=subprocess.DEVNULL)
+    if p.returncode != 0:
+        _keep_logs("bench_" + "_".join(a.strip("-") for a in args[:6]), p)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]     # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_selfplay_with_timed_record_exchange():
+    d = _bench(["--gpus", "2", "--all-on-device0", "--dist-backend", "gloo", "--selfplay", "--timed-gather", "--games", "512",
+                "--playout", "40", "--steps", "64", "--warmup", "8", "--age-steps", "64", "--steady-steps", "0", "--no-cpu-baseline"])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    assert len(c["per_rank_sims_per_s"]) == 2 and all(v > 0 for v in c["per_rank_sims_per_s"])
+    assert c["record_gather"] is True
+    sp = c["selfplay"]
+    assert sp["timed_gather"] is True and sp["gathers"] >= 1 and sp["gathered_records"] > 0
+    assert sp["stalled_games"] == 0 and sp["dropped_records"] == 0
+    assert c["trees_with_error_status"] == 0
+    # whole-job value: the two ranks' simulations over the slowest rank's time
+    assert d["value"] > max(c["per_rank_sims_per_s"]) and d["value"] <= sum(c["per_rank_sims_per_s"]) * 1.001
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_search_loop_default_engine():
+    """The default loop (search, aged trees, steady leg, strict leg) with two ranks: both legs carry two per-rank figures."""
+    d = _bench(["--gpus", "2", "--all-on-device0", "--dist-backend", "gloo", "--games", "512", "--playout", "64", "--steps", "24",
+                "--warmup", "4", "--age-steps", "48", "--steady-steps", "48", "--strict-steps", "16", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["value_source"] == "steady_state"
+    assert len(d["steady_state"]["per_rank_sims_per_s"]) == 2 and len(d["strict_engine"]["per_rank_sims_per_s"]) == 2
+    assert d["contract_steps"]["steps"] == 24 and d["config"]["record_gather"] is True
+    assert d["config"]["trees_with_error_status"] == 0
+    assert d["strict_engine"]["net_error"]["meets_1e-3_abs_logit_and_value"] is True
+
+
+@pytest.mark.gpu
+def test_bench_rccl_world_of_one():
+    """RCCL (backend "nccl") with a world of 1: process-group set-up on the device, the timed all-gather of records, barriers."""
+    d = _bench(["--force-dist", "--selfplay", "--timed-gather", "--games", "512", "--playout", "40", "--steps", "64", "--warmup", "8",
+                "--age-steps", "64", "--steady-steps", "0", "--no-cpu-baseline"])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["dist_backend"] == "nccl" and c["record_gather"] is True
+    assert c["selfplay"]["gathers"] >= 1 and c["selfplay"]["gathered_records"] > 0 and c["trees_with_error_status"] == 0
+
+
+@pytest.mark.gpu
+def test_train_two_ranks_end_with_identical_weights(tmp_path):
+    """`torchrun --nproc-per-node 2 main.py --mode train`: each rank plays its own games, the records are all-gathered, the
+    policy update is data-parallel (gradients averaged, control flow rank-consistent): afterwards both replicas hold the same
+    bits, the same global step and the same replay buffer length."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(CCHESS_DIST_BACKEND="gloo", CCHESS_ALL_ON_DEVICE0="1", CCHESS_WEIGHT_DIGEST_DIR=str(tmp_path),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "main.py"), "--mode", "train", "--games", "128", "--train_playout", "20",
+           "--batch_size", "64", "--res_block_nums", "2", "--max_batches", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=900, stdin=subprocess.DEVNULL)
+    if p.returncode != 0:
+        _keep_logs("train_two_ranks", p)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read().split() for r in range(2)]
+    assert got[0] == got[1], got                     # weights digest, global step, buffer length
+    assert int(got[0][1]) >= 1 and int(got[0][2]) > 64
+    assert "samples:" in p.stdout and "kl:" in p.stdout
