@@ -159,27 +159,37 @@ def cpu_baseline(blocks, seconds_target=12.0):
 
 
 def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
-    """K1 on its own (48 B board in + 264 B mask out = 312 B/position, HBM-bound in principle): cz_movegen_mask
-    over n positions (the run's synthetic positions, tiled), HIP events around `reps` launches."""
+    """K1 on its own (48 B board in + 264 B mask out = 312 B/position, HBM-bound in principle): cz_movegen over n
+    positions (the run's synthetic positions, tiled), HIP events around `reps` launches.  Headline: the mask-only kernel
+    (moves = NULL: k_movegen_mask, one position per lane) — what §8(d)'s 312 B describe; beside it the ordered-list kernel
+    (k_movegen, list + mask: the reference's get_legal_moves contract)."""
     G = boards.shape[0]
     b = boards.repeat((n + G - 1) // G, 1)[:n].contiguous()
     sd = side.repeat((n + G - 1) // G)[:n].contiguous()
-    rules.movegen(b, sd, want_mask=True)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        rules.movegen(b, sd, want_mask=True)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / reps
+
+    def timed(**kw):
+        rules.movegen(b, sd, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            rules.movegen(b, sd, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    sec = timed(want_mask=True, want_moves=False)
+    sec_list = timed(want_mask=True, want_moves=True)
     alg = 312.0 * n
-    abi = (90 + 1 + 256 + 264 + 2) * float(n)
-    return {"bound": "hbm", "kernel": "k_movegen (stand-alone K1: ordered move list + 2086-bit mask; inside the search the generator runs in k_select)",
+    abi = (90 + 1 + 264 + 2) * float(n)
+    abi_list = (90 + 1 + 256 + 264 + 2) * float(n)
+    return {"bound": "hbm", "kernel": "k_movegen_mask (stand-alone K1, the legal-move SET: 2086-bit mask + count, one position per lane, register bit sets; inside the search the ordered generator runs in k_select)",
             "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "positions": n, "positions_per_s": n / sec, "us_per_launch": sec * 1e6, "algorithmic_bytes_per_position": 312,
             "abi_bytes_per_position": abi / n, "abi_GBps": abi / sec / 1e9,
-            "note": "issue-bound (VALU + LDS round trips of the per-piece generator), not bandwidth-bound: see DESIGN.md"}
+            "ordered_list_kernel": {"kernel": "k_movegen (ordered move list in the reference's generation order + mask, four positions per wave)",
+                                    "positions_per_s": n / sec_list, "us_per_launch": sec_list * 1e6, "achieved": alg / sec_list / 1e9,
+                                    "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "abi_bytes_per_position": abi_list / n, "abi_GBps": abi_list / sec_list / 1e9,
+                                    "note": "issue-bound (VALU + LDS round trips of the per-piece generator and the ordering), not bandwidth-bound: see DESIGN.md"}}
 
 
 def self_launch(n):

@@ -1,5 +1,6 @@
 // cz_api.hip — the extern "C" boundary of libcchess_hip.so (declared in include/cchess_hip.h).
 #include "cz_internal.h"
+#include "cz_maskgen.h"
 
 #include <stdarg.h>
 #include <string.h>
@@ -128,6 +129,12 @@ int cz_create(int device, int max_games, int max_nodes_per_tree, cz_ctx **out) {
         CZ_HIP(hipMemcpy(sd, ht.srcdst, sizeof(ht.srcdst), hipMemcpyHostToDevice));
         CZ_HIP(hipMemcpy(zb, ht.zob, sizeof(ht.zob), hipMemcpyHostToDevice));
         c->tab.lut = lut; c->tab.unflip = unf; c->tab.srcdst = sd; c->tab.zob = zb;
+        CzmTables mt;   // the mask-only generator's per-square tables, derived from the label LUT
+        czm_build_tables(ht.lut, &mt);
+        CzmTables *dmt = nullptr;
+        if (hipMalloc(&dmt, sizeof(CzmTables)) != hipSuccess) { cz_set_error("cz_create: hipMalloc(mask tables) failed"); delete c; return CZ_ENOMEM; }
+        CZ_HIP(hipMemcpy(dmt, &mt, sizeof(mt), hipMemcpyHostToDevice));
+        c->mask_tab = dmt;
     }
     // per-tree arrays
     {
@@ -165,6 +172,7 @@ void cz_destroy(cz_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->pend_block) (void)hipFree(c->pend_block);
     if (c->tab_block) (void)hipFree(c->tab_block);
+    if (c->mask_tab) (void)hipFree(const_cast<CzmTables *>(c->mask_tab));
     if (c->tree_block) (void)hipFree(c->tree_block);
     if (c->pool_block) (void)hipFree(c->pool_block);
     if (c->sp_block) (void)hipFree(c->sp_block);

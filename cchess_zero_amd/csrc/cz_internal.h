@@ -147,6 +147,7 @@ struct cz_ctx {
     int sim_target;    // cz_search_set_sim_target: completed simulations per tree a k > 1 search stops at (0: no limit)
     int step_parity;   // which evcnt entry the current compact step uses
     const int32_t *batch_count;  // cz_set_batch_count: device row count bounding the net launches, or NULL
+    const struct CzmTables *mask_tab;  // cz_maskgen.h tables on the device (k_movegen_mask)
     unsigned long long *clock_probe;  // cz_set_clock_probe: [clock_probe_wgs][4] stamps written by the trunk kernels, or NULL
     int clock_probe_wgs, clock_probe_last_grid;
     CzSelfplay sp;     // cz_selfplay_begin

@@ -18,13 +18,14 @@ class Rules:
             return a.to(self.dev).to(dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a)).to(self.dev).to(dtype).contiguous()
 
-    def movegen(self, boards, side, want_mask=True):
-        """GameBoard.get_legal_moves for G positions -> (moves [G,128] i16(u16 bits), count [G], mask [G,66] i32)."""
+    def movegen(self, boards, side, want_mask=True, want_moves=True):
+        """GameBoard.get_legal_moves for G positions -> (moves [G,128] i16(u16 bits), count [G], mask [G,66] i32).
+        want_moves=False: only the legal-move SET (mask) and the count — the mask-only kernel (k_movegen_mask), moves is None."""
         self.ctx.bind_stream()   # torch's current stream
         boards = self._dev(boards, torch.uint8).reshape(-1, NSQ)
         side = self._dev(side, torch.uint8)
         G = boards.shape[0]
-        moves = torch.empty((G, MAXMOVES), dtype=torch.int16, device=self.dev)
+        moves = torch.empty((G, MAXMOVES), dtype=torch.int16, device=self.dev) if want_moves else None
         count = torch.empty(G, dtype=torch.int16, device=self.dev)
         mask = torch.empty((G, MASK_WORDS), dtype=torch.int32, device=self.dev) if want_mask else None
         check(lib().cz_movegen(self.ctx.h, _ptr(boards), _ptr(side), G, _ptr(moves), _ptr(count), _ptr(mask)), "cz_movegen")

@@ -65,7 +65,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cchess_zero_amd", "csrc")
     flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
     hot = {"cz_conv.hip": ["k_tower8_c128", "k_trunk_split_c128"], "cz_search.hip": ["k_select", "k_expand_backup", "k_advance", "k_root_stats"],
-           "cz_heads.hip": ["k_policy_fc", "k_value_fc"], "cz_rules.hip": ["k_movegen", "k_encode_planes"],
+           "cz_heads.hip": ["k_policy_fc", "k_value_fc"], "cz_rules.hip": ["k_movegen", "k_movegen_mask", "k_encode_planes"],
            "cz_selfplay.hip": ["k_sp_choose", "k_sp_adjudicate", "k_sp_flush"]}
 
     def asm(src):
@@ -83,7 +83,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
                 assert int(m.group(2)) == 0, "%s uses %s bytes of scratch" % (m.group(1), m.group(2))
                 checked += 1
     # 2 + 2 trunk instantiations; 4 select + 2 select_k + 3 expand + 2 expand_k + advance + root_stats; 2 heads; 3 rules; 3 self-play
-    assert checked >= 4 + 13 + 2 + 3 + 3, checked
+    assert checked >= 4 + 13 + 2 + 3 + 3, checked   # (k_movegen also matches k_movegen_mask)
 
 
 def test_generated_slab_asm_is_in_sync(tmp_path):

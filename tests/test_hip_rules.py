@@ -17,11 +17,9 @@ def _u16(t):
     return t.cpu().numpy().view(np.uint16)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lane"])
-def test_movegen_golden(rules, rules_golden, kernel, monkeypatch):
-    """Ordered move lists, counts and 2086-bit masks of 4 381 reference positions; `kernel`: four positions per wave
-    (k_movegen, small batches) or one position per lane (k_movegen_tp, the default from 4 096 positions on)."""
-    monkeypatch.setenv("CCHESS_MOVEGEN", kernel)
+def test_movegen_golden(rules, rules_golden):
+    """Ordered move lists, counts and 2086-bit masks of 4 381 reference positions (k_movegen: four positions per wave); and the
+    same masks and counts from the mask-only kernel (k_movegen_mask: one position per lane, no list)."""
     g = rules_golden
     moves, count, mask = rules.movegen(g["boards"], g["side"])
     moves, count, mask = _u16(moves), _u16(count), mask.cpu().numpy().view(np.uint32)
@@ -33,6 +31,11 @@ def test_movegen_golden(rules, rules_golden, kernel, monkeypatch):
         for l in g["moves"][i, :count[i]]:
             exp[i, l >> 5] |= np.uint32(1) << np.uint32(l & 31)
     assert np.array_equal(mask, exp)
+    none, count2, mask2 = rules.movegen(g["boards"], g["side"], want_moves=False)
+    assert none is None and np.array_equal(_u16(count2), g["counts"])
+    assert np.array_equal(mask2.cpu().numpy().view(np.uint32), exp)
+    _, count3, nomask = rules.movegen(g["boards"], g["side"], want_mask=False, want_moves=False)   # counts only
+    assert nomask is None and np.array_equal(_u16(count3), g["counts"])
 
 
 def test_apply_move_golden(rules, rules_golden):
@@ -70,12 +73,11 @@ def test_planes_golden(rules, rules_golden):
     assert torch.equal(ph[..., :14].float().cpu(), torch.from_numpy(p32)) and float(ph[..., 14:].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lane"])
-def test_rules_vs_oracle_large_corpus(rules, kernel, monkeypatch):
+def test_rules_vs_oracle_large_corpus(rules):
     """Seeded random playouts driven entirely on the GPU (movegen -> pick -> apply), every position
-    cross-checked against the C oracle: ordered moves, next board, hash, planes."""
+    cross-checked against the C oracle: ordered moves, next board, hash, planes; and at every ply the mask-only kernel's
+    masks and counts for ALL 2 048 positions against the list kernel's (82 k positions)."""
     from oracle import oracle as O
-    monkeypatch.setenv("CCHESS_MOVEGEN", kernel)
     rng = np.random.default_rng(1234)
     G = 2048
     boards = torch.from_numpy(np.tile(O.fen_to_board(O.START_FEN), (G, 1))).cuda()
@@ -83,7 +85,9 @@ def test_rules_vs_oracle_large_corpus(rules, kernel, monkeypatch):
     zt, zs = O.zobrist_table()
     checked = 0
     for ply in range(40):
-        moves, count, _ = rules.movegen(boards, side, want_mask=False)
+        moves, count, lmask = rules.movegen(boards, side)
+        _, mcount, mmask = rules.movegen(boards, side, want_moves=False)
+        assert torch.equal(mcount, count) and torch.equal(mmask, lmask)
         hb, hs = boards.cpu().numpy(), side.cpu().numpy()
         mv, cnt = _u16(moves), _u16(count)
         planes = rules.encode_planes(boards, side).cpu().numpy()
@@ -117,32 +121,60 @@ def test_rules_edge_sizes(rules):
     assert int(_u16(c)[0]) == 44
 
 
-@pytest.mark.parametrize("G", [1, 63, 64, 65, 130, 4097])
-def test_movegen_lane_kernel_ragged_sizes_and_alignment(rules, rules_golden, G, monkeypatch):
-    """k_movegen_tp on batch sizes around its 64-position groups, with the boards at an even and at an ODD byte address
-    (the ABI promises byte alignment only: the odd case takes the byte-load path), list and mask or list only — against
-    the golden lists; rows beyond the batch are not touched."""
+@pytest.mark.parametrize("G", [1, 3, 4, 5, 63, 64, 65, 130, 4097])
+def test_movegen_ragged_sizes_and_alignment_raw_abi(rules, rules_golden, G):
+    """cz_movegen through the raw C-ABI on batch sizes around the kernels' group sizes (4 positions per wave for the list
+    kernel, 64 for the mask-only kernel), with the boards at a 16-byte-aligned, an even and an ODD byte address (the ABI promises
+    byte alignment only), and the mask at a 16-byte-aligned and a 4-byte-aligned address: list + mask, list only, mask only,
+    count only — against the golden lists; rows beyond the batch are not touched."""
     from cchess_zero_amd._lib import check, lib
     from cchess_zero_amd.engine import _ptr
-    monkeypatch.setenv("CCHESS_MOVEGEN", "lane")
     g = rules_golden
     idx = (np.arange(G) * 37) % len(g["boards"])
-    for off in (0, 1):
-        raw = torch.zeros(G * 90 + 2, dtype=torch.uint8, device="cuda")
+    exp = np.zeros((G, 66), np.uint32)
+    for i in range(G):
+        for l in g["moves"][idx[i], :g["counts"][idx[i]]]:
+            exp[i, l >> 5] |= np.uint32(1) << np.uint32(l & 31)
+    for off in (0, 2, 1):
+        raw = torch.zeros(G * 90 + 16, dtype=torch.uint8, device="cuda")
         raw[off:off + G * 90] = torch.from_numpy(g["boards"][idx].reshape(-1)).cuda()
         boards = raw[off:off + G * 90]
         side = torch.from_numpy(g["side"][idx]).cuda()
-        moves = torch.full((G + 2, 128), 0x1234, dtype=torch.int16, device="cuda")
-        count = torch.full((G + 2,), 0x1234, dtype=torch.int16, device="cuda")
-        mask = torch.full((G + 2, 66), 0x55, dtype=torch.int32, device="cuda")
-        for want_mask in (True, False):
-            check(lib().cz_movegen(rules.ctx.h, _ptr(boards), _ptr(side), G, _ptr(moves), _ptr(count), _ptr(mask) if want_mask else None), "cz_movegen")
-            mv, ct = _u16(moves), _u16(count)
-            assert np.array_equal(ct[:G], g["counts"][idx]) and np.array_equal(mv[:G], g["moves"][idx])
-            assert (mv[G:] == 0x1234).all() and (ct[G:] == 0x1234).all()
-        mk = mask.cpu().numpy().view(np.uint32)
-        exp = np.zeros((G, 66), np.uint32)
-        for i in range(G):
-            for l in g["moves"][idx[i], :g["counts"][idx[i]]]:
-                exp[i, l >> 5] |= np.uint32(1) << np.uint32(l & 31)
-        assert np.array_equal(mk[:G], exp) and (mk[G:] == 0x55).all()
+        for moff in (0, 1):
+            for want_moves, want_mask in ((True, True), (True, False), (False, True), (False, False)):
+                moves = torch.full((G + 2, 128), 0x1234, dtype=torch.int16, device="cuda")
+                count = torch.full((G + 2,), 0x1234, dtype=torch.int16, device="cuda")
+                mraw = torch.full(((G + 2) * 66 + 4,), 0x55, dtype=torch.int32, device="cuda")
+                mask = mraw[moff:moff + (G + 2) * 66].view(G + 2, 66)
+                check(lib().cz_movegen(rules.ctx.h, _ptr(boards), _ptr(side), G, _ptr(moves) if want_moves else None, _ptr(count),
+                                       _ptr(mask) if want_mask else None), "cz_movegen")
+                mv, ct = _u16(moves), _u16(count)
+                assert np.array_equal(ct[:G], g["counts"][idx]) and (ct[G:] == 0x1234).all()
+                if want_moves:
+                    assert np.array_equal(mv[:G], g["moves"][idx]) and (mv[G:] == 0x1234).all()
+                else:
+                    assert (mv == 0x1234).all()
+                mk = mask.cpu().numpy().view(np.uint32)
+                if want_mask:
+                    assert np.array_equal(mk[:G], exp) and (mk[G:] == 0x55).all()
+                else:
+                    assert (mk == 0x55).all()
+
+
+def test_movegen_mask_kernel_flags_unexpressible_positions(rules):
+    """Both kernels answer 0xFFFF for a position the move vocabulary cannot express: 17 pieces of the side to move; an advisor
+    off the palace's diagonal points whose step (e2 -> d1) has no label."""
+    from oracle import oracle as O
+    b = O.fen_to_board(O.START_FEN)
+    many = b.copy()
+    many[4 * 9 + 4] = 6               # a sixth red pawn on e4: 17 red pieces
+    adv = b.copy()
+    adv[3], adv[2 * 9 + 4] = 0, 2     # the red advisor from d0 to e2: e2 -> d1 / f1 are inside the palace and unlabelled
+    boards = np.stack([b, many, adv])
+    side = np.zeros(3, np.uint8)
+    _, c_list, _ = rules.movegen(boards, side)
+    _, c_mask, _ = rules.movegen(boards, side, want_moves=False)
+    cl, cm = _u16(c_list), _u16(c_mask)
+    assert cl[0] == 44 and cm[0] == 44
+    assert cl[1] == 0xFFFF and cm[1] == 0xFFFF
+    assert cl[2] == 0xFFFF and cm[2] == 0xFFFF

@@ -1,0 +1,72 @@
+"""cz_maskgen.h (the mask-only move generator cz_movegen runs when moves == NULL: one lane = one position, bit sets in
+registers) compiled for the HOST and held, on the CPU, to the golden move lists of the unmodified reference (4 381 positions,
+tests/golden/rules.npz) and to the C oracle on seeded random playouts — the same function the GPU kernel k_movegen_mask
+inlines, so its rules are pinned without a GPU; tests/test_hip_rules.py then pins the kernel around it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("maskgen") / "libmaskgen_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "maskgen_host.cpp")])
+    lib = C.CDLL(so)
+    from oracle import oracle as O
+    lut = np.ascontiguousarray(O.lut(), np.int16)
+    tab = (C.c_uint8 * lib.czm_host_sizeof_tables())()
+    lib.czm_host_tables(lut.ctypes.data_as(C.c_void_p), tab)
+
+    def masks(boards, side):
+        boards = np.ascontiguousarray(boards, np.uint8).reshape(-1, 90)
+        side = np.ascontiguousarray(side, np.uint8)
+        n = len(boards)
+        m = np.zeros((n, 66), np.uint32)
+        c = np.zeros(n, np.int32)
+        lib.czm_host_masks(tab, boards.ctypes.data_as(C.c_void_p), side.ctypes.data_as(C.c_void_p), n, m.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+        return m, c
+    return masks
+
+
+def _mask_of(moves):
+    m = np.zeros(66, np.uint32)
+    for l in moves:
+        m[int(l) >> 5] |= np.uint32(1) << np.uint32(int(l) & 31)
+    return m
+
+
+def test_maskgen_matches_reference_golden_lists(host, rules_golden):
+    g = rules_golden
+    m, c = host(g["boards"], g["side"])
+    assert np.array_equal(c, g["counts"].astype(np.int32))
+    exp = np.stack([_mask_of(g["moves"][i, :g["counts"][i]]) for i in range(len(c))])
+    bad = np.nonzero((m != exp).any(axis=1))[0]
+    assert len(bad) == 0, (len(bad), bad[:5])
+    assert int(np.unpackbits(m.view(np.uint8), axis=1).sum()) == int(g["counts"].sum())
+
+
+def test_maskgen_matches_oracle_on_random_playouts(host):
+    """Seeded uniform-random playouts with the C oracle (both colours, captures, kings facing, pieces on every edge): the mask
+    and the count at every ply, ~12 000 positions."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(99)
+    boards, sides, want = [], [], []
+    for game in range(160):
+        b, s = O.fen_to_board(O.START_FEN), 0
+        for ply in range(110):
+            mv = O.legal_moves(b, s)
+            boards.append(b.copy()); sides.append(s); want.append(mv)
+            if len(mv) == 0 or not (b == 1).any() or not (b == 8).any():
+                break
+            b = O.apply_move(b, int(mv[rng.integers(len(mv))]))[0]
+            s ^= 1
+    m, c = host(np.stack(boards), np.array(sides, np.uint8))
+    assert len(boards) > 8000
+    for i in range(len(boards)):
+        assert c[i] == len(want[i]), i
+        assert np.array_equal(m[i], _mask_of(want[i])), i
