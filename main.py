@@ -643,12 +643,11 @@ if __name__ == '__main__':
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("CCHESS_ALL_ON_DEVICE0"):   # tests: the N>1 code path on a one-GPU box (with CCHESS_DIST_BACKEND=gloo)
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from cchess_zero_amd import parallel as _pl
-        if os.environ.get("CCHESS_ALL_ON_DEVICE0"):   # tests: the N>1 code path on a one-GPU box (with CCHESS_DIST_BACKEND=gloo)
-            local_rank = 0
-            torch.cuda.set_device(0)
         cpus = _pl.pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))   # own CPUs per rank
         torch.set_num_threads(max(1, min(4, len(cpus) if cpus else 2)))   # the intra-op pools were sized for the whole box
         if os.environ.get("CCHESS_DIST_BACKEND", "nccl") == "gloo":
