@@ -702,7 +702,7 @@ def main():
            "games_per_gpu": G, "playout": playout, "conv_backend": net.backend, "policy_fc": "in-expansion, legal moves only" if fused_fc else "full 2086 logits",
            "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "hip_graph": graph[0] is not None, "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
            "positions": "seeded random playouts from the start position, ply~U[0,80]",
-           "nodes_per_tree": cap, "node_pool_GB": G * cap * 28 / 1e9,
+           "nodes_per_tree": cap, "node_pool_GB": G * cap * 30 / 1e9,
            "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "rank0_cpus": cpus, "per_rank_sims_per_s": per_rank,
            "simulations_counted": total_sims, "net_rows": total_rows,
            "simulations_per_net_row": total_sims / max(1.0, total_rows), "terminal_extra": TE, "advance_every": args.advance_every,

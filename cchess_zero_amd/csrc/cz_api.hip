@@ -33,7 +33,7 @@ struct Carver {
 void carve_pool(Carver &c, CzPool &p, size_t n) {
     p.P = c.take<float>(n); p.W = c.take<float>(n); p.Q = c.take<float>(n);
     p.N = c.take<int32_t>(n); p.parent = c.take<int32_t>(n); p.child_begin = c.take<int32_t>(n);
-    p.child_count = c.take<uint16_t>(n); p.move = c.take<uint16_t>(n);
+    p.child_count = c.take<uint16_t>(n); p.move = c.take<uint16_t>(n); p.sd = c.take<uint16_t>(n);
 }
 
 void carve_trees(Carver &c, CzTrees &t, size_t G, size_t words) {
@@ -300,6 +300,11 @@ int cz_search_debug_eval_cache_key_bits(cz_ctx *c, int bits) {
     CZ_REQUIRE(c && (bits == 64 || (bits >= 8 && bits <= 24)), "cz_search_debug_eval_cache_key_bits: bits must be 8..24 or 64");
     // narrowed keys keep the 7-bit bucket field (bits 17..23) plus the bits - 7 lowest bits: entries still spread over the buckets
     c->t.ec_key_mask = bits == 64 ? ~0ull : ((0x7Full << 17) | ((1ull << (bits - 7)) - 1ull));
+    return CZ_OK;
+}
+int cz_search_debug_advance_in_global_memory(cz_ctx *c, int on) {
+    CZ_REQUIRE(c, "cz_search_debug_advance_in_global_memory: null context");
+    c->adv_force_global = on != 0;
     return CZ_OK;
 }
 int cz_search_eval_cache_collisions(cz_ctx *c, unsigned long long *collisions) {

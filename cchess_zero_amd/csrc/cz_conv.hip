@@ -2,7 +2,6 @@
 #include "cz_internal.h"
 #include "cz_conv_kernel.h"
 #include "cz_trunk_split.h"
-#include <stdlib.h>
 
 extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, const void *residual,
                                     void *out, int B, int relu) {

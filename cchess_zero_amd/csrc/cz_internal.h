@@ -46,6 +46,7 @@ struct CzPool {
     float *P, *W, *Q;
     int32_t *N, *parent, *child_begin;
     uint16_t *child_count, *move;
+    uint16_t *sd;   // src | dst << 8 of `move` (k_select applies the move without the label -> (src, dst) table round trip)
 };
 
 // cz_selfplay_*: per game slot, the (s, pi, z) records of the game in progress (cchess_main.selfplay keeps
@@ -140,6 +141,7 @@ struct cz_ctx {
     void *tree_block;  // single allocation behind the per-tree arrays
     void *pool_block;
     bool adv_attr_set;   // dynamic-LDS opt-in of k_advance_lds done
+    bool adv_force_global;   // cz_search_debug_advance_in_global_memory (tests): take the path of pools whose bitmap exceeds LDS
     bool conv_attr_set, tower_attr_set, split_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1
@@ -160,6 +162,7 @@ struct TreeView {
     float *P, *W, *Q;
     int32_t *N, *parent, *child_begin;
     uint16_t *child_count, *move;
+    uint16_t *sd;   // src | dst << 8 of `move` (k_select applies the move without the label -> (src, dst) table round trip)
 };
 
 __device__ __forceinline__ TreeView view_of(const CzTrees &t, int g) {
@@ -168,14 +171,14 @@ __device__ __forceinline__ TreeView view_of(const CzTrees &t, int g) {
     TreeView v;
     v.P = p.P + base; v.W = p.W + base; v.Q = p.Q + base;
     v.N = p.N + base; v.parent = p.parent + base; v.child_begin = p.child_begin + base;
-    v.child_count = p.child_count + base; v.move = p.move + base;
+    v.child_count = p.child_count + base; v.move = p.move + base; v.sd = p.sd + base;
     return v;
 }
 
 __device__ __forceinline__ void init_root(TreeView v, int idx) {
     v.P[idx] = 1.0f;  // p_ = 0.75 + 0.25 * dirichlet([0.3]) == 1 (quirk Q4), main.py:238
     v.W[idx] = 0.f; v.Q[idx] = 0.f; v.N[idx] = 0; v.parent[idx] = -1; v.child_begin[idx] = -1;
-    v.child_count[idx] = 0; v.move[idx] = 0xFFFF;
+    v.child_count[idx] = 0; v.move[idx] = 0xFFFF; v.sd[idx] = 0;
 }
 
 // evaluation cache: forget everything tree g knows (fresh root: reset / reload / re-seed / failed advance)

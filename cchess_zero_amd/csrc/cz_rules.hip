@@ -3,7 +3,6 @@
 // kernels: no MFMA here by design.
 #include "cz_internal.h"
 #include "cz_maskgen.h"
-#include <stdlib.h>
 
 namespace {
 

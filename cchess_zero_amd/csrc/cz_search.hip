@@ -13,7 +13,6 @@
 #include "cz_internal.h"
 
 #include <math.h>
-#include <stdlib.h>
 
 namespace {
 
@@ -211,7 +210,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                         if (i < cc) {
                             cP[r] = v.P[cb + i]; cN[r] = v.N[cb + i]; cQ[r] = v.Q[cb + i];
                             cBeg[r] = v.child_begin[cb + i]; cCnt[r] = v.child_count[cb + i];
-                            cSd[r] = tab.srcdst[v.move[cb + i]];
+                            cSd[r] = v.sd[cb + i];   // (src, dst) stored with the node: no label -> table round trip on the descent
                         }
                     }
 #pragma unroll
@@ -282,8 +281,9 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                         const unsigned long long ek = t.ec_key[eb0 + lane];
                         const int en = t.ec_node[eb0 + lane];
                         const float ev = t.ec_val[eb0 + lane];
-                        const unsigned long long m = __ballot(ek == key);
-                        if (m) {
+                        // every entry of the bucket with the leaf's key is a candidate (after a key collision two positions
+                        // share a key): the stored position decides
+                        for (unsigned long long m = __ballot(ek == key); m; m &= m - 1ull) {
                             const int hl = __ffsll((long long)m) - 1;
                             // the candidate's position against the leaf's: 12 lanes, one dword each
                             const uint32_t lb = lane < 12 ? t.ec_board[(eb0 + hl) * 12 + lane] : 0u;
@@ -291,9 +291,9 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                                 src = __builtin_amdgcn_readlane(en, hl);
                                 pend = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), hl));
                                 hit = true;
-                            } else if (lane == 0) {
-                                t.ec_collisions[g] += 1u;   // same key, another position: treated as a miss
+                                break;
                             }
+                            if (lane == 0) t.ec_collisions[g] += 1u;   // same key, another position: not this entry
                         }
                         if (lane == 0) { t.ec_hits[g] += hit ? 1u : 0u; t.ec_lookups[g] += 1u; }
                     }
@@ -306,7 +306,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                             const int i = lane + 64 * r;
                             if (i < n) {
                                 const int c = begin + i;
-                                v.P[c] = v.P[scb + i]; v.move[c] = v.move[scb + i];
+                                v.P[c] = v.P[scb + i]; v.move[c] = v.move[scb + i]; v.sd[c] = v.sd[scb + i];
                                 v.W[c] = 0.f; v.Q[c] = 0.f; v.N[c] = 0; v.parent[c] = leaf; v.child_begin[c] = -1;
                                 v.child_count[c] = 0;
                             }
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
                     const int c = begin + i;
                     v.P[c] = pr[i] / tot;  // n.P /= tot_p, main.py:186-187
                     v.W[c] = 0.f; v.Q[c] = 0.f; v.N[c] = 0; v.parent[c] = leaf; v.child_begin[c] = -1;
-                    v.child_count[c] = 0; v.move[c] = lab[r];
+                    v.child_count[c] = 0; v.move[c] = lab[r]; v.sd[c] = tab.srcdst[lab[r]];
                 }
             }
             if (lane == 0) { v.child_begin[leaf] = begin; v.child_count[leaf] = (uint16_t)n; t.n_nodes[g] = begin + n; }
@@ -578,9 +578,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
             const unsigned long long key = t.pend_key[g];
             const size_t eb0 = (size_t)g * CZ_EC_ENTRIES + (size_t)ec_bucket(key) * 64;
             const unsigned long long ek = t.ec_key[eb0 + lane];
-            if (__ballot(ek == key) == 0ull) {
+            // already remembered?  Only an entry with this key AND this position counts (the lookup may have been skipped by
+            // its per-launch budget); a same-key entry holding ANOTHER position — a key collision — does not keep this one out
+            bool have = false;
+            const uint32_t mine = lane < 12 ? t.pend_board[(size_t)g * 12 + lane] : 0u;
+            for (unsigned long long m = __ballot(ek == key); m && !have; m &= m - 1ull) {
+                const int hl = __ffsll((long long)m) - 1;
+                const uint32_t lb = lane < 12 ? t.ec_board[(eb0 + hl) * 12 + lane] : 0u;
+                have = __ballot(lb != mine) == 0ull;
+            }
+            if (!have) {
                 const unsigned long long em = __ballot(ek == 0ull);
-                const int slot = em ? __ffsll((long long)em) - 1 : (int)((key >> 40) & 63);
+                int slot = em ? __ffsll((long long)em) - 1 : (int)((key >> 40) & 63);
                 if (lane == slot) { t.ec_key[eb0 + lane] = key; t.ec_node[eb0 + lane] = leaf; t.ec_val[eb0 + lane] = val; }
                 if (lane < 12) t.ec_board[(eb0 + slot) * 12 + lane] = t.pend_board[(size_t)g * 12 + lane];
             }
@@ -717,8 +726,8 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
                     int bi = best.i;
                     if (__shfl((int)first_nan, 0, 64)) bi = 0;
                     const int c = cb + bi;
-                    const int l = v.move[c];
-                    const int src = tab.srcdst[l] & 0xFF, dst = tab.srcdst[l] >> 8;
+                    const int sdc = v.sd[c];
+                    const int src = sdc & 0xFF, dst = sdc >> 8;
                     const int cap = b[dst];
                     __syncthreads();
                     if (lane == 0) {
@@ -840,7 +849,7 @@ __global__ __launch_bounds__(64) void k_expand_backup_k(CzTrees t, CzTables tab,
                     const int c = begin + i;
                     v.P[c] = pr[i] / tot;
                     v.W[c] = 0.f; v.Q[c] = 0.f; v.N[c] = 0; v.parent[c] = leaf; v.child_begin[c] = -1;
-                    v.child_count[c] = 0; v.move[c] = lab[r];
+                    v.child_count[c] = 0; v.move[c] = lab[r]; v.sd[c] = tab.srcdst[lab[r]];
                 }
             }
             if (lane == 0) { v.child_begin[leaf] = begin; v.child_count[leaf] = (uint16_t)n; t.n_nodes[g] = begin + n; }
@@ -1012,10 +1021,10 @@ __global__ __launch_bounds__(256) void k_advance_global(CzTrees t, CzTables tab,
         const bool keep = i < n && mark_tst(bits, i);
         float nP = 0.f, nW = 0.f, nQ = 0.f;
         int nN = 0, np = -1, ncb = -1;
-        uint16_t ncc = 0, nmv = 0;
+        uint16_t ncc = 0, nmv = 0, nsd = 0;
         if (keep) {
             nP = v.P[i]; nW = v.W[i]; nQ = v.Q[i]; nN = v.N[i]; np = v.parent[i]; ncb = v.child_begin[i];
-            ncc = v.child_count[i]; nmv = v.move[i];
+            ncc = v.child_count[i]; nmv = v.move[i]; nsd = v.sd[i];
         }
         __syncthreads();   // the whole chunk is in registers before any of its slots is overwritten
         if (keep) {
@@ -1023,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_advance_global(CzTrees t, CzTables tab,
             v.P[o] = nP; v.W[o] = nW; v.Q[o] = nQ; v.N[o] = nN;
             v.parent[o] = i == found ? -1 : mark_rank_of(bits, rank, np);
             v.child_begin[o] = ncb >= 0 ? mark_rank_of(bits, rank, ncb) : -1;
-            v.child_count[o] = ncc; v.move[o] = nmv;
+            v.child_count[o] = ncc; v.move[o] = nmv; v.sd[o] = nsd;
         }
     }
     if (tid == 0) {
@@ -1159,22 +1168,22 @@ __device__ __forceinline__ void advance_tree_lds(const CzTrees &t, const CzTable
     // whose loads are therefore issued before this chunk's stores)
     float nP = 0.f, nW = 0.f, nQ = 0.f;
     int nN = 0, np = -1, ncb = -1;
-    uint16_t ncc = 0, nmv = 0;
+    uint16_t ncc = 0, nmv = 0, nsd = 0;
     bool nkeep = first + tid < n && lmark_tst(bits, first + tid);
     if (nkeep) {
         const int i = first + tid;
-        nP = v.P[i]; nW = v.W[i]; nQ = v.Q[i]; nN = v.N[i]; np = v.parent[i]; ncb = v.child_begin[i]; ncc = v.child_count[i]; nmv = v.move[i];
+        nP = v.P[i]; nW = v.W[i]; nQ = v.Q[i]; nN = v.N[i]; np = v.parent[i]; ncb = v.child_begin[i]; ncc = v.child_count[i]; nmv = v.move[i]; nsd = v.sd[i];
     }
     for (int base = first; base < n; base += CZ_ADV_T) {
         const int i = base + tid;
         const bool keep = nkeep;
         const float cP = nP, cW = nW, cQ = nQ;
         const int cN = nN, cp = np, ccb = ncb;
-        const uint16_t ccc = ncc, cmv = nmv;
+        const uint16_t ccc = ncc, cmv = nmv, csd = nsd;
         const int in = i + CZ_ADV_T;
         nkeep = in < n && lmark_tst(bits, in);
         if (nkeep) {
-            nP = v.P[in]; nW = v.W[in]; nQ = v.Q[in]; nN = v.N[in]; np = v.parent[in]; ncb = v.child_begin[in]; ncc = v.child_count[in]; nmv = v.move[in];
+            nP = v.P[in]; nW = v.W[in]; nQ = v.Q[in]; nN = v.N[in]; np = v.parent[in]; ncb = v.child_begin[in]; ncc = v.child_count[in]; nmv = v.move[in]; nsd = v.sd[in];
         }
         __syncthreads();   // every thread holds its node of this chunk (loaded one iteration ago) before any slot of it is overwritten
         if (keep) {
@@ -1182,7 +1191,7 @@ __device__ __forceinline__ void advance_tree_lds(const CzTrees &t, const CzTable
             v.P[o] = cP; v.W[o] = cW; v.Q[o] = cQ; v.N[o] = cN;
             v.parent[o] = i == found ? -1 : lmark_rank_of(bits, rank, cp);
             v.child_begin[o] = ccb >= 0 ? lmark_rank_of(bits, rank, ccb) : -1;
-            v.child_count[o] = ccc; v.move[o] = cmv;
+            v.child_count[o] = ccc; v.move[o] = cmv; v.sd[o] = csd;
         }
     }
     if (tid == 0) {
@@ -1301,7 +1310,7 @@ int czk_search_advance(cz_ctx *c, const uint16_t *played) {
     // bitmap + ranks of one tree in LDS: 12 bytes per 64 nodes (38 KB for the bench's 205 056-node pools)
     const size_t lds = (size_t)c->t.words * 12;
     const size_t lds_max = 150 * 1024;   // 160 KB per CU minus the kernel's static LDS; the attribute is per function, so always the maximum
-    if (lds <= lds_max && !getenv("CCHESS_ADVANCE_GLOBAL")) {
+    if (lds <= lds_max && !c->adv_force_global) {
         if (!c->adv_attr_set) {
             CZ_HIP(hipFuncSetAttribute((const void *)k_advance_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             c->adv_attr_set = true;

@@ -212,6 +212,9 @@ int cz_search_set_eval_cache(cz_ctx *, int on);
 int cz_search_eval_cache_stats(cz_ctx *, unsigned long long *hits, unsigned long long *lookups);
 int cz_search_eval_cache_collisions(cz_ctx *, unsigned long long *collisions);
 int cz_search_debug_eval_cache_key_bits(cz_ctx *, int bits);
+/* tests: cz_search_advance keeps the kept-node bitmap of a tree in LDS when it fits (12 bytes per 64 nodes) and in global memory
+ * otherwise; on != 0 forces the global-memory kernel so that it is exercised at test sizes. */
+int cz_search_debug_advance_in_global_memory(cz_ctx *, int on);
 int cz_search_select_k(cz_ctx *, int mode, int k, const uint8_t *active, void *leaf_planes, int dtype,
                        int channels, uint8_t *needs_eval);
 int cz_search_expand_backup_k(cz_ctx *, int k, const void *logits, const void *value, int dtype);

@@ -187,21 +187,24 @@ def test_fused_step_configs2_full_length_1600_playouts_vs_oracle():
 # inference, not of the kernels, whose arithmetic the two tests above pin exactly.  The thresholds sit just below the
 # measured levels (10-15 trees of 1024: the fp32 side runs MIOpen's convolutions, whose choice of kernel — and with it the
 # last bits of the fp32 logits — is not the same on every box): a numerically worse kernel fails.
-_AGREE = {"bf16": (torch.bfloat16, 0.93, 0.10), "fp16": (torch.float16, 0.975, 0.025)}
+# The STRICT engine (fp16 hi + lo halves, k_trunk_split_c128) is within 4e-5 of the fp32 logits on these weights: the
+# searches must agree like two fp32 evaluations do — >= 0.999 of the most visited root moves, visit L1 <= 0.002.
+_AGREE = {"bf16": (torch.bfloat16, 0.93, 0.10, False), "fp16": (torch.float16, 0.975, 0.025, False),
+          "strict": (torch.float16, 0.999, 0.002, True)}
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "strict"])
 def test_fused_search_agrees_with_fp32_engine(dname):
-    """The fused 16-bit net vs the fp32 engine (torch/MIOpen fp32 convs, full logits) on the same 1024 roots, 400
-    playouts, trained-like weights: the root move a self-play game would most likely play (most visited child) and the
-    visit distributions (L1 distance) are compared."""
+    """The fused 16-bit net (and the strict split engine) vs the fp32 engine (torch/MIOpen fp32 convs, full logits) on the same
+    1024 roots, 400 playouts, trained-like weights: the root move a self-play game would most likely play (most visited child)
+    and the visit distributions (L1 distance) are compared."""
     from cchess_zero_amd.engine import SearchEngine
     from cchess_zero_amd.net import PolicyValueModule, PolicyValueNet
-    dtype, min_agree, max_l1 = _AGREE[dname]
+    dtype, min_agree, max_l1, split = _AGREE[dname]
     G, playouts = 1024, 400
     boards, side, rr = _positions(G, 77)
     mod = PolicyValueModule(7, seed=3)
-    a = PolicyValueNet(7, "cuda:0", dtype, module=mod)
+    a = PolicyValueNet(7, "cuda:0", dtype, module=mod, split=split)
     nethelpers.trained_like_(a)
     b = PolicyValueNet(7, "cuda:0", torch.float32, module=a.module, backend="torch")
     ea = SearchEngine(G, (playouts + 2) * 80, plane_dtype=dtype, channels=16)

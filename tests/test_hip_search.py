@@ -63,13 +63,11 @@ def test_search_matches_reference_at_depth(mcts_deep_golden):
 
 
 @pytest.mark.parametrize("mode,advance", [("pos", "lds"), ("signed", "lds"), ("pos", "global")])
-def test_search_vs_oracle_batch(rules_golden, mode, advance, monkeypatch):
+def test_search_vs_oracle_batch(rules_golden, mode, advance):
     """256 trees from corpus positions, 3 plies x 48 playouts, device-resident loop; compared with the
     oracle: needs_eval + planes every step, root stats and whole-tree dumps after each ply.  advance: the in-place
     compaction of cz_search_advance with the bitmap in LDS (default) or in global memory (pools too large for LDS)."""
     from oracle import oracle as O
-    if advance == "global":
-        monkeypatch.setenv("CCHESS_ADVANCE_GLOBAL", "1")
     g = rules_golden
     ok = [(g["boards"][i] == 1).any() and (g["boards"][i] == 8).any() and g["counts"][i] > 0 for i in range(len(g["boards"]))]
     idx = np.nonzero(ok)[0][::11][:256]
@@ -78,6 +76,9 @@ def test_search_vs_oracle_batch(rules_golden, mode, advance, monkeypatch):
     rr = (np.arange(G) * 7 % 61).astype(np.int32)
     rr[::5] = 57
     hip = _HipEngine(G, 20000)
+    if advance == "global":
+        from cchess_zero_amd._lib import check, lib
+        check(lib().cz_search_debug_advance_in_global_memory(hip.e.ctx.h, 1), "cz_search_debug_advance_in_global_memory")
     orc = O.Search(G, 20000)
     hip.reset(boards, side, rr)
     orc.reset(boards, side, rr)
