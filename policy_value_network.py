@@ -108,7 +108,13 @@ class policy_value_network(object):
             os.makedirs(self.save_dir, exist_ok=True)
         c = self._ckpts()
         tf_ckpt = tf_checkpoint.latest_checkpoint(self.save_dir)   # tf.train.get_checkpoint_state(save_dir), :165-168
-        if c:
+        # both kinds may sit in one directory (a model directory of the reference that this code has trained on since, or the
+        # other way round after export_tf_checkpoint): the NEWEST one — the larger global step — is the model
+        tf_step = -1
+        if tf_ckpt:
+            m = re.search(r"ckpt-(\d+)$", tf_ckpt)
+            tf_step = int(m.group(1)) if m else 0
+        if c and c[-1][0] >= tf_step:
             self.restore(c[-1][1])
             print("Successfully loaded:", c[-1][1])
         elif tf_ckpt:   # a model directory written by the reference itself (tf.train.Saver: checkpoint + .index + .data)

@@ -169,6 +169,15 @@ def test_facade_restores_a_tf_model_directory(tmp_path):
     assert sorted(back) == sorted(v)
     for k in v:
         assert back[k].dtype == v[k].dtype and np.array_equal(back[k], v[k]), k
+    # both kinds in one directory: the newest (larger global step) is the model — first a .pt at step 300 beside the TF
+    # checkpoint of step 250, then a TF export at step 400 beside that .pt
+    pv2.global_step = 300
+    pv2.save_dir = str(mdir)
+    pv2.save(300)
+    assert policy_value_network(2, save_dir=str(mdir), seed=7).global_step == 300
+    pv2.global_step = 400
+    pv2.export_tf_checkpoint(save_dir=str(mdir))
+    assert policy_value_network(2, save_dir=str(mdir), seed=7).global_step == 400
 
 
 def test_product_writer_equals_the_independent_writer_byte_for_byte(tmp_path):
@@ -211,3 +220,105 @@ def test_trainer_momentum_slots_round_trip():
     assert all(np.array_equal(s1[k], s2[k]) for k in s1)
     for p, q in zip(m.parameters(), m2.parameters()):
         assert torch.equal(tr.opt.state[p]["momentum_buffer"], tr2.opt.state[q]["momentum_buffer"])
+
+
+# ---- known answers from the PUBLISHED specifications (not from this repo's own writer) ---------------------------------------------
+# The reader above is otherwise checked against tests/tf_bundle_writer.py, written by the same author from the same reading of the
+# format.  These vectors come from elsewhere: RFC 3720 appendix B.4 (CRC32C of iSCSI, the same polynomial; LevelDB's
+# util/crc32c_test.cc "StandardResults" lists the same five), LevelDB's crc32c.h (the mask: rotate right by 15, add 0xa282ead8) and
+# table_format.md / coding.cc (varint32, BlockHandle, block trailer, footer magic 0xdb4775248b80fb57).
+RFC3720_CRC32C = [
+    (bytes(32), 0x8A9136AA),                              # 32 bytes of zeros
+    (bytes([0xFF]) * 32, 0x62A8AB43),                     # 32 bytes of ones
+    (bytes(range(32)), 0x46DD794E),                       # 32 incrementing bytes
+    (bytes(range(31, -1, -1)), 0x113FDB5C),               # 32 decrementing bytes
+    (bytes([0x01, 0xC0, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x14, 0x00, 0x00, 0x00, 0x00, 0x00,
+            0x04, 0x00, 0x00, 0x00, 0x00, 0x14, 0x00, 0x00, 0x00, 0x18, 0x28, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x02, 0x00, 0x00, 0x00,
+            0x00, 0x00, 0x00, 0x00]), 0xD9963A56),        # an iSCSI SCSI Read (10) command PDU
+    (b"123456789", 0xE3069283),                           # the CRC catalogue's check value for CRC-32C
+]
+
+
+def test_crc32c_known_answers_rfc3720_and_leveldb_mask():
+    for data, want in RFC3720_CRC32C:
+        assert T.crc32c(data) == want, (data[:4], hex(T.crc32c(data)), hex(want))
+        half = len(data) // 2                               # incremental form: crc(a + b) = crc(b, crc(a))
+        assert T.crc32c(data[half:], T.crc32c(data[:half])) == want
+    big = bytes(range(256)) * 64                            # >= 4096 bytes: the library's C helper when it is built — same answer
+    t = T._crc_table()
+    c = 0xFFFFFFFF
+    for b in big:
+        c = t[(c ^ b) & 0xFF] ^ (c >> 8)
+    assert T.crc32c(big) == c ^ 0xFFFFFFFF
+    # leveldb::crc32c::Mask: ((crc >> 15) | (crc << 17)) + 0xa282ead8; crc32c_test.cc: Mask(Value("foo")) != Value("foo"), Unmask(Mask(x)) == x
+    c = T.crc32c(b"foo")
+    m = T.masked_crc32c(b"foo")
+    assert m == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF and m != c
+    rot = (m - 0xA282EAD8) & 0xFFFFFFFF
+    assert ((rot >> 17) | (rot << 15)) & 0xFFFFFFFF == c
+
+
+def _bitwise_crc32c(data):
+    """CRC-32C straight from its definition (reflected polynomial 0x82F63B78, init and final xor 0xFFFFFFFF), one bit at a time."""
+    c = 0xFFFFFFFF
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+    return c ^ 0xFFFFFFFF
+
+
+def test_reads_a_bundle_assembled_byte_by_byte_from_the_published_format(tmp_path):
+    """A one-tensor V2 checkpoint put together here, byte by byte, from the published format descriptions alone (LevelDB
+    table_format.md: blocks of prefix-compressed entries + restart array + 5-byte trailer, footer of two BlockHandles padded to
+    40 bytes + the magic; TensorFlow tensor_bundle.proto: BundleHeaderProto under the empty key, BundleEntryProto per tensor,
+    checksums masked CRC-32C) with a bit-at-a-time CRC — none of the repo's writers is involved."""
+    import struct
+    assert all(_bitwise_crc32c(d) == w for d, w in RFC3720_CRC32C)
+
+    def masked(b):
+        c = _bitwise_crc32c(b)
+        return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    values = np.array([[1.5, -2.0, 0.25], [3.0, 4.5, -8.0]], np.float32)
+    data = values.tobytes()                                                     # .data shard: the tensor's bytes, little-endian
+    # BundleEntryProto: dtype = 1 (DT_FLOAT) | shape { dim { size: 2 } dim { size: 3 } } | offset 0 omitted | size = 24 | crc32c fixed32
+    shape = bytes([0x12, 0x02, 0x08, 0x02, 0x12, 0x02, 0x08, 0x03])             # TensorShapeProto: field 2 (dim), each dim: field 1 (size)
+    entry = bytes([0x08, 0x01, 0x12, len(shape)]) + shape + bytes([0x28, 24, 0x35]) + struct.pack("<I", masked(data))
+    header = bytes([0x08, 0x01, 0x1A, 0x02, 0x08, 0x01])                        # num_shards = 1, version { producer: 1 }; endianness LITTLE = 0 omitted
+    key = b"conv2d/kernel"
+
+    def block(entries):        # every entry a restart point: shared = 0
+        body, restarts = b"", []
+        for k, v in entries:
+            restarts.append(len(body))
+            body += bytes([0, len(k), len(v)]) + k + v                          # varint32 shared, non_shared, value_length (< 128: one byte each)
+        body += b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
+        return body + b"\x00" + struct.pack("<I", masked(body + b"\x00"))       # trailer: compression type 0 (none) + masked crc of block + type
+    d = block([(b"", header), (key, entry)])
+    meta = (struct.pack("<I", 0) + struct.pack("<I", 1))                        # the (empty) metaindex block: one restart at offset 0
+    meta = meta + b"\x00" + struct.pack("<I", masked(meta + b"\x00"))
+
+    def handle(offset, size):  # BlockHandle: varint64 offset, varint64 size (size excludes the 5-byte trailer)
+        out = b""
+        for n in (offset, size):
+            while n >= 128:
+                out += bytes([(n & 0x7F) | 0x80])
+                n >>= 7
+            out += bytes([n])
+        return out
+    index = block([(b"d", handle(0, len(d) - 5))])                              # a separator >= the data block's last key
+    footer = handle(len(d), len(meta) - 5) + handle(len(d) + len(meta), len(index) - 5)
+    footer += bytes(40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    assert footer[-8:] == bytes([0x57, 0xFB, 0x80, 0x8B, 0x24, 0x75, 0x47, 0xDB]) and len(footer) == 48
+    prefix = str(tmp_path / "best_model.ckpt-7")
+    open(prefix + ".index", "wb").write(d + meta + index + footer)
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    assert T.is_tf_checkpoint(prefix)
+    got = T.read_checkpoint(prefix)
+    assert list(got) == ["conv2d/kernel"] and got["conv2d/kernel"].dtype == np.float32
+    assert np.array_equal(got["conv2d/kernel"], values)
+    bad = bytearray(data)
+    bad[5] ^= 1
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(bad))
+    with pytest.raises(T.CheckpointError):
+        T.read_checkpoint(prefix)

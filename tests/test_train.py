@@ -109,7 +109,8 @@ def test_train_step_on_device_fast_kernels(blocks, lr):
     off by up to 1.5e-4) — the same few discrete patterns on every box, i.e. which kernel MIOpen's search settled on.  So this
     test holds the first step to the bounds of the deterministic test (a wrong sign, slot, momentum or clip scale is an O(1)
     error there already) and, at 7 blocks, the second step to loss 1e-3, gradient norm 1e-2 and a relative L2 error of each
-    kernel's update of 0.2 — the second step is there to see momentum accumulate through the fast kernels.
+    kernel's update of 5e-2 (3x the worst of the 110 processes: the documented bound holds in EVERY process, no retry) — the
+    second step is there to see momentum accumulate through the fast kernels.
     CZ_TRAIN_PROBE=1 prints the worst tensors of every step."""
     _check_train_step(blocks, lr, "cuda:0", 2e-3 if blocks == 2 else 6e-2, deterministic=False, first_step_only=blocks > 2)
 
@@ -151,7 +152,7 @@ def _check_train_step(blocks, lr, device, upd_tol=2e-3, deterministic=None, firs
             l2 = float(np.linalg.norm(d_got - d_ref) / np.linalg.norm(d_ref))
             worst.append((float(err / scale), l2, k))
             if loose:
-                ok = l2 <= 0.2 or d_ref.ndim == 1
+                ok = l2 <= 5e-2 or d_ref.ndim == 1
             else:
                 # conv biases in front of a batch-statistic BatchNorm have an analytically ZERO data gradient (the mean is
                 # subtracted again): in fp32 what remains is cancellation noise, hence the small absolute term
