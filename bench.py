@@ -559,12 +559,12 @@ def main():
     tower_kernel = "k_trunk_split_c128" if split else "k_tower8_c128"
     traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_strict.json" if split else "pmc_traffic.json")))
         want = {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype}
         if ({k: tj["config"].get(k) for k in want} == want and bool(tj["config"].get("compact", False)) == bool(compact)
                 and args.backend in ("auto", "hip") and tj["kernel"] == tower_kernel):
             traffic = tj["traffic_bytes_per_launch"]
-            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; algorithmic bytes %d)" % tj["algorithmic_bytes_per_launch"]
+            traffic_src = "profiles/pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; algorithmic bytes %d)" % ("_strict" if split else "", tj["algorithmic_bytes_per_launch"])
     except Exception:
         pass
     st, nodes, sims, depth = eng.status()

@@ -3,13 +3,18 @@
 utilisation, per-wave cycle split and LDS conflict rate."""
 import collections
 import csv
+import os
 import sys
+
+KSUB = os.environ.get("PMC_KERNEL", "tower")          # "trunk_split" for the strict engine's kernel
+WG_P = int(os.environ.get("PMC_WG_POSITIONS", "4"))   # positions per workgroup (k_trunk_split_c128: 2)
+SLABS = int(os.environ.get("PMC_SLABS_PER_LAYER", "18"))   # (k_trunk_split_c128: 36)
 
 
 def load(d):
     c, dur = collections.defaultdict(list), []
     for r in csv.DictReader(open(d + "/p_counter_collection.csv")):
-        if "tower" in r["Kernel_Name"]:
+        if KSUB in r["Kernel_Name"]:
             c[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return {k: sum(v) / len(v) for k, v in c.items()}, (sum(dur) / len(dur) if dur else 0.0)
@@ -19,7 +24,7 @@ def main():
     a, dur = load(sys.argv[1])
     b, _ = load(sys.argv[2])
     B, nb = int(sys.argv[3]), int(sys.argv[4])
-    slabs = (B / 4) * 2 * nb * 18          # workgroup-slabs per launch (4 positions per workgroup)
+    slabs = (B / WG_P) * 2 * nb * SLABS    # workgroup-slabs per launch
     clk = a["GRBM_GUI_ACTIVE"] / 8 / dur   # GHz; GRBM_GUI_ACTIVE sums the 8 XCDs
     wc = a["SQ_WAVE_CYCLES"] * 4           # quad-cycles -> cycles
     mfma_total = B * 90 / 32 * 4 * 2 * nb * 72  # 32x32x16 MFMAs incl. no padding
@@ -36,7 +41,7 @@ def main():
     if len(sys.argv) > 5:   # machine-readable copy for profiles/
         import json
         label = sys.argv[6] if len(sys.argv) > 6 else "tools/ubench/tower_base %d positions, %d blocks, random bf16 data" % (B, nb)
-        out = {"kernel": "k_tower8_c128 (%s)" % label,
+        out = {"kernel": "%s (%s)" % ("k_trunk_split_c128" if KSUB == "trunk_split" else "k_tower8_c128", label),
                "method": "rocprofv3 --kernel-trace --pmc, two separate passes (tools/pmc_ubench.sh): a = GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SALU "
                          "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES; b = SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM "
                          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles",

@@ -3,7 +3,8 @@
 artefacts under profiles/: <round>_kernel_stats.csv, <round>_summary.md, <round>_bench_under_rocprof.json
 and pmc_traffic.json (the file bench.py attaches as roofline.traffic when its configuration matches).
 
-usage: tools/summarize_profile.py gpurun_out/prof r01b [kernel-substring]
+usage: tools/summarize_profile.py gpurun_out/prof r01b [kernel-substring [suffix]]
+       suffix (e.g. "_strict"): pmc_traffic<suffix>.json / pmc_tree_traffic<suffix>.json (bench.py looks the strict engine's up there)
 """
 import csv
 import glob
@@ -34,6 +35,7 @@ def pmc_mean(path, counter, kernel_sub):
 def main():
     src, rnd = sys.argv[1], sys.argv[2]
     ksub = sys.argv[3] if len(sys.argv) > 3 else "k_tower8_c128"
+    sfx = sys.argv[4] if len(sys.argv) > 4 else ""
     prof = os.path.join(ROOT, "profiles")
     stats = find(os.path.join(src, "stats"), "*kernel_stats.csv")
     shutil.copy(stats, os.path.join(prof, rnd + "_kernel_stats.csv"))
@@ -46,7 +48,7 @@ def main():
     dom = [r for r in rows if ksub in r["Name"]][0]
     md = ["# %s — rocprofv3 --kernel-trace --stats of the default bench" % rnd, "",
           "Command on the MI355X box (tools/profile_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- "
-          "python bench.py --no-cpu-baseline --steps 100 --warmup 8`", "",
+          "python bench.py --no-cpu-baseline --strict-steps 0 --steps 100 --warmup 8 --steady-steps 0` (dtype %s)" % bline["dtype"], "",
           "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
     for r in rows[:12]:
         md.append("| `%s` | %s | %.1f | %s |" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
@@ -61,7 +63,8 @@ def main():
     # algorithmic bytes of one launch: planes in (bf16 [G][90][16]) + all folded weights once
     # (first conv 9*16*128, 2*blocks layers of 9*128*128, bf16) + biases (f32) + head conv output (f32 [G][90][3])
     rows_ = cfg.get("net_rows_per_step", G)   # compact batches: fewer rows than trees
-    alg = int(rows_ * 90 * 16 * 2 + (9 * 16 * 128 + 2 * blocks * 9 * 128 * 128) * 2 + (2 * blocks + 1) * 128 * 4 + rows_ * 90 * 3 * 4)
+    halves = 2 if bline["dtype"].endswith("x2") else 1   # the strict engine streams every weight as hi + lo
+    alg = int(rows_ * 90 * 16 * 2 + (9 * 16 * 128 + 2 * blocks * 9 * 128 * 128) * 2 * halves + (2 * blocks + 1) * 128 * 4 + rows_ * 90 * 3 * 4)
     tj = {"kernel": ksub, "config": {"B": G, "res_block_nums": blocks, "dtype": bline["dtype"], "compact": bool(cfg.get("compact_batches", False)),
                                      "net_rows_per_step": rows_},
           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
@@ -74,9 +77,9 @@ def main():
                   "LDS-DMA pattern, so the truth lies between x1 and x2). WRITE_SIZE equals the head conv outputs only: the trunk never "
                   "leaves the CU. The read side is far above the algorithmic input because every workgroup streams the whole folded weight "
                   "set (L2 / Infinity Cache hits for all but the first sweep)."}
-    json.dump(tj, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+    json.dump(tj, open(os.path.join(prof, "pmc_traffic%s.json" % sfx), "w"), indent=1)
     md += ["", "HBM PMC (separate passes): FETCH_SIZE %.0f KiB raw, WRITE_SIZE %.0f KiB per launch -> traffic %.3e B "
-           "(algorithmic %.3e B); see pmc_traffic.json." % (fetch, write, tj["traffic_bytes_per_launch"], alg)]
+           "(algorithmic %.3e B); see pmc_traffic%s.json." % (fetch, write, tj["traffic_bytes_per_launch"], alg, sfx)]
     # the HBM-bound tree / rules kernels of the same runs: counter traffic per launch and the GB/s that implies
     dur = {r["Name"]: float(r["AverageNs"]) for r in rows}
     tree = {}
@@ -97,7 +100,7 @@ def main():
                "method": "same two rocprofv3 --pmc passes as pmc_traffic.json; avg_us from the --kernel-trace --stats pass; FETCH_SIZE is given "
                          "raw (x1) and with the gfx950 x2 correction for wide coalesced reads (these kernels mix narrow gathers and wide "
                          "loads: the truth lies between)"}
-        json.dump(tj2, open(os.path.join(prof, "pmc_tree_traffic.json"), "w"), indent=1)
+        json.dump(tj2, open(os.path.join(prof, "pmc_tree_traffic%s.json" % sfx), "w"), indent=1)
         md += ["", "Tree / rules kernels (HBM-bound; counter traffic per launch, x1 .. x2 FETCH correction):", "",
                "| kernel | avg us | fetch KiB raw | write KiB | GB/s (x1 .. x2) |", "|---|---|---|---|---|"]
         for k, v in tree.items():
