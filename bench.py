@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--selfplay", action="store_true", help="time the device-resident self-play loop (asynchronous plies)")
     ap.add_argument("--terminal-extra", type=int, default=4, help="terminal / drawn simulations a tree may complete inside one select launch (0: one simulation per tree and step, round-1 behaviour)")
     ap.add_argument("--eval-cache", action="store_true", help="evaluation cache (cz_search_set_eval_cache): a leaf whose position the tree has evaluated before is expanded from the remembered node inside the select launch, without a net row; trees are bit-identical with it on or off.  Off in the default (headline) run")
+    ap.add_argument("--xcache", type=int, default=0, metavar="LOG2_ENTRIES", help="with --eval-cache: the cross-tree level (cz_search_set_xcache), 2**LOG2_ENTRIES entries of 1088 bytes shared by all trees of the rank (20 = 1.1 GB); pays in self-play from the start position, where the games share their openings")
     ap.add_argument("--advance-every", type=int, default=8, help="steps between checks for trees that have had their playouts")
     ap.add_argument("--timed-gather", action="store_true", help="with --selfplay and N > 1: all-gather the finished games' records every 64 lock-steps, inside the timed region")
     ap.add_argument("--torch-advance", action="store_true", help="A/B only: the round-2 advance of ready trees (status / root statistics / argmax / reload as ~20 torch ops) instead of cz_search_pick_ready + cz_search_advance + cz_search_reload_finished")
@@ -394,6 +395,7 @@ def main():
         from cchess_zero_amd.selfplay import SelfPlay
         sp = SelfPlay(eng, net, playout, exploration=True, temperature=1.0, seed=77 + rank, continuous=True)
         sp.eval_cache = bool(args.eval_cache)
+        sp.xcache_log2 = args.xcache if args.eval_cache else 0
         sp.start(boards, side, rr)
         eng.compact = compact
 
@@ -422,6 +424,8 @@ def main():
     else:
         if args.eval_cache:
             eng.set_eval_cache(True)
+            if args.xcache:
+                eng.set_xcache(args.xcache)
         eng.reset(boards, side, rr)
         eng.set_terminal_extra(TE)
         eng.set_sim_target(playout)
@@ -708,7 +712,8 @@ def main():
            "simulations_per_net_row": total_sims / max(1.0, total_rows), "terminal_extra": TE, "advance_every": args.advance_every,
            "net_rows_per_s": total_rows / dt,
            "age_steps": age, "tree_state_at_t0": ("every tree has finished a first, shortened search (cut at its own threshold, uniform in [8, %d] simulations) and stands at its own phase of a %d-playout search on the subtree it kept" % (age, playout)) if (age >= 8 and not sp) else "fresh searches",
-           "eval_cache": (dict(zip(("hits", "lookups"), eng.eval_cache_stats())) if args.eval_cache else None), "games_reloaded_rank0": int(reloaded.item()),
+           "eval_cache": (dict(zip(("hits", "lookups"), eng.eval_cache_stats())) if args.eval_cache else None),
+           "xcache": (dict(eng.xcache_stats(), log2_entries=args.xcache) if (args.eval_cache and args.xcache) else None), "games_reloaded_rank0": int(reloaded.item()),
            "mean_leaf_depth": mean_depth, "mean_nodes_per_tree": float(nodes.float().mean().item()),
            "trees_with_error_status": bad, "status_bits": st_bits}
     if sp:

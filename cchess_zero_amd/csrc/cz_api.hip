@@ -173,6 +173,7 @@ void cz_destroy(cz_ctx *c) {
     if (c->pend_block) (void)hipFree(c->pend_block);
     if (c->tab_block) (void)hipFree(c->tab_block);
     if (c->mask_tab) (void)hipFree(const_cast<CzmTables *>(c->mask_tab));
+    if (c->xc_block) (void)hipFree(c->xc_block);
     if (c->tree_block) (void)hipFree(c->tree_block);
     if (c->pool_block) (void)hipFree(c->pool_block);
     if (c->sp_block) (void)hipFree(c->sp_block);
@@ -291,9 +292,42 @@ int cz_search_set_eval_cache(cz_ctx *c, int on) {
         // an empty cache: entries of an earlier use would point into trees that no longer exist
         CZ_HIP(hipMemsetAsync(c->ec_block, 0, per * 8, c->stream));
         czk_search_clear_cache_stats(c);
+        if (c->t.xc_base) CZ_HIP(hipMemsetAsync(c->xc_block, 0, ((size_t)1 << c->xc_log2_entries) * 8 + 64, c->stream));   // and the cross-tree level
     } else {
         c->t.ec_key = nullptr; c->t.ec_node = nullptr; c->t.ec_val = nullptr; c->t.ec_board = nullptr; c->t.pend_board = nullptr;
+        if (c->xc_block) return cz_search_set_xcache(c, 0);   // the cross-tree level lives behind the per-tree probe
     }
+    return CZ_OK;
+}
+int cz_search_set_xcache(cz_ctx *c, int log2_entries) {
+    CZ_REQUIRE(c && (log2_entries == 0 || (log2_entries >= 6 && log2_entries <= 24)), "cz_search_set_xcache: log2_entries must be 0 (off) or 6..24");
+    CZ_HIP(hipSetDevice(c->device));
+    if (log2_entries == 0 || (c->xc_block && c->xc_log2_entries != log2_entries)) {
+        if (c->xc_block) { CZ_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->xc_block); }
+        c->xc_block = nullptr; c->xc_log2_entries = 0;
+        c->t.xc_base = nullptr; c->t.xc_mask = 0;
+        if (log2_entries == 0) return CZ_OK;
+    }
+    if (!c->t.ec_key) { cz_set_error("cz_search_set_xcache: switch the per-tree evaluation cache on first (cz_search_set_eval_cache(ctx, 1))"); return CZ_EINVAL; }
+    const size_t n = (size_t)1 << log2_entries;
+    // per entry: key 8, value 4, count 4, position 48, labels 256, (src, dst) 256, priors 512 = 1088 bytes; + 4 counters
+    if (!c->xc_block) {
+        const size_t bytes = n * 1088 + 64;
+        if (hipMalloc(&c->xc_block, bytes) != hipSuccess) { c->xc_block = nullptr; cz_set_error("cz_search_set_xcache: hipMalloc(%zu B) failed", bytes); return CZ_ENOMEM; }
+        c->xc_log2_entries = log2_entries;
+        c->t.xc_base = (char *)c->xc_block;
+        c->t.xc_mask = (uint32_t)(n / 64 - 1);
+    }
+    // an empty table (new weights => remembered evaluations are stale): only the keys and the counters need clearing
+    CZ_HIP(hipMemsetAsync(c->xc_block, 0, n * 8 + 64, c->stream));
+    return CZ_OK;
+}
+int cz_search_xcache_stats(cz_ctx *c, unsigned long long *stats4) {
+    CZ_REQUIRE(c && stats4, "cz_search_xcache_stats: null argument");
+    stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0;
+    if (!c->t.xc_base) return CZ_OK;
+    CZ_HIP(hipMemcpyAsync(stats4, czx_stats(c->t), 32, hipMemcpyDeviceToHost, c->stream));
+    CZ_HIP(hipStreamSynchronize(c->stream));
     return CZ_OK;
 }
 int cz_search_debug_eval_cache_key_bits(cz_ctx *c, int bits) {

@@ -125,6 +125,17 @@ struct CzTrees {
     uint32_t *ec_board;               // [max_games][CZ_EC_ENTRIES][12] the entry's position, packed (wave_pack_board): checked on every hit
     uint32_t *pend_board;             // [max_games][12] packed position of the pending leaf (select -> expand_backup)
     unsigned long long ec_key_mask;   // ~0; tests narrow it (cz_search_debug_eval_cache_key_bits) to force key collisions
+    // cross-tree level of the evaluation cache (cz_search_set_xcache): ONE table per context, shared by all of its trees.  An
+    // entry cannot lend node indices (the lender tree's nodes move at its next re-root), so it is self-contained: key, packed
+    // position, the value the evaluation backed up, the move count, the <= 128 labels / (src, dst) pairs / priors.  Entries are
+    // written once: k_expand_backup claims an empty slot of the key's 64-entry bucket with an atomic compare-and-swap on the key
+    // and fills it; k_select (a later launch: the kernel boundary publishes the payload) only reads.  Emptied by the host
+    // whenever the weights change.
+    // ONE base pointer (the kernels are short of scalar registers): with n = (xc_mask + 1) * 64 entries the block holds
+    //   keys u64 [n] | counters u64 [8] | value f32 [n] | move count u32 [n] | position u32 [n][12] | labels u16 [n][128] |
+    //   (src, dst) u16 [n][128] | priors f32 [n][128]        (czx_* below)
+    char *xc_base;                    // NULL: off
+    uint32_t xc_mask;                 // buckets - 1 (a power of two); a bucket = 64 consecutive entries
     // compact evaluation batches (cz_search_select_compact): row of the step's leaf in planes / z / value, or -1
     int32_t *slot_of;                 // [max_games]
     int32_t *evcnt;                   // [2] rows handed out this step / next step (ping-pong, zeroed one step ahead)
@@ -149,6 +160,8 @@ struct cz_ctx {
     int sim_target;    // cz_search_set_sim_target: completed simulations per tree a k > 1 search stops at (0: no limit)
     int step_parity;   // which evcnt entry the current compact step uses
     const int32_t *batch_count;  // cz_set_batch_count: device row count bounding the net launches, or NULL
+    void *xc_block;      // cz_search_set_xcache: the cross-tree table's allocation
+    int xc_log2_entries;
     const struct CzmTables *mask_tab;  // cz_maskgen.h tables on the device (k_movegen_mask)
     unsigned long long *clock_probe;  // cz_set_clock_probe: [clock_probe_wgs][4] stamps written by the trunk kernels, or NULL
     int clock_probe_wgs, clock_probe_last_grid;
@@ -156,6 +169,17 @@ struct cz_ctx {
     void *sp_block;
     void *ec_block;    // cz_search_set_eval_cache
 };
+
+// cross-tree cache: the arrays inside CzTrees::xc_base
+__host__ __device__ __forceinline__ size_t czx_n(const CzTrees &t) { return ((size_t)t.xc_mask + 1) * 64; }
+__host__ __device__ __forceinline__ unsigned long long *czx_key(const CzTrees &t) { return reinterpret_cast<unsigned long long *>(t.xc_base); }
+__host__ __device__ __forceinline__ unsigned long long *czx_stats(const CzTrees &t) { return reinterpret_cast<unsigned long long *>(t.xc_base + czx_n(t) * 8); }   // hits, lookups, entries written, claims lost
+__host__ __device__ __forceinline__ float *czx_val(const CzTrees &t) { return reinterpret_cast<float *>(t.xc_base + czx_n(t) * 8 + 64); }
+__host__ __device__ __forceinline__ uint32_t *czx_cnt(const CzTrees &t) { return reinterpret_cast<uint32_t *>(t.xc_base + czx_n(t) * 12 + 64); }
+__host__ __device__ __forceinline__ uint32_t *czx_board(const CzTrees &t) { return reinterpret_cast<uint32_t *>(t.xc_base + czx_n(t) * 16 + 64); }
+__host__ __device__ __forceinline__ uint16_t *czx_moves(const CzTrees &t) { return reinterpret_cast<uint16_t *>(t.xc_base + czx_n(t) * 64 + 64); }
+__host__ __device__ __forceinline__ uint16_t *czx_sd(const CzTrees &t) { return reinterpret_cast<uint16_t *>(t.xc_base + czx_n(t) * 320 + 64); }
+__host__ __device__ __forceinline__ float *czx_P(const CzTrees &t) { return reinterpret_cast<float *>(t.xc_base + czx_n(t) * 576 + 64); }
 
 // ---- device helpers shared by cz_search.hip / cz_selfplay.hip -----------------------------------
 struct TreeView {

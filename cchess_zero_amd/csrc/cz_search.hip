@@ -114,6 +114,7 @@ __device__ __forceinline__ unsigned long long wave_position_key(const uint8_t *b
     return h ? h : 1ull;
 }
 __device__ __forceinline__ int ec_bucket(unsigned long long key) { return (int)((key >> 17) & (CZ_EC_BUCKETS - 1)); }
+__device__ __forceinline__ uint32_t xc_bucket(unsigned long long key) { return (uint32_t)(key >> 24); }   // cross-tree table: other key bits
 // The position itself, packed: 90 squares x 4 bits (piece codes 0..14) in 12 dwords, side to move in the top nibble of the
 // last one.  Lane j < 12 packs squares 8j .. 8j+7 (LDS bytes 90..95 of the board are zero).  A cache entry carries this
 // image of its node's position and a hit is only taken when it equals the leaf's: the 64-bit key finds the candidate, the
@@ -141,7 +142,7 @@ __device__ __forceinline__ uint32_t wave_pack_board(const uint8_t *b, int side, 
 // strictly sequential, so the tree after N simulations is bit-identical to the one-simulation-per-step schedule; what
 // changes is that a step now completes 1 / (1 - f) simulations per net row (f = share of terminal simulations, 8.5 % on
 // the bench workload).  sim_target > 0 stops a tree at that many completed simulations (cz_search_set_sim_target).
-template <typename T, bool COMPACT, bool CACHE>
+template <typename T, bool COMPACT, bool CACHE, bool XC = false>
 __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &tab, int G, int mode,
                                             const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                             T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
@@ -297,8 +298,24 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                         }
                         if (lane == 0) { t.ec_hits[g] += hit ? 1u : 0u; t.ec_lookups[g] += 1u; }
                     }
+                    // second level (XC kernels): the context's cross-tree table (cz_search_set_xcache) — a position ANOTHER tree
+                    // has had evaluated.  Its entries are self-contained (labels, (src, dst), priors, value) and read-only here.
+                    long long xe = -1;
+                    if (XC && !hit && may_cache) {
+                        const size_t xb0 = (size_t)(xc_bucket(key) & t.xc_mask) * 64;
+                        const unsigned long long xk = czx_key(t)[xb0 + lane];
+                        for (unsigned long long m = __ballot(xk == key); m; m &= m - 1ull) {
+                            const int hl = __ffsll((long long)m) - 1;
+                            const uint32_t lb = lane < 12 ? czx_board(t)[(xb0 + hl) * 12 + lane] : 0u;
+                            if (__ballot(lb != pk) == 0ull) { xe = (long long)(xb0 + hl); break; }
+                        }
+                        if (xe >= 0) { pend = czx_val(t)[xe]; hit = true; }
+                        if (lane == 0) { atomicAdd(&czx_stats(t)[1], 1ull); if (xe >= 0) atomicAdd(&czx_stats(t)[0], 1ull); }
+                    }
                     if (!hit) break;
-                    const int scb = v.child_begin[src], n = v.child_count[src];
+                    // the lender: an expanded node of this tree (its children's arrays) or a cross-tree entry's arrays
+                    const int scb = (XC && xe >= 0) ? 0 : v.child_begin[src];
+                    const int n = (XC && xe >= 0) ? (int)czx_cnt(t)[xe] : (int)v.child_count[src];
                     const int begin = t.n_nodes[g];
                     if (begin + n <= t.cap) {   // leaf_node.expand with the lender's priors
 #pragma unroll
@@ -306,7 +323,12 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                             const int i = lane + 64 * r;
                             if (i < n) {
                                 const int c = begin + i;
-                                v.P[c] = v.P[scb + i]; v.move[c] = v.move[scb + i]; v.sd[c] = v.sd[scb + i];
+                                if (XC && xe >= 0) {
+                                    const size_t o = (size_t)xe * CZD_MAXMOVES + i;
+                                    v.P[c] = czx_P(t)[o]; v.move[c] = czx_moves(t)[o]; v.sd[c] = czx_sd(t)[o];
+                                } else {
+                                    v.P[c] = v.P[scb + i]; v.move[c] = v.move[scb + i]; v.sd[c] = v.sd[scb + i];
+                                }
                                 v.W[c] = 0.f; v.Q[c] = 0.f; v.N[c] = 0; v.parent[c] = leaf; v.child_begin[c] = -1;
                                 v.child_count[c] = 0;
                             }
@@ -404,6 +426,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_sel
                                                      const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                                      T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
     select_body<T, false, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
+}
+// ... and with the cross-tree level behind it (cz_search_set_xcache).  Their own instantiations: the extra probe costs registers
+// (65 VGPRs: 7 waves per SIMD) that the plain cache kernels (59) do not pay.
+template <typename T>
+__global__ __launch_bounds__(64) void k_select_xcache(CzTrees t, CzTables tab, int G, int mode,
+                                                      const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                                      T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
+    select_body<T, false, true, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
+}
+template <typename T>
+__global__ __launch_bounds__(64) void k_select_compact_xcache(CzTrees t, CzTables tab, int G, int mode,
+                                                              const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
+                                                              T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
+    select_body<T, true, true, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
 }
 template <typename T>
 __global__ __launch_bounds__(64) void k_select_compact_cache(CzTrees t, CzTables tab, int G, int mode,
@@ -592,6 +628,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
                 int slot = em ? __ffsll((long long)em) - 1 : (int)((key >> 40) & 63);
                 if (lane == slot) { t.ec_key[eb0 + lane] = key; t.ec_node[eb0 + lane] = leaf; t.ec_val[eb0 + lane] = val; }
                 if (lane < 12) t.ec_board[(eb0 + slot) * 12 + lane] = t.pend_board[(size_t)g * 12 + lane];
+            }
+            // cross-tree level (cz_search_set_xcache): file the evaluation for the OTHER trees as well — a write-once entry in an
+            // empty slot of the key's bucket, claimed by compare-and-swap on the key (two trees expanding the same position in this
+            // launch: one of them wins the slot, the other finds the key taken or loses the swap and leaves).  Readers are the
+            // select kernels of later launches, so the payload needs no flag: the kernel boundary publishes it.
+            if (t.xc_base) {
+                const size_t xb0 = (size_t)(xc_bucket(key) & t.xc_mask) * 64;
+                const unsigned long long xk = czx_key(t)[xb0 + lane];
+                const unsigned long long xm = __ballot(xk == 0ull);
+                if (__ballot(xk == key) == 0ull && xm) {
+                    // the first empty slot at or behind a key-dependent position: trees filing different positions into one
+                    // bucket in the same launch do not all go for slot 0 (the loser of a swap does not retry: write-once table)
+                    const int rot = (int)((key >> 40) & 63);
+                    const unsigned long long xr = rot ? (xm >> rot) | (xm << (64 - rot)) : xm;
+                    const int slot = (__ffsll((long long)xr) - 1 + rot) & 63;
+                    int won = 0;
+                    if (lane == 0) won = atomicCAS(&czx_key(t)[xb0 + slot], 0ull, key) == 0ull ? 1 : 0;
+                    won = __shfl(won, 0, 64);
+                    if (won) {
+                        const size_t e = xb0 + slot;
+                        const int n2 = t.pend_nmoves[g];
+                        const int cb2 = begin;   // the children written above: lane l re-reads exactly the elements lane l wrote
+                        if (lane < 12) czx_board(t)[e * 12 + lane] = mine;
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int i = lane + 64 * r;
+                            if (i < n2) {
+                                czx_P(t)[e * CZD_MAXMOVES + i] = v.P[cb2 + i];
+                                czx_moves(t)[e * CZD_MAXMOVES + i] = v.move[cb2 + i];
+                                czx_sd(t)[e * CZD_MAXMOVES + i] = v.sd[cb2 + i];
+                            }
+                        }
+                        if (lane == 0) { czx_val(t)[e] = val; czx_cnt(t)[e] = (uint32_t)n2; atomicAdd(&czx_stats(t)[2], 1ull); }
+                    } else if (lane == 0) {
+                        atomicAdd(&czx_stats(t)[3], 1ull);
+                    }
+                }
             }
         }
         if (kind == 3) { if (lane == 0) t.pend_kind[g] = 0; return; }
@@ -1256,8 +1329,11 @@ int czk_search_select(cz_ctx *c, int mode, const uint8_t *active, void *planes, 
     const int par = c->step_parity;
 #define CZ_LAUNCH_SELECT(KERNEL, TT, ONE)                                                                               \
     hipLaunchKernelGGL((KERNEL<TT>), dim3(c->G), dim3(64), 0, c->stream, c->t, c->tab, c->G, mode, active, (TT *)planes, C, ONE, needs_eval, par, c->sim_target, c->terminal_extra)
-    const bool cache = c->t.ec_key != nullptr;
-    if (dtype == CZ_F32) {
+    const bool cache = c->t.ec_key != nullptr, xc = cache && c->t.xc_base != nullptr;
+    if (xc) {
+        if (dtype == CZ_F32) { if (compact) CZ_LAUNCH_SELECT(k_select_compact_xcache, float, 1.0f); else CZ_LAUNCH_SELECT(k_select_xcache, float, 1.0f); }
+        else { if (compact) CZ_LAUNCH_SELECT(k_select_compact_xcache, uint16_t, one16); else CZ_LAUNCH_SELECT(k_select_xcache, uint16_t, one16); }
+    } else if (dtype == CZ_F32) {
         if (cache) { if (compact) CZ_LAUNCH_SELECT(k_select_compact_cache, float, 1.0f); else CZ_LAUNCH_SELECT(k_select_cache, float, 1.0f); }
         else { if (compact) CZ_LAUNCH_SELECT(k_select_compact, float, 1.0f); else CZ_LAUNCH_SELECT(k_select, float, 1.0f); }
     } else {

@@ -81,6 +81,7 @@ class SearchEngine:
         self.need = None
         self.terminal_extra = 0
         self.eval_cache = False
+        self.xcache_log2 = 0
 
     def set_terminal_extra(self, n):
         """Terminal simulations (king captured / 60-ply rule: no net evaluation needed, main.py:409-416) a tree may complete
@@ -99,6 +100,25 @@ class SearchEngine:
         self.ctx.bind_stream()
         check(lib().cz_search_set_eval_cache(self.ctx.h, 1 if on else 0), "cz_search_set_eval_cache")
         self.eval_cache = bool(on)
+        if not on:
+            self.xcache_log2 = 0    # the cross-tree level lives behind the per-tree probe: the library frees it with it
+
+    def set_xcache(self, log2_entries):
+        """Cross-tree level of the evaluation cache (cz_search_set_xcache; needs set_eval_cache(True)): one table of
+        2**log2_entries self-contained entries (1088 bytes each) shared by all trees of the context — a leaf whose position ANY
+        tree has evaluated is expanded inside the select launch from the remembered row (verified against the stored position;
+        trees bit-identical).  0 frees it; calling it again empties it (do so whenever the weights change — set_eval_cache(True)
+        empties both levels)."""
+        assert self.eval_cache or not log2_entries, "set_eval_cache(True) first"
+        self.ctx.bind_stream()
+        check(lib().cz_search_set_xcache(self.ctx.h, int(log2_entries)), "cz_search_set_xcache")
+        self.xcache_log2 = int(log2_entries)
+
+    def xcache_stats(self):
+        """-> dict(hits, lookups, written, lost) of the cross-tree level since it was last emptied."""
+        a = (C.c_ulonglong * 4)()
+        check(lib().cz_search_xcache_stats(self.ctx.h, a), "cz_search_xcache_stats")
+        return dict(hits=int(a[0]), lookups=int(a[1]), written=int(a[2]), lost=int(a[3]))
 
     def eval_cache_stats(self):
         """-> (hits, lookups) summed over the trees since the cache was turned on."""

@@ -129,7 +129,7 @@ class SelfPlay:
     """
 
     def __init__(self, engine, net, playouts, exploration=True, temperature=1.0, seed=0, max_plies=512, ring_records=None,
-                 continuous=True, eval_cache=False):
+                 continuous=True, eval_cache=False, xcache_log2=0):
         self.eng, self.net = engine, net
         self.playouts = int(playouts)
         self.exploration = bool(exploration)
@@ -138,6 +138,8 @@ class SelfPlay:
         self.continuous = bool(continuous)
         # evaluation cache (engine.set_eval_cache): valid as long as the net's weights do not change — start() empties it
         self.eval_cache = bool(eval_cache)
+        # its cross-tree level (engine.set_xcache): games from one start position share their openings
+        self.xcache_log2 = int(xcache_log2) if eval_cache else 0
         self.dev = engine.dev
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
         self.ring_records = ring_records
@@ -152,6 +154,8 @@ class SelfPlay:
         eng = self.eng
         if self.eval_cache or eng.eval_cache:
             eng.set_eval_cache(self.eval_cache)   # turning it on empties it: new weights, new cache
+            if self.eval_cache and (self.xcache_log2 or eng.xcache_log2):
+                eng.set_xcache(self.xcache_log2)
         eng.reset(boards, side, rr)
         eng.compact = not self.continuous   # parked games drop out of the net's batch; a full batch needs no compaction
         G = eng.G

@@ -512,6 +512,9 @@ class cchess_main(object):
                           # the evaluation cache pays from a few hundred playouts per move on (in-tree repeat rate 1 % at 100
                           # playouts, 4 % at 400, 12 % at 1600; the lookup costs the select launch 10-25 us)
                           eval_cache=self.playout_counts >= 400,
+                          # ... and its cross-tree level: every game starts from the same position, the openings are shared
+                          # (2**18 entries = 285 MB)
+                          xcache_log2=18 if self.playout_counts >= 400 else 0,
                           # a drain interval can end every game of every slot in the worst case: room for ~160 plies per slot
                           ring_records=max(65536, 160 * G))
             b0 = np.tile(state_to_board(START_STATE), (G, 1))
@@ -520,7 +523,7 @@ class cchess_main(object):
             self._sp_weights_step = self.policy_value_netowrk.global_step
         elif self._sp_weights_step != self.policy_value_netowrk.global_step:
             if sp.eval_cache:
-                sp.eng.set_eval_cache(True)      # new weights: remembered evaluations are stale (turning it on empties it)
+                sp.eng.set_eval_cache(True)      # new weights: remembered evaluations are stale (turning it on empties both levels)
             self._sp_weights_step = self.policy_value_netowrk.global_step
         before = sp.stats()
         # asynchronous plies: every game moves when ITS search has had its playouts (simulations that end on a king capture

@@ -513,6 +513,95 @@ def test_eval_cache_follows_the_tree_through_advances(rules_golden, key_bits, ex
     check(lib().cz_search_debug_eval_cache_key_bits(hip.e.ctx.h, 64), "cz_search_debug_eval_cache_key_bits")
 
 
+@pytest.mark.parametrize("key_bits", [64, 11])
+def test_xcache_lends_evaluations_across_trees_and_keeps_every_tree(key_bits):
+    """The cross-tree level of the evaluation cache (cz_search_set_xcache): 61 trees rooted at the start position, at its 44
+    successors and at 16 second-ply positions — the root of one tree is an inner node of another, as the openings of self-play
+    games are — 2 plies x 300 playouts with a re-root in between, against the oracle's plain schedule: identical root
+    statistics and whole trees; evaluations ARE lent across trees (hits > 0, fewer net rows than with the per-tree level
+    alone); with keys narrowed to 2 048 values every false match is refused by the stored position."""
+    from oracle import oracle as O
+    from cchess_zero_amd._lib import check, lib
+    b0 = O.fen_to_board(O.START_FEN)
+    boards, side = [b0], [0]
+    for m in O.legal_moves(b0, 0):
+        boards.append(O.apply_move(b0, int(m))[0]); side.append(1)
+    b1 = boards[20]
+    for m in O.legal_moves(b1, 1)[:16]:
+        boards.append(O.apply_move(b1, int(m))[0]); side.append(0)
+    boards, side = np.stack(boards), np.array(side, np.uint8)
+    G, playouts = len(boards), 300
+    rr = np.zeros(G, np.int32)
+    fwd = fakenet.make_forward("signed", 5)
+
+    def run(xc):
+        hip = _HipEngine(G, 60000)
+        check(lib().cz_search_debug_eval_cache_key_bits(hip.e.ctx.h, key_bits), "cz_search_debug_eval_cache_key_bits")
+        hip.e.set_eval_cache(True)
+        if xc:
+            hip.e.set_xcache(12)
+        hip.reset(boards, side, rr)
+        rows, dumps = 0, []
+        for ply in range(2):
+            hip.e.set_terminal_extra(4)
+            hip.e.set_sim_target(playouts)
+            for mode in [0] + [1] * playouts:
+                busy = (hip.e.status()[2].cpu().numpy() < playouts) & (hip.status() & ~8 == 0)
+                if mode == 1 and not busy.any():
+                    break
+                hp, hn = hip.select(mode)
+                rows += int(hn.sum())
+                lg, v = fwd(hp)
+                hip.expand_backup(lg, v)
+            hip.e.set_sim_target(0)
+            hip.e.set_terminal_extra(0)
+            hs = hip.root_stats()
+            dumps.append((hs, [hip.tree_dump(t) for t in range(0, G, 4)], hip.status().copy()))
+            n = hs["N"].astype(np.int64).copy()
+            n[np.arange(128)[None, :] >= hs["count"].astype(np.int64)[:, None]] = -1
+            played = hs["label"][np.arange(G), n.argmax(axis=1)].astype(np.uint16)
+            played[hs["count"] == 0] = 0xFFFF
+            hip.advance(played)
+        st = hip.e.xcache_stats() if xc else None
+        hip.e.set_eval_cache(False)
+        check(lib().cz_search_debug_eval_cache_key_bits(hip.e.ctx.h, 64), "cz_search_debug_eval_cache_key_bits")
+        return rows, dumps, st
+
+    orc = O.Search(G, 60000)
+    orc.reset(boards, side, rr)
+    odumps = []
+    for ply in range(2):
+        for step in range(playouts + 1):
+            op, on = orc.select(0 if step == 0 else 1)
+            lg, v = fwd(op)
+            orc.expand_backup(lg, v)
+        os_ = orc.root_stats()
+        odumps.append((os_, [orc.tree_dump(t) for t in range(0, G, 4)], orc.status()[0].copy()))
+        n = os_["N"].astype(np.int64).copy()
+        n[np.arange(128)[None, :] >= os_["count"].astype(np.int64)[:, None]] = -1
+        played = os_["label"][np.arange(G), n.argmax(axis=1)].astype(np.uint16)
+        played[os_["count"] == 0] = 0xFFFF
+        orc.advance(played)
+    rows_tree, d_tree, _ = run(False)
+    rows_xc, d_xc, st = run(True)
+    for got in (d_tree, d_xc):
+        for ply in range(2):
+            hs, dumps, status = got[ply]
+            os_, odump, ostatus = odumps[ply]
+            for k in ("label", "N", "count"):
+                assert np.array_equal(hs[k], os_[k]), (ply, k)
+            for k in ("Q", "P", "W"):
+                assert np.array_equal(hs[k].view(np.uint32), os_[k].view(np.uint32)), (ply, k)
+            assert np.array_equal(status, ostatus)
+            for a, b in zip(dumps, odump):
+                assert np.array_equal(a, b), ply
+    print("cross-tree cache (%d-bit keys), %d trees x 2 plies x %d playouts: net rows %d with the per-tree level alone, %d with the "
+          "cross-tree level; %s" % (key_bits, G, playouts, rows_tree, rows_xc, st))
+    assert st["written"] > 0 and st["lookups"] >= st["hits"]
+    if key_bits == 64:      # (narrowed keys all fall into ONE bucket of the cross-tree table: 64 entries; what counts there is
+        assert st["hits"] > 0 and rows_xc < rows_tree     #  that every false match is refused — the identity asserted above)
+
+
 def test_advance_ready_device_driver_matches_host_logic():
     """cz_search_pick_ready -> cz_search_advance -> cz_search_reload_finished (the greedy driver bench.py's search loop
     runs every few steps) against the same decisions taken on the host from cz_search_status / root_stats / root_state:

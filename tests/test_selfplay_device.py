@@ -149,27 +149,34 @@ def test_eval_cache_and_terminal_extra_leave_real_net_selfplay_unchanged():
     — visit counts, sampled moves, results — are byte-identical with the cache and in-select terminal simulations on or off."""
     G, playouts, plies = 64, 24, 30
 
-    def run(cache):
+    def run(cache, xcache=0):
         net, eng, sp = _setup(G, 8192, playouts, seed=11)
         if cache:
             eng.set_eval_cache(True)
             eng.set_terminal_extra(4)
+            if xcache:
+                eng.set_xcache(xcache)
         sp.run(plies)
         rec = sp.drain()
         st = sp.stats()
         hits = eng.eval_cache_stats() if cache else (0, 0)
+        xst = eng.xcache_stats() if xcache else None
         if cache:
             eng.set_terminal_extra(0)
             eng.set_eval_cache(False)
-        return rec, st, hits
+        return rec, st, hits, xst
 
-    rec0, st0, _ = run(False)
-    rec1, st1, hits = run(True)
-    print("real net, %d games x %d plies x %d playouts: %d records; cache hits %d / %d lookups" %
-          (G, plies, playouts, len(rec0), hits[0], hits[1]))
+    rec0, st0, _, _ = run(False)
+    rec1, st1, hits, _ = run(True)
+    rec2, st2, hits2, xst = run(True, 14)      # + the cross-tree level: all 64 games start from the same position
+    print("real net, %d games x %d plies x %d playouts: %d records; cache hits %d / %d lookups; with the cross-tree level %s" %
+          (G, plies, playouts, len(rec0), hits[0], hits[1], xst))
     assert len(rec0) > 0 and rec0.shape == rec1.shape and np.array_equal(rec0, rec1)
-    assert {k: st0[k] for k in ("games", "red_wins", "black_wins", "draws", "plies")} == {k: st1[k] for k in ("games", "red_wins", "black_wins", "draws", "plies")}
-    assert hits[0] > 0
+    assert rec0.shape == rec2.shape and np.array_equal(rec0, rec2)
+    keys = ("games", "red_wins", "black_wins", "draws", "plies")
+    assert {k: st0[k] for k in keys} == {k: st1[k] for k in keys} == {k: st2[k] for k in keys}
+    assert hits[0] > 0 and xst["hits"] > 0 and xst["written"] > 0
+    assert st2["lock_steps"] <= st1["lock_steps"] <= st0["lock_steps"]
 
 
 def test_ring_overflow_is_reported_not_silently_drained():
