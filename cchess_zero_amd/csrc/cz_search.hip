@@ -277,9 +277,11 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                     pk = wave_pack_board(b, side, lane);
                     bool hit = false;
                     int src = 0;
+                    unsigned long long xk = 0ull;   // XC: the cross-tree bucket's keys, requested together with the tree's own
                     if (may_cache) {
                         const size_t eb0 = (size_t)g * CZ_EC_ENTRIES + (size_t)ec_bucket(key) * 64;
                         const unsigned long long ek = t.ec_key[eb0 + lane];
+                        if (XC) xk = czx_key(t)[(size_t)(xc_bucket(key) & t.xc_mask) * 64 + lane];   // one wait for both probes
                         const int en = t.ec_node[eb0 + lane];
                         const float ev = t.ec_val[eb0 + lane];
                         // every entry of the bucket with the leaf's key is a candidate (after a key collision two positions
@@ -303,7 +305,6 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                     long long xe = -1;
                     if (XC && !hit && may_cache) {
                         const size_t xb0 = (size_t)(xc_bucket(key) & t.xc_mask) * 64;
-                        const unsigned long long xk = czx_key(t)[xb0 + lane];
                         for (unsigned long long m = __ballot(xk == key); m; m &= m - 1ull) {
                             const int hl = __ffsll((long long)m) - 1;
                             const uint32_t lb = lane < 12 ? czx_board(t)[(xb0 + hl) * 12 + lane] : 0u;
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_sel
 // ... and with the cross-tree level behind it (cz_search_set_xcache).  Their own instantiations: the extra probe costs registers
 // (65 VGPRs: 7 waves per SIMD) that the plain cache kernels (59) do not pay.
 template <typename T>
-__global__ __launch_bounds__(64) void k_select_xcache(CzTrees t, CzTables tab, int G, int mode,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void k_select_xcache(CzTrees t, CzTables tab, int G, int mode,
                                                       const uint8_t *__restrict__ active, T *__restrict__ planes, int C,
                                                       T one, uint8_t *__restrict__ needs_eval, int parity, int sim_target, int extra) {
     select_body<T, false, true, true>(t, tab, G, mode, active, planes, C, one, needs_eval, parity, sim_target, extra);
