@@ -575,9 +575,20 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         CZ_T8_STAMP(1);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
+#if defined(CZ_T8_SKIPTEST)   // measurement only (tools/experiments/tower_skip_ubench.hip; never defined in the library): the first
+            // CZ_T8_SKIPTEST taps of every layer run a slab body WITHOUT the MFMAs of the wave's third cell tile — wrong results;
+            // what issuing 1/27 .. 1/3 fewer MFMAs buys in wall time under the power governor (zero-work removal)
+            if (tap < CZ_T8_SKIPTEST) {
+                T8_RUN(TW8_SKIP_ASM_H0, TW8F_SKIP_ASM_H0, ab, key)
+                tap_addr(tap + 1, nab, nkey);
+                T8_RUN(TW8_SKIP_ASM_H1, TW8F_SKIP_ASM_H1, nab, nkey)
+            } else
+#endif
+            {
             T8_RUN(TW8_SLAB_ASM_H0, TW8F_SLAB_ASM_H0, ab, key)      // two 16 KB slabs per tap
             tap_addr(tap + 1, nab, nkey);
             T8_RUN(TW8_SLAB_ASM_H1, TW8F_SLAB_ASM_H1, nab, nkey)
+            }
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
 #if defined(CZ_T8_TRACE) && CZ_T8_TRACE >= 2

@@ -60,7 +60,8 @@ inline void czm_build_tables(const int16_t *lut, CzmTables *t) {
     }
 }
 
-struct CzmSet { uint32_t a0, a1, a2; };   // squares 0..31, 32..63, 64..89
+struct CzmSet { uint64_t lo; uint32_t hi; };   // squares 0..63, 64..89 (two sources, not three: a three-way word select by square
+                                                // index made hipcc put the sets into scratch and index them there)
 
 CZM_FN uint32_t czm_dot4(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -71,35 +72,28 @@ CZM_FN uint32_t czm_dot4(uint32_t a, uint32_t b, uint32_t c) {
 }
 CZM_FN uint32_t czm_low(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << (n & 31)) - 1u); }   // bits 0 .. n-1, 0 <= n <= 32
 CZM_FN bool czm_tst(const CzmSet &s, int q) {   // 0 <= q < 90
-    const uint32_t wd = q < 32 ? s.a0 : (q < 64 ? s.a1 : s.a2);
-    return ((wd >> (q & 31)) & 1u) != 0u;
+    const uint32_t v = q < 64 ? (uint32_t)(s.lo >> (q & 63)) : s.hi >> (q & 31);
+    return (v & 1u) != 0u;
 }
-// low 32 bits of (hi:lo) >> sh, 0 <= sh < 32 (one v_alignbit_b32)
-CZM_FN uint32_t czm_funnel(uint32_t hi, uint32_t lo, int sh) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
-#else
-    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-#endif
+// the 9 bits of rank y (squares 9 y .. 9 y + 8)
+CZM_FN uint32_t czm_rank(const CzmSet &s, int y) {
+    const int p = 9 * y;                              // 0 .. 81
+    uint32_t v;
+    if (p < 56) v = (uint32_t)(s.lo >> p);            // ranks 0..6: inside lo
+    else if (p == 63) v = (uint32_t)(s.lo >> 63) | (s.hi << 1);   // rank 7: square 63 in lo, 64..71 in hi
+    else v = s.hi >> ((p - 64) & 31);                 // ranks 8, 9
+    return v & 0x1FFu;
 }
-// bits [p, p + 32) of the 96-bit value (a2:a1:a0), 0 <= p < 90 (bits beyond 95 read as 0)
-CZM_FN uint32_t czm_bits(const CzmSet &s, int p) {
-    const uint32_t lo = p < 32 ? s.a0 : (p < 64 ? s.a1 : s.a2);
-    const uint32_t hi = p < 32 ? s.a1 : (p < 64 ? s.a2 : 0u);
-    return czm_funnel(hi, lo, p & 31);
+// lowest / highest square of a set, -1 when it is empty — no loops: a kind has at most two pieces (pawns: five), so its squares
+// are the set's lowest and highest bit, and a lane with fewer pieces just computes a field it then zeroes
+CZM_FN int czm_lowest(const CzmSet &s) {
+    return s.lo ? __builtin_ctzll(s.lo) : (s.hi ? 64 + __builtin_ctz(s.hi) : -1);
 }
-// lowest square of the set (or -1) and its removal
-CZM_FN int czm_pop(CzmSet &s) {
-    if (s.a0) { const int b = __builtin_ctz(s.a0); s.a0 &= s.a0 - 1u; return b; }
-    if (s.a1) { const int b = __builtin_ctz(s.a1); s.a1 &= s.a1 - 1u; return 32 + b; }
-    if (s.a2) { const int b = __builtin_ctz(s.a2); s.a2 &= s.a2 - 1u; return 64 + b; }
-    return -1;
+CZM_FN int czm_highest(const CzmSet &s) {
+    return s.hi ? 95 - __builtin_clz(s.hi) : (s.lo ? 63 - __builtin_clzll(s.lo) : -1);
 }
-CZM_FN int czm_first(const CzmSet &s) {
-    if (s.a0) return __builtin_ctz(s.a0);
-    if (s.a1) return 32 + __builtin_ctz(s.a1);
-    if (s.a2) return 64 + __builtin_ctz(s.a2);
-    return -1;
+CZM_FN CzmSet czm_without(const CzmSet &s, int q) {   // q < 0: unchanged
+    return CzmSet{s.lo & ~((q >= 0 && q < 64) ? 1ull << (q & 63) : 0ull), s.hi & ~(q >= 64 ? 1u << (q & 31) : 0u)};
 }
 
 // "byte != 0" of the 90 board bytes XOR rep (rep = 0: occupancy; rep = a piece code in every byte: "byte != code")
@@ -115,17 +109,18 @@ CZM_FN CzmSet czm_nonzero_set(const uint32_t (&w)[23], uint32_t rep) {
         }
         out[k >> 3] |= byte << ((k >> 1 & 3) * 8);   // squares 4k .. 4k+7 -> bits (4k & 31) ..
     }
-    return CzmSet{out[0], out[1], out[2]};
+    return CzmSet{(uint64_t)out[0] | ((uint64_t)out[1] << 32), out[2]};
 }
 CZM_FN CzmSet czm_equal_set(const uint32_t (&w)[23], uint32_t code) {
     const CzmSet n = czm_nonzero_set(w, code * 0x01010101u);
-    return CzmSet{~n.a0, ~n.a1, ~n.a2 & 0x03FFFFFFu};
+    return CzmSet{~n.lo, ~n.hi & 0x03FFFFFFu};
 }
 
 // 10 bits of file x (bit r = square 9 r + x) of a set
 CZM_FN uint32_t czm_file(const CzmSet &s, int x) {   // 0 <= x <= 8
-    // t = s >> x, then the bits at the constant positions 9 r: 0, 9, 18, 27 | 36, 45, 54, 63 = t1 bits 4, 13, 22, 31 | 72, 81 = t2 bits 8, 17
-    const uint32_t t0 = czm_funnel(s.a1, s.a0, x), t1 = czm_funnel(s.a2, s.a1, x), t2 = s.a2 >> x;
+    // t = s >> x, then the bits at the constant positions 9 r: 0 .. 63 in the low 64 bits, 72 and 81 = bits 8 and 17 above
+    const uint64_t t = x ? (s.lo >> x) | ((uint64_t)s.hi << (64 - x)) : s.lo;
+    const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32), t2 = s.hi >> x;
     return (t0 & 1u) | ((t0 >> 9 & 1u) << 1) | ((t0 >> 18 & 1u) << 2) | ((t0 >> 27 & 1u) << 3) | ((t1 >> 4 & 1u) << 4) | ((t1 >> 13 & 1u) << 5) |
            ((t1 >> 22 & 1u) << 6) | ((t1 >> 31) << 7) | ((t2 >> 8 & 1u) << 8) | ((t2 >> 17 & 1u) << 9);
 }
@@ -133,7 +128,8 @@ CZM_FN uint32_t czm_file(const CzmSet &s, int x) {   // 0 <= x <= 8
 // destinations of a rook / cannon at index p on a line of `len` squares: o = occupancy bits, e = enemy bits (main.py:757-833,
 // 947-1062): the empty run in both directions; rook: + the first occupied square if it is an enemy; cannon: + the SECOND
 // occupied square (behind exactly one screen) if it is an enemy
-CZM_FN uint32_t czm_line_dests(uint32_t o, uint32_t e, int p, int len, bool cannon) {
+template <bool cannon>
+CZM_FN uint32_t czm_line_dests(uint32_t o, uint32_t e, int p, int len) {
     uint32_t d;
     {   // towards index 0
         const uint32_t m = o & czm_low(p);
@@ -169,134 +165,135 @@ CZM_FN void czm_or_field(OrWord &or_word, int bit, uint32_t field) {
     or_word(wi + 1, off ? field >> (32 - off) : 0u);     // wi + 1 <= 64 for every base + 25-bit field
 }
 
+struct CzmNo { static constexpr bool value = false; };
+struct CzmYes { static constexpr bool value = true; };
+
 // w: the 90 board bytes (sq = y * 9 + x, code = 1 + index in "KARBNPCkarbnpc"; bytes 90, 91 of w[22] must be zero);
 // side 0 = red ('w', codes 1..7, home ranks 0..4) to move, 1 = black.  Returns the number of legal moves, or -1 when the
 // position is not a Xiangqi position the vocabulary can express (more than 16 pieces of a colour; an advisor / bishop move
-// without a label).
+// without a label).  Branch-free apart from the loops: every lane runs every kind's code; a missing piece (square -1) computes
+// on square 0 and its field is zeroed before it is OR-ed in.
 template <typename OrWord>
 CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, OrWord or_word) {
     const uint32_t own0 = side ? 7u : 0u;   // own piece code = kind + own0 (kind: K 1, A 2, R 3, B 4, N 5, P 6, C 7)
     const CzmSet occ = czm_nonzero_set(w, 0u);
-    CzmSet K = czm_equal_set(w, 1u + own0), A = czm_equal_set(w, 2u + own0), R = czm_equal_set(w, 3u + own0);
-    CzmSet B = czm_equal_set(w, 4u + own0), N = czm_equal_set(w, 5u + own0), P = czm_equal_set(w, 6u + own0);
-    const CzmSet C = czm_equal_set(w, 7u + own0);
+    const CzmSet K = czm_equal_set(w, 1u + own0), A = czm_equal_set(w, 2u + own0), R = czm_equal_set(w, 3u + own0);
+    const CzmSet B = czm_equal_set(w, 4u + own0), N = czm_equal_set(w, 5u + own0), C = czm_equal_set(w, 7u + own0);
+    CzmSet P = czm_equal_set(w, 6u + own0);
     const CzmSet EK = czm_equal_set(w, side ? 1u : 8u);           // the enemy king
-    const CzmSet own = {K.a0 | A.a0 | R.a0 | B.a0 | N.a0 | P.a0 | C.a0, K.a1 | A.a1 | R.a1 | B.a1 | N.a1 | P.a1 | C.a1,
-                        K.a2 | A.a2 | R.a2 | B.a2 | N.a2 | P.a2 | C.a2};
-    const CzmSet enemy = {occ.a0 & ~own.a0, occ.a1 & ~own.a1, occ.a2 & ~own.a2};
-    bool err = __builtin_popcount(own.a0) + __builtin_popcount(own.a1) + __builtin_popcount(own.a2) > 16;
+    const CzmSet own = {K.lo | A.lo | R.lo | B.lo | N.lo | P.lo | C.lo, K.hi | A.hi | R.hi | B.hi | N.hi | P.hi | C.hi};
+    const CzmSet enemy = {occ.lo & ~own.lo, occ.hi & ~own.hi};
+    bool err = __builtin_popcountll(own.lo) + __builtin_popcount(own.hi) > 16;
     int count = 0;
-    auto notown = [&](int q) { return !czm_tst(own, q); };      // validate_move, main.py:727: empty or enemy
-
-    // ---- rooks and cannons (at most 2 + 2; a lane with fewer idles)
-    CzmSet S = {R.a0 | C.a0, R.a1 | C.a1, R.a2 | C.a2};
-#pragma unroll 1
-    for (int it = 0; it < 4; ++it) {
-        const int sq = czm_pop(S);
-        if (sq < 0) continue;
-        const int y = sq / 9, x = sq - y * 9;
-        const bool cannon = czm_tst(C, sq);
-        const uint32_t rd = czm_line_dests(czm_bits(occ, y * 9) & 0x1FFu, czm_bits(enemy, y * 9) & 0x1FFu, x, 9, cannon);
-        const uint32_t fd = czm_line_dests(czm_file(occ, x), czm_file(enemy, x), y, 10, cannon);
-        const uint32_t f = czm_ortho_field(rd, fd, x, y);
+    auto notown = [&](int q) { return !czm_tst(own, q < 0 ? 0 : (q > 89 ? 89 : q)); };   // validate_move, main.py:727: empty or enemy
+    auto put = [&](int bit, uint32_t f, bool ok) {
+        f = ok ? f : 0u;
         count += __builtin_popcount(f);
-        czm_or_field(or_word, T.base[sq], f);
+        czm_or_field(or_word, bit, f);
+    };
+
+    // ---- rooks, then cannons (main.py:757-833, 947-1062): at most two of each — the kind's lowest and highest square
+    auto slider = [&](int sq, bool ok, auto is_cannon) {
+        constexpr bool cannon = decltype(is_cannon)::value;
+        const int q = ok ? sq : 0;
+        const int y = q / 9, x = q - y * 9;
+        const uint32_t rd = czm_line_dests<cannon>(czm_rank(occ, y), czm_rank(enemy, y), x, 9);
+        const uint32_t fd = czm_line_dests<cannon>(czm_file(occ, x), czm_file(enemy, x), y, 10);
+        put(T.base[q], czm_ortho_field(rd, fd, x, y), ok);
+    };
+    {
+        const int r0 = czm_lowest(R), r1 = czm_highest(R), c0 = czm_lowest(C), c1 = czm_highest(C);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) slider(it ? r1 : r0, it ? r1 > r0 : r0 >= 0, CzmNo{});
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) slider(it ? c1 : c0, it ? c1 > c0 : c0 >= 0, CzmYes{});
     }
     // ---- knights (main.py:835-856): jump j lands on (x + dx, y + dy); the leg is the orthogonal neighbour on the long side
-#pragma unroll 1
-    for (int it = 0; it < 2; ++it) {
-        const int sq = czm_pop(N);
-        if (sq < 0) continue;
-        const int y = sq / 9, x = sq - y * 9;
-        const uint32_t on = T.knon[sq];
+    auto knight = [&](int sq, bool ok) {
+        const int q0 = ok ? sq : 0;
+        const uint32_t on = T.knon[q0];
         uint32_t f = 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int dx = (j == 0 || j == 2) ? -2 : (j == 1 || j == 5) ? -1 : (j == 3 || j == 7) ? 1 : 2;
             const int dy = (j == 1 || j == 3) ? -2 : (j == 0 || j == 4) ? -1 : (j == 2 || j == 6) ? 1 : 2;
-            const int leg = (dx == 2 || dx == -2) ? sq + dx / 2 : sq + (dy / 2) * 9;
+            const int leg = (dx == 2 || dx == -2) ? q0 + dx / 2 : q0 + (dy / 2) * 9;
             const bool onb = ((on >> j) & 1u) != 0u;
-            const int q = onb ? sq + dy * 9 + dx : sq, lg = onb ? leg : sq;   // keep the bit tests on the board
-            const bool ok = onb && notown(q) && !czm_tst(occ, lg);
-            f |= (uint32_t)ok << __builtin_popcount(on & czm_low(j));
+            const int q = onb ? q0 + dy * 9 + dx : q0, lg = onb ? leg : q0;   // keep the bit tests on the board
+            const bool good = (int)onb & (int)notown(q) & (int)!czm_tst(occ, lg);
+            f |= (uint32_t)good << __builtin_popcount(on & czm_low(j));
         }
-        (void)x; (void)y;
-        count += __builtin_popcount(f);
-        czm_or_field(or_word, T.base[sq] + 17, f);
+        put(T.base[q0] + 17, f, ok);
+    };
+    {
+        const int n0 = czm_lowest(N), n1 = czm_highest(N);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) knight(it ? n1 : n0, it ? n1 > n0 : n0 >= 0);
     }
     // ---- king (main.py:919-946) + the flying general (main.py:1097-1107: kings on one file, nothing between)
     {
-        const int sq = czm_first(K);
-        if (sq >= 0) {
-            const int y = sq / 9, x = sq - y * 9;
-            const int ylo = side ? 7 : 0, yhi = side ? 9 : 2;
-            uint32_t rd = 0u, fd = 0u;
-            if (x - 1 >= 3 && x - 1 <= 5 && y >= ylo && y <= yhi && notown(sq - 1)) rd |= 1u << (x - 1);
-            if (x + 1 >= 3 && x + 1 <= 5 && y >= ylo && y <= yhi && notown(sq + 1)) rd |= 1u << (x + 1);
-            if (y - 1 >= ylo && y - 1 <= yhi && x >= 3 && x <= 5 && notown(sq - 9)) fd |= 1u << (y - 1);
-            if (y + 1 >= ylo && y + 1 <= yhi && x >= 3 && x <= 5 && notown(sq + 9)) fd |= 1u << (y + 1);
-            const int eq = czm_first(EK);
-            if (eq >= 0) {
-                const int ey = eq / 9, ex = eq - ey * 9;
-                if (ex == x) {
-                    const int lo = y < ey ? y : ey, hi = y < ey ? ey : y;
-                    const uint32_t between = czm_low(hi) & ~czm_low(lo + 1);
-                    if ((czm_file(occ, x) & between) == 0u) fd |= 1u << ey;
-                }
-            }
-            const uint32_t f = czm_ortho_field(rd, fd, x, y);
-            count += __builtin_popcount(f);
-            czm_or_field(or_word, T.base[sq], f);
-        }
+        const int sq = czm_lowest(K), eq = czm_lowest(EK);
+        const bool ok = sq >= 0;
+        const int q = ok ? sq : 0;
+        const int y = q / 9, x = q - y * 9;
+        const int ylo = side ? 7 : 0, yhi = side ? 9 : 2;
+        const bool iny = (y >= ylo) & (y <= yhi), inx = (x >= 3) & (x <= 5);
+        uint32_t rd = 0u, fd = 0u;
+        rd |= (uint32_t)(iny & (x >= 4) & (x <= 6) & notown(q - 1)) << ((x + 8) % 9);      // x - 1, kept in range
+        rd |= (uint32_t)(iny & (x >= 2) & (x <= 4) & notown(q + 1)) << ((x + 1) % 9);
+        fd |= (uint32_t)(inx & (y - 1 >= ylo) & (y - 1 <= yhi) & notown(q - 9)) << ((y + 9) % 10);   // y - 1
+        fd |= (uint32_t)(inx & (y + 1 >= ylo) & (y + 1 <= yhi) & notown(q + 9)) << ((y + 1) % 10);
+        const int e = eq >= 0 ? eq : 0;
+        const int ey = e / 9, ex = e - ey * 9;
+        const int lo = y < ey ? y : ey, hi = y < ey ? ey : y;
+        const uint32_t between = czm_low(hi) & ~czm_low(lo + 1);
+        fd |= (uint32_t)((eq >= 0) & (ex == x) & ((czm_file(occ, x) & between) == 0u)) << ey;
+        put(T.base[q], czm_ortho_field(rd, fd, x, y), ok);
     }
-    // ---- pawns (main.py:1063-1095): black advances to y-1, red to y+1; sideways once past the river
+    // ---- pawns (main.py:1063-1095): black advances to y-1, red to y+1; sideways once past the river; at most five
 #pragma unroll 1
     for (int it = 0; it < 5; ++it) {
-        const int sq = czm_pop(P);
-        if (sq < 0) continue;
-        const int y = sq / 9, x = sq - y * 9;
-        uint32_t rd = 0u, fd = 0u;
+        const int sq = czm_lowest(P);
+        P = czm_without(P, sq);
+        const bool ok = sq >= 0;
+        const int q = ok ? sq : 0;
+        const int y = q / 9, x = q - y * 9;
         const int fy = side ? y - 1 : y + 1;
-        if (fy >= 0 && fy <= 9 && notown(fy * 9 + x)) fd |= 1u << fy;
-        if (side ? y < 5 : y > 4) {
-            if (x + 1 <= 8 && notown(sq + 1)) rd |= 1u << (x + 1);
-            if (x - 1 >= 0 && notown(sq - 1)) rd |= 1u << (x - 1);
-        }
-        const uint32_t f = czm_ortho_field(rd, fd, x, y);
-        count += __builtin_popcount(f);
-        czm_or_field(or_word, T.base[sq], f);
+        const bool fin = (fy >= 0) & (fy <= 9), river = side ? y < 5 : y > 4;
+        const uint32_t fd = (uint32_t)(fin & notown(fy * 9 + x)) << (fin ? fy : 0);
+        uint32_t rd = (uint32_t)(river & (x <= 7) & notown(q + 1)) << ((x + 1) % 9);
+        rd |= (uint32_t)(river & (x >= 1) & notown(q - 1)) << ((x + 8) % 9);
+        put(T.base[q], czm_ortho_field(rd, fd, x, y), ok);
     }
     // ---- advisors (main.py:889-918: one diagonal step inside the palace) and bishops (main.py:857-888: two diagonal steps,
     //      the eye empty, own half of the board); their labels are the 48 literals at the end of the vocabulary
-#pragma unroll
-    for (int kind = 0; kind < 2; ++kind) {
-        CzmSet &Q = kind ? B : A;
+    auto literal = [&](int sq, bool ok, int kind) {
+        const int q0 = ok ? sq : 0;
         const int st = kind ? 2 : 1;
         const int ylo = kind ? (side ? 5 : 0) : (side ? 7 : 0), yhi = kind ? (side ? 9 : 4) : (side ? 9 : 2);
         const int xlo = kind ? 0 : 3, xhi = kind ? 8 : 5;
-#pragma unroll 1
-        for (int it = 0; it < 2; ++it) {
-            const int sq = czm_pop(Q);
-            if (sq < 0) continue;
-            const int y = sq / 9, x = sq - y * 9;
+        const int y = q0 / 9, x = q0 - y * 9;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int sy = (d < 2 ? -1 : 1), sx = (d == 0 || d == 3) ? -1 : 1;
-                const int ty = y + sy * st, tx = x + sx * st;
-                const bool in = ty >= ylo && ty <= yhi && tx >= xlo && tx <= xhi;
-                const int q = in ? ty * 9 + tx : sq, eye = in ? (y + sy) * 9 + x + sx : sq;
-                const bool ok = in && notown(q) && (kind == 0 || !czm_tst(occ, eye));
-                if (ok) {
-                    const uint32_t l = T.ab[kind][sq * 4 + d];
-                    if (l == 0xFFu) err = true;
-                    else {
-                        const int bit = CZM_NLIT_BASE + (int)l;
-                        or_word(bit >> 5, 1u << (bit & 31));
-                        count += 1;
-                    }
-                }
-            }
+        for (int d = 0; d < 4; ++d) {
+            const int sy = (d < 2 ? -1 : 1), sx = (d == 0 || d == 3) ? -1 : 1;
+            const int ty = y + sy * st, tx = x + sx * st;
+            const bool in = (ty >= ylo) & (ty <= yhi) & (tx >= xlo) & (tx <= xhi);
+            const int q = in ? ty * 9 + tx : q0, eye = in ? (y + sy) * 9 + x + sx : q0;
+            const bool good = (int)ok & (int)in & (int)notown(q) & (int)(kind == 0 || !czm_tst(occ, eye));
+            const uint32_t l = T.ab[kind][q0 * 4 + d];
+            err |= good & (l == 0xFFu);
+            const int bit = CZM_NLIT_BASE + (int)(l & 63u);
+            const bool set = good & (l != 0xFFu);
+            or_word(bit >> 5, set ? 1u << (bit & 31) : 0u);
+            count += set ? 1 : 0;
         }
+    };
+    {
+        const int a0 = czm_lowest(A), a1 = czm_highest(A), b0 = czm_lowest(B), b1 = czm_highest(B);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) literal(it ? a1 : a0, it ? a1 > a0 : a0 >= 0, 0);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) literal(it ? b1 : b0, it ? b1 > b0 : b0 >= 0, 1);
     }
     return err ? -1 : count;
 }

@@ -247,6 +247,12 @@ def main():
     txt += "\n// position-per-wave variant (4 waves, 3 cell tiles x 4 channel tiles each, two fragment sets)\n"
     txt += emit("TWP_SLAB_ASM_H0", slabP(0)) + "\n" + emit("TWP_SLAB_ASM_H1", slabP(1))
     txt += "\n" + emit("TWP_SLAB_ASM_FIRST", slabP(0, first=True))
+    # zero-work elasticity experiment (tower_skip_ubench.hip): k_tower8_c128's slab with the MFMAs of the wave's third cell tile
+    # removed (a third of the MFMAs; wrong results, timing only) — what does issuing fewer MFMAs buy under the power governor?
+    drop = lambda L: [l for l in L if not (l.startswith("v_mfma") and ("%[c20]" in l or "%[c21]" in l))]
+    txt += "\n// k_tower8_c128 slab without the third cell tile's MFMAs (timing experiment)\n"
+    txt += emit("TW8F_SKIP_ASM_H0", f16(drop(slab8(0)))) + "\n" + emit("TW8F_SKIP_ASM_H1", f16(drop(slab8(1)))) + "\n"
+    txt += emit("TW8_SKIP_ASM_H0", drop(slab8(0))) + "\n" + emit("TW8_SKIP_ASM_H1", drop(slab8(1))) + "\n"
     if os.environ.get("CZ_TP_EXP"):   # timing experiments only (wrong results): 1 = no barrier, 2 = no DMA, 4 = no LDS waits, 8 = no fragment reads, 16 = no address math
         e = int(os.environ["CZ_TP_EXP"])
         txt = txt.replace("#define TWP_SLAB_ASM_H", "#define TWP_REAL_SLAB_ASM_H")

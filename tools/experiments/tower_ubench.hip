@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
     const int grid = variant == 4 ? (B + TW_P - 1) / TW_P : (B + T8_P - 1) / T8_P;
 #define LAUNCH() do { if (variant == 4) hipLaunchKernelGGL(k_tower_c128, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); \
                       else if (variant == 1) hipLaunchKernelGGL(k_towerp_c128, dim3(grid), dim3(TP_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks); \
-                      else hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks, (const int *)nullptr); } while (0)
+                      else hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, in, w, bias, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, 2 * nblocks, (const int *)nullptr, (unsigned long long *)nullptr); } while (0)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) LAUNCH();
     CK(hipDeviceSynchronize());

@@ -49,8 +49,8 @@ int main(int argc, char **argv) {
     auto launch = [&](int which, bool planes_path) {
         const uint16_t *i_ = planes_path ? nullptr : in, *p_ = planes_path ? pl : nullptr;
         if (which == 0) {
-            if (f16) hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, i_, w, bias, out[0], hw, hb, ho[0], p_, w0, b0, B, nl, nullptr);
-            else hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, i_, w, bias, out[0], hw, hb, ho[0], p_, w0, b0, B, nl, nullptr);
+            if (f16) hipLaunchKernelGGL((k_tower8_c128<true, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, i_, w, bias, out[0], hw, hb, ho[0], p_, w0, b0, B, nl, nullptr, nullptr);
+            else hipLaunchKernelGGL((k_tower8_c128<false, 4>), dim3(grid), dim3(T8_THREADS), T8_LDS_BYTES, 0, i_, w, bias, out[0], hw, hb, ho[0], p_, w0, b0, B, nl, nullptr, nullptr);
         } else if (var == 2) {
             if (f16) hipLaunchKernelGGL((k_towerd_c128<true>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, 0, i_, w, bias, out[1], hw, hb, ho[1], p_, w0, b0, B, nl, nullptr);
             else hipLaunchKernelGGL((k_towerd_c128<false>), dim3(grid), dim3(TD_THREADS), TD_LDS_BYTES, 0, i_, w, bias, out[1], hw, hb, ho[1], p_, w0, b0, B, nl, nullptr);
