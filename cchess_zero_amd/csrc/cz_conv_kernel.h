@@ -573,22 +573,25 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             TW_LOADSET(0, 0, 512, f0, ab, key, vb);   // waited for by the first k-step itself
         }
         CZ_T8_STAMP(1);
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
+        int tap = 0;
 #if defined(CZ_T8_SKIPTEST)   // measurement only (tools/experiments/tower_skip_ubench.hip; never defined in the library): the first
-            // CZ_T8_SKIPTEST taps of every layer run a slab body WITHOUT the MFMAs of the wave's third cell tile — wrong results;
-            // what issuing 1/27 .. 1/3 fewer MFMAs buys in wall time under the power governor (zero-work removal)
-            if (tap < CZ_T8_SKIPTEST) {
-                T8_RUN(TW8_SKIP_ASM_H0, TW8F_SKIP_ASM_H0, ab, key)
-                tap_addr(tap + 1, nab, nkey);
-                T8_RUN(TW8_SKIP_ASM_H1, TW8F_SKIP_ASM_H1, nab, nkey)
-            } else
+        // CZ_T8_SKIPTEST taps of every layer run a slab body WITHOUT the MFMAs of the wave's third cell tile — wrong results;
+        // what issuing 1/9 .. 1/3 fewer MFMAs buys in wall time under the power governor (zero-work removal).  A
+        // loop of its own: the two slab bodies under one branch made hipcc copy the accumulators at the join
+#pragma unroll 1
+        for (; tap < CZ_T8_SKIPTEST; ++tap) {
+            T8_RUN(TW8_SKIP_ASM_H0, TW8F_SKIP_ASM_H0, ab, key)
+            tap_addr(tap + 1, nab, nkey);
+            T8_RUN(TW8_SKIP_ASM_H1, TW8F_SKIP_ASM_H1, nab, nkey)
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+        }
 #endif
-            {
+#pragma unroll 1
+        for (; tap < 9; ++tap) {
             T8_RUN(TW8_SLAB_ASM_H0, TW8F_SLAB_ASM_H0, ab, key)      // two 16 KB slabs per tap
             tap_addr(tap + 1, nab, nkey);
             T8_RUN(TW8_SLAB_ASM_H1, TW8F_SLAB_ASM_H1, nab, nkey)
-            }
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
 #if defined(CZ_T8_TRACE) && CZ_T8_TRACE >= 2
