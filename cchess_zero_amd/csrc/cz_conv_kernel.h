@@ -366,6 +366,15 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
     const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + (unsigned)Geo::THREADS * 16u;   // second DMA piece of a slab
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // Cell order inside the workgroup (round 4): LDS row k of (position p, cell y * 10 + x) is 40 y + 10 p + x — the cells of one
+    // board rank of all four positions are adjacent — and the 384 GEMM rows are the 24 padding rows FIRST, then k = 0 .. 359.  The
+    // first two row tiles then hold nothing but padding and rank-0 cells, whose three dy = -1 taps are off the board: those
+    // MFMAs multiply the zero row and are not issued (T8_SKIP below).  dx = +-1 is still the neighbouring row, dy = +-1 is 40
+    // rows away, a tile's 32 lanes still read 32 consecutive rows (the chunk swizzle stays conflict-free).
+    auto lds_row_of = [](int natural) {   // natural = p * 90 + y * 10 + x
+        const int p = natural / 90, c = natural - p * 90, y = c / 10, x = c - y * 10;
+        return 40 * y + 10 * p + x;
+    };
 
     auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
         const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * Geo::SLAB_BYTES;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             const int r = idx >> 4, c = idx & 15;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < nrows) v = g[idx];
-            *reinterpret_cast<uint4 *>(smem + lds_addr(r * CV_ROWB, c)) = v;
+            *reinterpret_cast<uint4 *>(smem + lds_addr(lds_row_of(r) * CV_ROWB, c)) = v;
         }
     } else {
         const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
@@ -409,21 +418,25 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int rowb[CV_RT], tapmask[CV_RT];
+    // a cell group owns the row tiles wr, wr + 4, wr + 8: the two all-rank-0 tiles (0 and 1) then belong to groups 0 and 1, i.e. to
+    // one wave on EACH of the four SIMDs (waves w and w + 4 share a SIMD): the MFMAs they skip are balanced over the SIMDs
+    int rowb[CV_RT], tapmask[CV_RT], natb[CV_RT];
 #pragma unroll
     for (int i = 0; i < CV_RT; ++i) {
-        const int r = 32 * (wr * CV_RT + i) + l31;
-        const int pix = r % 90, h = pix / 10, w = pix - h * 10;
-        rowb[i] = r * CV_ROWB;
+        const int k = 32 * (wr + 4 * i) + l31 - 24;       // LDS row; k < 0: one of the 24 padding rows
+        const int kk = k < 0 ? 0 : k;
+        const int h = kk / 40, rem = kk - h * 40, pp = rem / 10, w = rem - pp * 10;
+        rowb[i] = kk * CV_ROWB;
+        natb[i] = (pp * 90 + h * 10 + w) * 32;           // the cell's 32 bytes of input planes (natural order)
         int m = 0;
         for (int t = 0; t < 9; ++t) {
             const int y = h + t / 3 - 1, x = w + t % 3 - 1;
-            if (r < Geo::ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+            if (k >= 0 && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
         }
         tapmask[i] = m;
     }
     auto tap_addr = [&](int tap, int (&ab)[CV_RT], int (&key)[CV_RT]) {
-        const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
+        const int delta = ((tap / 3 - 1) * 40 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
             const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : Geo::ZERO_OFF;
@@ -444,13 +457,13 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     auto refresh_rb = [&]() {
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
-            const int r = 32 * (wr * CV_RT + i) + l31;
-            rb[i] = (r < Geo::ROWS ? r : 0) * CV_ROWB;
+            const int k = 32 * (wr + 4 * i) + l31 - 24;
+            rb[i] = (k < 0 ? 0 : k) * CV_ROWB;
             asm volatile("" : "+v"(rb[i]));
         }
     };
     auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
-        live = 32 * (wr * CV_RT + i) + l31 < Geo::ROWS;
+        live = 32 * (wr + 4 * i) + l31 >= 24;
         const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
         return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
     };
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             bf16x8 af[CV_RT];
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) {
-                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : Geo::ZERO_OFF;
+                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + (natb[i] + shift * 32) : Geo::ZERO_OFF;
                 af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
             }
 #pragma unroll
@@ -535,12 +548,30 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
               [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
               [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
               [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst)                                                \
-            : "memory")
+            : "memory", "scc")   /* the bodies' s_add_u32 (M0 stepping) writes SCC */
 #define T8_SLAB_ARGS()                                                                                          \
         const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << Geo::SLAB_SHIFT); \
         const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                     \
         const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * Geo::SLAB_BYTES; \
         const int ldst = Geo::W_OFF + ((((unsigned)g + 3u) & 3u) << Geo::SLAB_SHIFT) + (wave_u << 10);
+#define T8_SLABV(ASMSTR, NAB, NKEY)   /* the same operands + the wave-uniform skip mask; clobbers VCC */                 \
+        asm volatile(ASMSTR                                                                                      \
+            : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),          \
+              [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),                                                        \
+              [f0a0] "+v"(f0.a[0]), [f0a1] "+v"(f0.a[1]), [f0a2] "+v"(f0.a[2]), [f0b0] "+v"(f0.b[0]), [f0b1] "+v"(f0.b[1]), \
+              [f1a0] "=&v"(f1.a[0]), [f1a1] "=&v"(f1.a[1]), [f1a2] "=&v"(f1.a[2]), [f1b0] "=&v"(f1.b[0]), [f1b1] "=&v"(f1.b[1]), \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [keep] "=&s"(keep)                                     \
+            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),          \
+              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
+              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
+              [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst), [skipm] "s"(skipm)                            \
+            : "memory", "vcc", "scc")
+#define T8_RUNV(BF, HF, NAB, NKEY)                                                                              \
+        {                                                                                                       \
+            T8_SLAB_ARGS()                                                                                      \
+            if constexpr (F16) { T8_SLABV(HF, NAB, NKEY); } else { T8_SLABV(BF, NAB, NKEY); }                   \
+            ++g;                                                                                                \
+        }
 #define T8_RUN(BF, HF, NAB, NKEY)                                                                               \
         {                                                                                                       \
             T8_SLAB_ARGS()                                                                                      \
@@ -549,6 +580,8 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         }
 
     int g = 0;
+    int skipm;   // cell groups 0 and 1 (waves 0..3): their first row tile skips the dy = -1 taps.  Defined by scalar asm so that it IS a scalar register
+    asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cselect_b32 %0, 1, 0" : "=s"(skipm) : "s"(wave_u) : "scc");
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
         f32x16 acc[CV_RT][CV_CT];
@@ -586,6 +619,19 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
         }
+#else
+        // taps 0..2 (dy = -1): cell groups 0 and 1 (waves 0..3) own a first row tile of rank-0 cells and padding only — all its
+        // inputs are the zero row — and branch around that tile's MFMAs inside the slab body (scalar branches on VCC = skipm);
+        // groups 2 and 3 fall through them.  One wave of each kind sits on every SIMD, so every SIMD issues 1/12 fewer MFMAs in
+        // these six slabs (5.6 % of a layer's MFMAs; adding 0 * w is exact: the outputs are bit-identical)
+#pragma unroll 1
+        for (; tap < 3; ++tap) {
+            T8_RUNV(TW8_SKIP0_ASM_H0, TW8F_SKIP0_ASM_H0, ab, key)
+            tap_addr(tap + 1, nab, nkey);
+            T8_RUNV(TW8_SKIP0_ASM_H1, TW8F_SKIP0_ASM_H1, nab, nkey)
+#pragma unroll
+            for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+        }
 #endif
 #pragma unroll 1
         for (; tap < 9; ++tap) {
@@ -620,7 +666,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
         for (int idx = tid; idx < nrows * 16; idx += Geo::THREADS) {
             const int r = idx >> 4, c = idx & 15;
-            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(r * CV_ROWB, c));
+            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(lds_row_of(r) * CV_ROWB, c));
         }
     }
     if (head_out) {
@@ -630,7 +676,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         // The summation order per (cell, channel) is unchanged — chunks in a fixed order, eight products left to right —
         // so the outputs are bit-identical to the earlier kernel and do not depend on the row's position in the batch.
         for (int r = tid; r < nrows; r += Geo::THREADS) {
-            const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
+            const int rowoff = lds_row_of(r) * CV_ROWB, key = (rowoff >> 8) & 15;
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
 #pragma unroll 4
             for (int c = 0; c < 16; ++c) {
@@ -653,8 +699,10 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     }
 }
 #undef T8_SLAB
+#undef T8_SLABV
 #undef T8_SLAB_ARGS
 #undef T8_RUN
+#undef T8_RUNV
 
 
 #undef TW_LOADSET

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
               [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
               [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
               [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst)                                                \
-            : "memory")
+            : "memory", "scc")
 #define XS_RUN(BF, HF, NAB, NKEY)                                                                               \
         {                                                                                                       \
             const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << Geo::SLAB_SHIFT); \

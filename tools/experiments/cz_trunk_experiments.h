@@ -273,7 +273,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void k_tower_c128(const uint16_t *__
               [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
               [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
               [voff1] "v"(voff1), [voff2] "v"(voff2), [voff3] "v"(voff3), [sbase] "s"(sbase), [ldst] "s"(ldst)        \
-            : "memory")
+            : "memory", "scc")
 #define TW_SLAB_ARGS()                                                                                          \
         const int vb = vb0 + (((unsigned)g & 3u) << 14), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << 14);         \
         const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1; /* past the end: re-fetch the last slab (never read) */ \

@@ -132,6 +132,21 @@ def main():
     txt += emit("TW8_SLAB_ASM_H0", slab8(0)) + "\n" + emit("TW8_SLAB_ASM_H1", slab8(1))
     txt += "\n// the same with fp16 operands\n"
     txt += emit("TW8F_SLAB_ASM_H0", f16(slab8(0))) + "\n" + emit("TW8F_SLAB_ASM_H1", f16(slab8(1)))
+    # the dy = -1 taps: a cell group whose FIRST row tile holds only rank-0 cells and padding rows (groups 0 and 1) reads the zero
+    # row for all of that tile's inputs and does not issue its two MFMAs per k-step: a scalar branch around each of them on VCC
+    # (set from the wave-uniform 32-bit %[skipm] at the top of the body; nothing in the body writes VCC).  One body for all waves —
+    # a wave-dependent choice between two bodies makes hipcc copy / spill the accumulators where the paths join.
+    def branchy(L):
+        out = ["s_cmp_lg_u32 %[skipm], 0", "s_cselect_b64 vcc, -1, 0"]
+        for l in L:
+            if l.startswith("v_mfma") and ("%[c00]" in l or "%[c01]" in l):
+                out += ["s_cbranch_vccnz 1f", l, "1:"]
+            else:
+                out.append(l)
+        return out
+    txt += "\n// slab bodies whose first-row-tile MFMAs sit behind a scalar branch (dy = -1 taps), bf16 and fp16\n"
+    txt += emit("TW8_SKIP0_ASM_H0", branchy(slab8(0))) + "\n" + emit("TW8_SKIP0_ASM_H1", branchy(slab8(1))) + "\n"
+    txt += emit("TW8F_SKIP0_ASM_H0", f16(branchy(slab8(0)))) + "\n" + emit("TW8F_SKIP0_ASM_H1", f16(branchy(slab8(1))))
     open(os.path.join(csrc, "cz_tower_slab_asm.inc"), "w").write(txt)
     txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
     txt += "// k_trunk_split_c128: 8 waves / 2 positions, operands split into hi + lo halves, 9 MFMAs per k-step, bf16 and fp16\n"
