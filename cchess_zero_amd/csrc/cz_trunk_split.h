@@ -130,6 +130,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
     auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
     const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + (unsigned)Geo::THREADS * 16u;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // Cell order inside the workgroup (as in k_tower8_c128): LDS row k of (position p, cell y * 10 + x) is 20 y + 10 p + x, and the
+    // 192 GEMM rows are the 12 padding rows FIRST, then k = 0 .. 179: the first row tile holds nothing but padding and the rank-0
+    // cells of both positions, whose dy = -1 taps are off the board — cell group 0 (waves 0..3, one per SIMD) does not issue
+    // that tile's three MFMAs per k-step in taps 0..2 (XS_SKIP0 bodies below)
+    auto lds_row_of = [](int natural) {   // natural = p * 90 + y * 10 + x
+        const int p = natural / 90, c = natural - p * 90, y = c / 10, x = c - y * 10;
+        return 20 * y + 10 * p + x;
+    };
 
     auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
         const unsigned char *src = reinterpret_cast<const unsigned char *>(wpk) + (size_t)slab * Geo::SLAB_BYTES;
@@ -164,21 +172,23 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int rowb[3], tapmask[3];
+    int rowb[3], tapmask[3], natb[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int r = 32 * (wr * 3 + i) + l31;
-        const int pix = r % 90, h = pix / 10, w = pix - h * 10;
-        rowb[i] = r * CV_ROWB;
+        const int k = 32 * (wr * 3 + i) + l31 - 12;       // LDS row; k < 0: one of the 12 padding rows
+        const int kk = k < 0 ? 0 : k;
+        const int h = kk / 20, rem = kk - h * 20, pp = rem / 10, w = rem - pp * 10;
+        rowb[i] = kk * CV_ROWB;
+        natb[i] = (pp * 90 + h * 10 + w) * 32;           // the cell's 32 bytes of input planes (natural order)
         int m = 0;
         for (int t = 0; t < 9; ++t) {
             const int y = h + t / 3 - 1, x = w + t % 3 - 1;
-            if (r < Geo::ROWS && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+            if (k >= 0 && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
         }
         tapmask[i] = m;
     }
     auto tap_addr = [&](int tap, int (&ab)[3], int (&key)[3]) {
-        const int delta = ((tap / 3 - 1) * 10 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
+        const int delta = ((tap / 3 - 1) * 20 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             ab[i] = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : Geo::ZERO_OFF;
@@ -192,14 +202,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
     auto refresh_rb = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int r = 32 * (wr * 3 + i) + l31;
-            rb[i] = (r < Geo::ROWS ? r : 0) * CV_ROWB;
+            const int k = 32 * (wr * 3 + i) + l31 - 12;
+            rb[i] = (k < 0 ? 0 : k) * CV_ROWB;
             asm volatile("" : "+v"(rb[i]));
         }
     };
     // hi half of (cell of tile i, channels n0 .. n0+3); the lo half is LO_OFF bytes behind
     auto cell_ptr = [&](int i, int q, bool &live) -> unsigned char * {
-        live = 32 * (wr * 3 + i) + l31 < Geo::ROWS;
+        live = 32 * (wr * 3 + i) + l31 >= 12;
         const int n0 = ct * 32 + 8 * q + 4 * khalf;
         return smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1);
     };
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
             bf16x8 af[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + ((rowb[i] >> 3) + shift * 32) : Geo::ZERO_OFF;
+                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + (natb[i] + shift * 32) : Geo::ZERO_OFF;
                 af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
             }
 #pragma unroll
@@ -274,6 +284,32 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
               [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
               [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst)                                                \
             : "memory", "scc")
+#define XS_SLABV(ASMSTR, NAB, NKEY)   /* the same operands + the wave-uniform skip mask; clobbers VCC */                 \
+        asm volatile(ASMSTR                                                                                      \
+            : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]),                                             \
+              [f0ah0] "+v"(f0.ah[0]), [f0ah1] "+v"(f0.ah[1]), [f0ah2] "+v"(f0.ah[2]),                             \
+              [f0al0] "+v"(f0.al[0]), [f0al1] "+v"(f0.al[1]), [f0al2] "+v"(f0.al[2]),                             \
+              [f0wh] "+v"(f0.wh), [f0wl] "+v"(f0.wl),                                                            \
+              [f1ah0] "=&v"(f1.ah[0]), [f1ah1] "=&v"(f1.ah[1]), [f1ah2] "=&v"(f1.ah[2]),                          \
+              [f1al0] "=&v"(f1.al[0]), [f1al1] "=&v"(f1.al[1]), [f1al2] "=&v"(f1.al[2]),                          \
+              [f1wh] "=&v"(f1.wh), [f1wl] "=&v"(f1.wl),                                                          \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [keep] "=&s"(keep)                                     \
+            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),          \
+              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),   \
+              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [vb] "v"(vb), [vbn] "v"(vbn), [voff0] "v"(voff0),          \
+              [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst), [skipm] "s"(skipm)                            \
+            : "memory", "vcc", "scc")
+#define XS_ARGS()                                                                                               \
+            const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << Geo::SLAB_SHIFT); \
+            const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                 \
+            const unsigned char *sbase = reinterpret_cast<const unsigned char *>(wpk) + (size_t)gn * Geo::SLAB_BYTES; \
+            const int ldst = Geo::W_OFF + ((((unsigned)g + 3u) & 3u) << Geo::SLAB_SHIFT) + (wave_u << 10);
+#define XS_RUNV(BF, HF, NAB, NKEY)                                                                              \
+        {                                                                                                       \
+            XS_ARGS()                                                                                           \
+            if constexpr (F16) { XS_SLABV(HF, NAB, NKEY); } else { XS_SLABV(BF, NAB, NKEY); }                   \
+            ++g;                                                                                                \
+        }
 #define XS_RUN(BF, HF, NAB, NKEY)                                                                               \
         {                                                                                                       \
             const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT), vbn = vb0 + ((((unsigned)g + 1u) & 3u) << Geo::SLAB_SHIFT); \
@@ -285,6 +321,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
         }
 
     int g = 0;
+    int skipm;   // cell group 0 (waves 0..3): its first row tile skips the dy = -1 taps.  Defined by scalar asm so that it IS a scalar register
+    asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cselect_b32 %0, 1, 0" : "=s"(skipm) : "s"(wave_u) : "scc");
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
         f32x16 acc[3];
@@ -310,8 +348,21 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
             const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT);
             XS_LOADSET(0, 0, 8192, f0, ab, key, vb);   // waited for by the first k-step itself
         }
+        // taps 0..2 (dy = -1): one wave of every SIMD (cell group 0) branches around the MFMAs of its all-rank-0 row tile
+        // (1/6 of the SIMD's MFMAs in these twelve slabs, 5.6 % of a layer's; adding 0 * w is exact: outputs bit-identical)
+        int tap = 0;
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
+        for (; tap < 3; ++tap) {
+            XS_RUNV(XS_SKIP0_ASM_Q0, XSF_SKIP0_ASM_Q0, ab, key)
+            XS_RUNV(XS_SKIP0_ASM_Q1, XSF_SKIP0_ASM_Q1, ab, key)
+            XS_RUNV(XS_SKIP0_ASM_Q2, XSF_SKIP0_ASM_Q2, ab, key)
+            tap_addr(tap + 1, nab, nkey);
+            XS_RUNV(XS_SKIP0_ASM_Q3, XSF_SKIP0_ASM_Q3, nab, nkey)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
+        }
+#pragma unroll 1
+        for (; tap < 9; ++tap) {
             XS_RUN(XS_SLAB_ASM_Q0, XSF_SLAB_ASM_Q0, ab, key)      // four 16 KB slabs (hi + lo of 32 input channels) per tap
             XS_RUN(XS_SLAB_ASM_Q1, XSF_SLAB_ASM_Q1, ab, key)
             XS_RUN(XS_SLAB_ASM_Q2, XSF_SLAB_ASM_Q2, ab, key)
@@ -337,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
         float4 *go = reinterpret_cast<float4 *>(out + (size_t)pos0 * 90 * 128);
         for (int idx = tid; idx < nrows * 16; idx += Geo::THREADS) {
             const int r = idx >> 4, c = idx & 15;
-            const int a = lds_addr(r * CV_ROWB, c);
+            const int a = lds_addr(lds_row_of(r) * CV_ROWB, c);
             const uint4 h = *reinterpret_cast<const uint4 *>(smem + a), l = *reinterpret_cast<const uint4 *>(smem + a + Geo::LO_OFF);
             const f32x2 h0 = unpack_pair<F16>(h.x), h1 = unpack_pair<F16>(h.y), h2 = unpack_pair<F16>(h.z), h3 = unpack_pair<F16>(h.w);
             const f32x2 l0 = unpack_pair<F16>(l.x), l1 = unpack_pair<F16>(l.y), l2 = unpack_pair<F16>(l.z), l3 = unpack_pair<F16>(l.w);
@@ -350,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
         // one thread per board cell, all three head channels; chunks in a fixed order, eight products left to right: a
         // position's outputs do not depend on the row / workgroup it lands on
         for (int r = tid; r < nrows; r += Geo::THREADS) {
-            const int rowoff = r * CV_ROWB, key = (rowoff >> 8) & 15;
+            const int rowoff = lds_row_of(r) * CV_ROWB, key = (rowoff >> 8) & 15;
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
 #pragma unroll 4
             for (int c = 0; c < 16; ++c) {
@@ -374,6 +425,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
     }
 }
 #undef XS_SLAB
+#undef XS_SLABV
+#undef XS_ARGS
+#undef XS_RUNV
 #undef XS_RUN
 #undef XS_LOADSET
 

@@ -136,10 +136,10 @@ def main():
     # row for all of that tile's inputs and does not issue its two MFMAs per k-step: a scalar branch around each of them on VCC
     # (set from the wave-uniform 32-bit %[skipm] at the top of the body; nothing in the body writes VCC).  One body for all waves —
     # a wave-dependent choice between two bodies makes hipcc copy / spill the accumulators where the paths join.
-    def branchy(L):
+    def branchy(L, accs=("%[c00],", "%[c01],")):
         out = ["s_cmp_lg_u32 %[skipm], 0", "s_cselect_b64 vcc, -1, 0"]
         for l in L:
-            if l.startswith("v_mfma") and ("%[c00]" in l or "%[c01]" in l):
+            if l.startswith("v_mfma") and any(l.split()[1] == a for a in accs):
                 out += ["s_cbranch_vccnz 1f", l, "1:"]
             else:
                 out.append(l)
@@ -152,6 +152,11 @@ def main():
     txt += "// k_trunk_split_c128: 8 waves / 2 positions, operands split into hi + lo halves, 9 MFMAs per k-step, bf16 and fp16\n"
     for hs in range(4):
         txt += emit("XS_SLAB_ASM_Q%d" % hs, slabX(hs, XS_LO_OFF)) + "\n" + emit("XSF_SLAB_ASM_Q%d" % hs, f16(slabX(hs, XS_LO_OFF))) + "\n"
+    # dy = -1 taps of the strict kernel: the first row tile of cell group 0 (12 padding rows + the 20 rank-0 cells of both positions)
+    txt += "// slab bodies whose first-row-tile MFMAs (3 of 9 per k-step) sit behind a scalar branch (dy = -1 taps)\n"
+    for hs in range(4):
+        b = branchy(slabX(hs, XS_LO_OFF), ("%[c0],",))
+        txt += emit("XS_SKIP0_ASM_Q%d" % hs, b) + "\n" + emit("XSF_SKIP0_ASM_Q%d" % hs, f16(b)) + "\n"
     open(os.path.join(csrc, "cz_trunk_split_asm.inc"), "w").write(txt)
     print("wrote cz_tower_slab_asm.inc (%d instructions per slab), cz_trunk_split_asm.inc (%d)" % (len(slab8(0)), len(slabX(0, XS_LO_OFF))))
 
