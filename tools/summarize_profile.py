@@ -56,6 +56,27 @@ def main():
            "(roofline.achieved %.1f TFLOP/s, frac %.3f; whole-job %.0f sims/s under the profiler)."
            % (ksub, float(dom["AverageNs"]) / 1e3, bline["roofline"]["us_per_launch"], bline["roofline"]["achieved"],
               bline["roofline"]["frac"], bline["value"])]
+    # the same average over the launches of the TIMED region only: the stats line above mixes in the ageing phase (800 untimed
+    # lock-steps on young trees, other data and kernel mix: the trunk runs 3-4 % slower there) and the small net-error probes
+    try:
+        tr = []
+        with open(find(os.path.join(src, "stats"), "*kernel_trace.csv")) as f:
+            for r in csv.DictReader(f):
+                if ksub in r["Kernel_Name"]:
+                    tr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
+        tr.sort()
+        full = max(t[2] for t in tr)
+        big = [t for t in tr if t[2] == full]
+        # bench order: ageing, warm-up, K timed steps, then the MFMA probe / net-error probes: the timed launches are the last K
+        # full-size ones that are followed by no other full-size launch of the loop
+        K = int(bline["steps"])
+        timed = big[-K:]
+        md += ["", "Over the %d launches of the timed region alone (kernel trace, the last %d full-batch launches): **%.1f us** "
+               "(min %.1f, max %.1f); the %d ageing / warm-up launches before them average %.1f us."
+               % (len(timed), K, sum(t[1] for t in timed) / len(timed) / 1e3, min(t[1] for t in timed) / 1e3, max(t[1] for t in timed) / 1e3,
+                  len(big) - len(timed), sum(t[1] for t in big[:-K]) / max(1, len(big) - K) / 1e3)]
+    except Exception as e:   # older outputs without the trace
+        md += ["", "(no per-launch trace: %s)" % e]
     fetch, nf = pmc_mean(find(os.path.join(src, "pmc_f"), "*counter_collection.csv"), "FETCH_SIZE", ksub)
     write, nw = pmc_mean(find(os.path.join(src, "pmc_w"), "*counter_collection.csv"), "WRITE_SIZE", ksub)
     cfg = bline["config"]
