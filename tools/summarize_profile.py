@@ -56,8 +56,10 @@ def main():
            "(roofline.achieved %.1f TFLOP/s, frac %.3f; whole-job %.0f sims/s under the profiler)."
            % (ksub, float(dom["AverageNs"]) / 1e3, bline["roofline"]["us_per_launch"], bline["roofline"]["achieved"],
               bline["roofline"]["frac"], bline["value"])]
-    # the same average over the launches of the TIMED region only: the stats line above mixes in the ageing phase (800 untimed
-    # lock-steps on young trees, other data and kernel mix: the trunk runs 3-4 % slower there) and the small net-error probes
+    # the same average over the launches of the TIMED region only: the stats line above mixes in the 800 untimed ageing steps and
+    # the small net-error probes.  (Under the profiler the timed region is 100 steps = 0.23 s right after a host-side pause:
+    # the power governor lets the first ~0.3 s after an idle gap run 3-4 % faster than the settled rate the ageing launches
+    # show — which is why bench.py's headline is its 2000-step leg, not a short one.)
     try:
         tr = []
         with open(find(os.path.join(src, "stats"), "*kernel_trace.csv")) as f:
@@ -72,7 +74,7 @@ def main():
         K = int(bline["steps"])
         timed = big[-K:]
         md += ["", "Over the %d launches of the timed region alone (kernel trace, the last %d full-batch launches): **%.1f us** "
-               "(min %.1f, max %.1f); the %d ageing / warm-up launches before them average %.1f us."
+               "(min %.1f, max %.1f); the %d ageing / warm-up launches before them average %.1f us (the settled rate of this box: the 100 timed steps under the profiler are 0.23 s right after a host-side pause, which the power governor lets run faster)."
                % (len(timed), K, sum(t[1] for t in timed) / len(timed) / 1e3, min(t[1] for t in timed) / 1e3, max(t[1] for t in timed) / 1e3,
                   len(big) - len(timed), sum(t[1] for t in big[:-K]) / max(1, len(big) - K) / 1e3)]
     except Exception as e:   # older outputs without the trace
