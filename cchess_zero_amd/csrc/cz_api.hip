@@ -129,7 +129,7 @@ int cz_create(int device, int max_games, int max_nodes_per_tree, cz_ctx **out) {
         CZ_HIP(hipMemcpy(sd, ht.srcdst, sizeof(ht.srcdst), hipMemcpyHostToDevice));
         CZ_HIP(hipMemcpy(zb, ht.zob, sizeof(ht.zob), hipMemcpyHostToDevice));
         c->tab.lut = lut; c->tab.unflip = unf; c->tab.srcdst = sd; c->tab.zob = zb;
-        CzmTables mt;   // the mask-only generator's per-square tables, derived from the label LUT
+        CzmTables mt = {};   // the mask-only generator's per-square tables, derived from the label LUT
         czm_build_tables(ht.lut, &mt);
         CzmTables *dmt = nullptr;
         if (hipMalloc(&dmt, sizeof(CzmTables)) != hipSuccess) { cz_set_error("cz_create: hipMalloc(mask tables) failed"); delete c; return CZ_ENOMEM; }

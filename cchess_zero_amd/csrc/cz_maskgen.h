@@ -35,7 +35,9 @@ struct CzmTables {
     uint16_t base[90];     // label of the first same-rank destination of source square sq = y * 9 + x
     uint8_t knon[90];      // bit j: knight jump j (vocabulary order: (dx,dy) = (-2,-1) (-1,-2) (-2,1) (1,-2) (2,-1) (-1,2) (2,1) (1,2)) lands on the board
     uint8_t ab[2][90 * 4]; // [0] advisor (step 1), [1] bishop (step 2): literal of (square, direction d: (dy,dx) = (-s,-s) (-s,+s) (+s,+s) (+s,-s)) - 2038, or 0xFF
+    uint8_t pad_[2];       // 992 bytes = 62 x 16: a wave copies the tables to LDS with ONE 16-byte load per lane
 };
+static_assert(sizeof(CzmTables) == 992, "CzmTables is copied as 62 uint4");
 
 // host: the tables from the 90 x 90 label LUT (label2i, main.py:217; cz_tables.hip)
 inline void czm_build_tables(const int16_t *lut, CzmTables *t) {
@@ -96,25 +98,25 @@ CZM_FN CzmSet czm_without(const CzmSet &s, int q) {   // q < 0: unchanged
     return CzmSet{s.lo & ~((q >= 0 && q < 64) ? 1ull << (q & 63) : 0ull), s.hi & ~(q >= 64 ? 1u << (q & 31) : 0u)};
 }
 
-// "byte != 0" of the 90 board bytes XOR rep (rep = 0: occupancy; rep = a piece code in every byte: "byte != code")
-CZM_FN CzmSet czm_nonzero_set(const uint32_t (&w)[23], uint32_t rep) {
+// Bit plane b of the 90 piece codes (codes are <= 15) as a square set: bit b of every byte, eight squares per pair of dwords by
+// two v_dot4_u32_u8 with the byte weights (1, 2, 4, 8) / (16, 32, 64, 128) — the bytes are 0 or 1 << b, so the packed byte
+// comes out shifted left by b.  Four planes cost 4 x 72 instructions; every "byte == code" set of the position is then a few
+// boolean operations on three registers (round 4: nine SWAR compares of all 23 dwords were a third of the kernel's VALU work).
+template <int b>
+CZM_FN CzmSet czm_plane(const uint32_t (&w)[23]) {
+    const uint32_t m = 0x01010101u << b;
     uint32_t out[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < 23; k += 2) {
-        const uint32_t f0 = (((w[k] ^ rep) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;      // bytes are <= 15: no carry between bytes
-        uint32_t byte = czm_dot4(f0, 0x08040201u, 0u);
-        if (k + 1 < 23) {
-            const uint32_t f1 = (((w[k + 1] ^ rep) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
-            byte = czm_dot4(f1, 0x80402010u, byte);
-        }
-        out[k >> 3] |= byte << ((k >> 1 & 3) * 8);   // squares 4k .. 4k+7 -> bits (4k & 31) ..
+        uint32_t byte = czm_dot4(w[k] & m, 0x08040201u, 0u);
+        if (k + 1 < 23) byte = czm_dot4(w[k + 1] & m, 0x80402010u, byte);
+        out[k >> 3] |= (byte >> b) << ((k >> 1 & 3) * 8);   // squares 4k .. 4k+7 -> bits (4k & 31) ..
     }
-    return CzmSet{(uint64_t)out[0] | ((uint64_t)out[1] << 32), out[2]};
+    return CzmSet{(uint64_t)out[0] | ((uint64_t)out[1] << 32), out[2] & 0x03FFFFFFu};
 }
-CZM_FN CzmSet czm_equal_set(const uint32_t (&w)[23], uint32_t code) {
-    const CzmSet n = czm_nonzero_set(w, code * 0x01010101u);
-    return CzmSet{~n.lo, ~n.hi & 0x03FFFFFFu};
-}
+CZM_FN CzmSet czm_and(const CzmSet &a, const CzmSet &b) { return CzmSet{a.lo & b.lo, a.hi & b.hi}; }
+CZM_FN CzmSet czm_xor(const CzmSet &a, const CzmSet &b) { return CzmSet{a.lo ^ b.lo, a.hi ^ b.hi}; }
+CZM_FN CzmSet czm_not(const CzmSet &a) { return CzmSet{~a.lo, ~a.hi & 0x03FFFFFFu}; }
 
 // 10 bits of file x (bit r = square 9 r + x) of a set
 CZM_FN uint32_t czm_file(const CzmSet &s, int x) {   // 0 <= x <= 8
@@ -175,12 +177,21 @@ struct CzmYes { static constexpr bool value = true; };
 // on square 0 and its field is zeroed before it is OR-ed in.
 template <typename OrWord>
 CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, OrWord or_word) {
-    const uint32_t own0 = side ? 7u : 0u;   // own piece code = kind + own0 (kind: K 1, A 2, R 3, B 4, N 5, P 6, C 7)
-    const CzmSet occ = czm_nonzero_set(w, 0u);
-    const CzmSet K = czm_equal_set(w, 1u + own0), A = czm_equal_set(w, 2u + own0), R = czm_equal_set(w, 3u + own0);
-    const CzmSet B = czm_equal_set(w, 4u + own0), N = czm_equal_set(w, 5u + own0), C = czm_equal_set(w, 7u + own0);
-    CzmSet P = czm_equal_set(w, 6u + own0);
-    const CzmSet EK = czm_equal_set(w, side ? 1u : 8u);           // the enemy king
+    // own piece code = kind + (side ? 7 : 0), kind: K 1, A 2, R 3, B 4, N 5, P 6, C 7.  Bit planes p0..p3 of the codes; red's
+    // own pieces have bit 3 clear and the kind in the low three bits, black's have bit 3 set and kind - 1 there: a bit-sliced
+    // "+ 1 where black moves" (XOR / AND with the lane's side mask, no selects) makes the low bits the kind for both sides.
+    const CzmSet p0 = czm_plane<0>(w), p1 = czm_plane<1>(w), p2 = czm_plane<2>(w), p3 = czm_plane<3>(w);
+    const CzmSet occ = {p0.lo | p1.lo | p2.lo | p3.lo, p0.hi | p1.hi | p2.hi | p3.hi};
+    const CzmSet sm = {side ? ~0ull : 0ull, side ? 0x03FFFFFFu : 0u};
+    const CzmSet n0 = czm_xor(p0, sm), c0 = czm_and(p0, sm), n1 = czm_xor(p1, c0), c1 = czm_and(p1, c0), n2 = czm_xor(p2, c1);
+    const CzmSet mine = czm_and(czm_xor(p3, czm_not(sm)), occ);    // bit 3 == side, not empty
+    const CzmSet i0 = czm_not(n0), i1 = czm_not(n1), i2 = czm_not(n2);
+    const CzmSet K = czm_and(mine, czm_and(n0, czm_and(i1, i2))), A = czm_and(mine, czm_and(i0, czm_and(n1, i2)));
+    const CzmSet R = czm_and(mine, czm_and(n0, czm_and(n1, i2))), B = czm_and(mine, czm_and(i0, czm_and(i1, n2)));
+    const CzmSet N = czm_and(mine, czm_and(n0, czm_and(i1, n2))), C = czm_and(mine, czm_and(n0, czm_and(n1, n2)));
+    CzmSet P = czm_and(mine, czm_and(i0, czm_and(n1, n2)));
+    // the enemy king: code 8 (bit 3 only) when red moves, code 1 (bit 0 only) when black moves
+    const CzmSet EK = czm_and(czm_and(czm_xor(p3, sm), czm_xor(p0, czm_not(sm))), czm_and(czm_not(p1), czm_not(p2)));
     const CzmSet own = {K.lo | A.lo | R.lo | B.lo | N.lo | P.lo | C.lo, K.hi | A.hi | R.hi | B.hi | N.hi | P.hi | C.hi};
     const CzmSet enemy = {occ.lo & ~own.lo, occ.hi & ~own.hi};
     bool err = __builtin_popcountll(own.lo) + __builtin_popcount(own.hi) > 16;

@@ -85,31 +85,52 @@ __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict
                                                      const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ count,
                                                      uint32_t *__restrict__ mask) {
     __shared__ __attribute__((aligned(16))) uint32_t rows[64 * CZ_MASK_WORDS + 4];   // first the 64 boards, then the 64 mask rows
-    __shared__ CzmTables T;
+    __shared__ __attribute__((aligned(16))) CzmTables T;
     const int lane = threadIdx.x;
-    for (int i = lane; i < (int)(sizeof(CzmTables) / 2); i += 64) reinterpret_cast<uint16_t *>(&T)[i] = reinterpret_cast<const uint16_t *>(gtab)[i];
+    if (lane < (int)(sizeof(CzmTables) / 16)) reinterpret_cast<uint4 *>(&T)[lane] = reinterpret_cast<const uint4 *>(gtab)[lane];   // hipMalloc'ed: 256-byte aligned
     const int ngroups = (G + 63) >> 6;
     const bool al16 = (reinterpret_cast<uintptr_t>(boards) & 15u) == 0, mal16 = mask && (reinterpret_cast<uintptr_t>(mask) & 15u) == 0;
+    // Persistent waves (the launch has at most a chip's worth): a wave walks its groups with a stride and requests the NEXT
+    // group's 5 760 board bytes (six 16-byte loads per lane) and side bytes into registers before it computes the current one,
+    // so that the only HBM round trip a wave waits for is its first (SQ counters of the one-group-per-wave kernel: half of a
+    // wave's life in s_waitcnt).  The prefetch needs 16-byte aligned boards (g0 * 90 is a multiple of 16); other addresses
+    // take the byte path without it.
+    uint4 pre[6];
+    int presd = 0;
+    auto prefetch = [&](int grp) {
+        const int g0 = grp * 64, np = min(64, G - g0), nbytes = np * CZ_NSQ;
+        const uint8_t *src = boards + (size_t)g0 * CZ_NSQ;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = lane + 64 * k;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i * 16 + 16 <= nbytes) v = reinterpret_cast<const uint4 *>(src)[i];   // the ragged piece of a batch's last group: below
+            pre[k] = v;
+        }
+        presd = (lane < np && side[g0 + lane]) ? 1 : 0;
+    };
+    if (al16 && (int)blockIdx.x < ngroups) prefetch(blockIdx.x);
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int g0 = grp * 64, np = min(64, G - g0), p = g0 + lane;
         const bool live = lane < np;
         __syncthreads();   // the previous group's rows have left (and the tables are in place)
-        {   // stage np * 90 board bytes
+        int sd;
+        if (al16) {   // the prefetched bytes -> LDS
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (lane + 64 * k < 64 * CZ_NSQ / 16) reinterpret_cast<uint4 *>(rows)[lane + 64 * k] = pre[k];
+            if (np < 64) {   // the last group of a batch: its ragged 16-byte piece byte by byte, never past the batch (wave-uniform branch)
+                const int nbytes = np * CZ_NSQ, full = nbytes & ~15;
+                if (lane < nbytes - full) reinterpret_cast<uint8_t *>(rows)[full + lane] = boards[(size_t)g0 * CZ_NSQ + full + lane];
+            }
+            sd = presd;
+        } else {
             const uint8_t *src = boards + (size_t)g0 * CZ_NSQ;
             uint8_t *dst = reinterpret_cast<uint8_t *>(rows);
             const int nbytes = np * CZ_NSQ;
-            if (al16) {   // g0 * 90 is a multiple of 16 (g0 is a multiple of 64)
-                for (int i = lane; i * 16 < nbytes; i += 64) {
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (i * 16 + 16 <= nbytes) v = reinterpret_cast<const uint4 *>(src)[i];
-                    else { uint8_t t[16] = {0}; for (int k = 0; i * 16 + k < nbytes; ++k) t[k] = src[i * 16 + k]; v = *reinterpret_cast<uint4 *>(t); }
-                    reinterpret_cast<uint4 *>(dst)[i] = v;
-                }
-            } else {
-                for (int i = lane; i < nbytes; i += 64) dst[i] = src[i];
-            }
+            for (int i = lane; i < nbytes; i += 64) dst[i] = src[i];
+            sd = (live && side[p]) ? 1 : 0;
         }
-        const int sd = (live && side[p]) ? 1 : 0;
         __syncthreads();
         uint32_t w[23];
         {   // the lane's 90 bytes start at byte 90 * lane: 4-aligned for even lanes, 2 (mod 4) for odd ones
@@ -126,6 +147,7 @@ __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict
             }
         }
         __syncthreads();   // every lane holds its board: the bytes become mask rows
+        if (al16 && grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);   // in flight while this group is computed
         for (int i = lane; i < 64 * CZ_MASK_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(rows)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         uint32_t *row = rows + lane * CZ_MASK_WORDS;
@@ -134,7 +156,11 @@ __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict
         __syncthreads();
         if (mask) {
             uint32_t *dstm = mask + (size_t)g0 * CZ_MASK_WORDS;
-            if (mal16) {
+            if (mal16 && np == 64) {   // 1 056 16-byte stores, statically counted (the waits on the prefetch stay counted too)
+#pragma unroll
+                for (int k = 0; k < 17; ++k)
+                    if (k < 16 || lane < 32) reinterpret_cast<uint4 *>(dstm)[lane + 64 * k] = reinterpret_cast<const uint4 *>(rows)[lane + 64 * k];
+            } else if (mal16) {
                 for (int i = lane; i < np * CZ_MASK_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(dstm)[i] = reinterpret_cast<const uint4 *>(rows)[i];
                 for (int i = (np * CZ_MASK_WORDS / 4) * 4 + lane; i < np * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
             } else {
@@ -206,7 +232,8 @@ int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, ui
     if (G == 0) return CZ_OK;
     if (moves && (reinterpret_cast<uintptr_t>(moves) & 15u)) { cz_set_error("cz_movegen: moves must be 16-byte aligned"); return CZ_EINVAL; }
     if (!moves) {   // the set, not the list: one lane per position (k_movegen_mask); mask may be NULL too (counts only)
-        hipLaunchKernelGGL(k_movegen_mask, dim3(grid_for((G + 63) / 64)), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, count, mask);
+        const int ngroups = (G + 63) / 64, chip = 256 * 8;   // 8 waves per CU fit (17.9 KB LDS, 187 VGPRs each): one resident generation, each walks its groups
+        hipLaunchKernelGGL(k_movegen_mask, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, count, mask);
     } else {        // the reference's ordered list (+ the mask derived from it): four positions per wave
         hipLaunchKernelGGL(k_movegen, dim3(grid_for((G + 3) / 4)), dim3(64), 0, c->stream, c->tab, boards, side, G, moves, count, mask);
     }
