@@ -123,31 +123,41 @@ CZM_FN uint32_t czm_file(const CzmSet &s, int x) {   // 0 <= x <= 8
     // t = s >> x, then the bits at the constant positions 9 r: 0 .. 63 in the low 64 bits, 72 and 81 = bits 8 and 17 above
     const uint64_t t = x ? (s.lo >> x) | ((uint64_t)s.hi << (64 - x)) : s.lo;
     const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32), t2 = s.hi >> x;
-    return (t0 & 1u) | ((t0 >> 9 & 1u) << 1) | ((t0 >> 18 & 1u) << 2) | ((t0 >> 27 & 1u) << 3) | ((t1 >> 4 & 1u) << 4) | ((t1 >> 13 & 1u) << 5) |
-           ((t1 >> 22 & 1u) << 6) | ((t1 >> 31) << 7) | ((t2 >> 8 & 1u) << 8) | ((t2 >> 17 & 1u) << 9);
+    // bits 0, 9, 18, 27 of t0 are 1, 2, 4, 8 in its four bytes and bits 4, 13, 22, 31 of t1 are 16 .. 128 in its bytes: the sum of
+    // the eight bytes (v_dot4 with weights 1) IS file bits 0..7; squares 72 and 81 are bits 8 and 17 of t2
+    const uint32_t lo8 = czm_dot4(t1 & 0x80402010u, 0x01010101u, czm_dot4(t0 & 0x08040201u, 0x01010101u, 0u));
+    return lo8 | (t2 & 0x100u) | ((t2 >> 8) & 0x200u);
 }
 
 // destinations of a rook / cannon at index p on a line of `len` squares: o = occupancy bits, e = enemy bits (main.py:757-833,
 // 947-1062): the empty run in both directions; rook: + the first occupied square if it is an enemy; cannon: + the SECOND
 // occupied square (behind exactly one screen) if it is an enemy
+// o - 2r: subtracting twice the slider's bit borrows through the empty squares above it up to the first occupied one, so
+// (o - 2r) ^ o is the run above r INCLUDING its first blocker (everything above when there is none); the run below comes from the
+// same formula on the bit-reversed line (v_bfrev_b32).  Rook: runs & (empty | enemy).  Cannon: the empty part of the runs, plus —
+// from the screen s = run & o — the second run (o - 2s) ^ o, whose occupied end is the target when it is an enemy.
+CZM_FN uint32_t czm_rev32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__clang__)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
 template <bool cannon>
 CZM_FN uint32_t czm_line_dests(uint32_t o, uint32_t e, int p, int len) {
+    const uint32_t r = 1u << p, rr = 0x80000000u >> p, orv = czm_rev32(o);
+    const uint32_t up = (o - (r << 1)) ^ o, dn = (orv - (rr << 1)) ^ orv;          // dn in the reversed domain
     uint32_t d;
-    {   // towards index 0
-        const uint32_t m = o & czm_low(p);
-        const int hit = m ? 31 - __builtin_clz(m) : -1;
-        d = czm_low(p) & ~czm_low(hit + 1);
-        const uint32_t m2 = hit >= 0 ? m & czm_low(hit) : 0u;
-        const int tgt = cannon ? (m2 ? 31 - __builtin_clz(m2) : -1) : hit;
-        if (tgt >= 0) d |= e & (1u << tgt);
-    }
-    {   // towards index len-1
-        const uint32_t m = (o >> p) >> 1;                      // squares above p
-        const int hit = m ? p + 1 + __builtin_ctz(m) : len;
-        d |= czm_low(hit) & ~czm_low(p + 1);
-        const uint32_t m2 = hit < len ? (m >> (hit - p - 1)) >> 1 : 0u;   // squares above hit
-        const int tgt = cannon ? (m2 ? hit + 1 + __builtin_ctz(m2) : len) : hit;
-        if (tgt < len) d |= e & (1u << tgt);
+    if (cannon) {
+        const uint32_t s = up & o, sr = dn & orv;                                  // the screens (one bit or none)
+        const uint32_t up2 = (o - (s << 1)) ^ o, dn2 = (orv - (sr << 1)) ^ orv;     // no screen: o ^ o = 0
+        d = ((up | czm_rev32(dn)) & ~o) | ((up2 | czm_rev32(dn2)) & o & e);
+    } else {
+        d = (up | czm_rev32(dn)) & (~o | e);
     }
     return d & czm_low(len);
 }

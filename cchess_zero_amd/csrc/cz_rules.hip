@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_movegen(CzTables tab, const uint8_t *__r
 // boards (5 760 contiguous bytes) into LDS with coalesced 16-byte loads, every lane pulls its own 90 bytes out as 23 dwords
 // (an odd lane's board starts on a 2-byte boundary: funnel shift), then the same LDS bytes become the wave's 64 mask rows
 // (66 words each, the ABI's layout, so the rows leave as one contiguous 16 896-byte block of 16-byte stores); a lane ORs its
-// <= 16 label fields into its own row with ds_or_b32.  17.6 KB of LDS per wave: 9 waves per CU.
+// <= 16 label fields into its own row with ds_or_b32.  17.9 KB of LDS per wave: 8 waves per CU, persistent (see below).
 // Algorithmic bytes: 90 + 1 in, 264 + 2 out per position (SURVEY 8(d) counts 312 with the board packed to 48 bytes).
 __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
                                                      const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ count,
