@@ -111,6 +111,31 @@ def test_rules_vs_oracle_large_corpus(rules):
     assert checked > 5000
 
 
+def test_mask_kernel_persistent_waves_walk_many_groups(rules, rules_golden):
+    """k_movegen_mask launches at most 2048 waves; a batch of more than 131 072 positions makes every wave walk several groups
+    with the next group's boards prefetched into registers.  300 011 positions (4 688 groups, a ragged last one of 11) cut from
+    the golden corpus at a stride that is no multiple of 64, so a position's lane and group change with its index: masks and
+    counts equal the list kernel's for every position, and the goldens' counts where a position is a golden one."""
+    b0 = np.asarray(rules_golden["boards"], np.uint8)
+    s0 = np.asarray(rules_golden["side"], np.uint8)
+    n0 = len(b0)
+    G = 300011
+    idx = (np.arange(G, dtype=np.int64) * 37) % n0
+    boards = torch.from_numpy(b0[idx]).cuda()
+    side = torch.from_numpy(s0[idx]).cuda()
+    _, mcount, mmask = rules.movegen(boards, side, want_moves=False)
+    ref_c = torch.empty(G, dtype=mcount.dtype, device="cuda")
+    ref_m = torch.empty_like(mmask)
+    for a in range(0, G, 65536):   # the list kernel in slices it handles with one group of four positions per wave
+        _, c, m = rules.movegen(boards[a:a + 65536], side[a:a + 65536])
+        ref_c[a:a + 65536] = c
+        ref_m[a:a + 65536] = m
+    assert torch.equal(mcount, ref_c)
+    assert torch.equal(mmask, ref_m)
+    gc = np.asarray(rules_golden["counts"]).astype(np.int64)[idx]
+    assert np.array_equal(_u16(mcount).astype(np.int64), gc)
+
+
 def test_rules_edge_sizes(rules):
     """Empty batch and a single position."""
     from oracle import oracle as O
