@@ -310,9 +310,9 @@ int cz_search_set_xcache(cz_ctx *c, int log2_entries) {
     }
     if (!c->t.ec_key) { cz_set_error("cz_search_set_xcache: switch the per-tree evaluation cache on first (cz_search_set_eval_cache(ctx, 1))"); return CZ_EINVAL; }
     const size_t n = (size_t)1 << log2_entries;
-    // per entry: key 8, value 4, count 4, position 48, labels 256, (src, dst) 256, priors 512 = 1088 bytes; + 4 counters
+    // per entry: key 8, value 4, count 4, position 48, labels 256, (src, dst) 256, priors 512 = 1088 bytes; + 16 bytes of counters per tree
     if (!c->xc_block) {
-        const size_t bytes = n * 1088 + 64;
+        const size_t bytes = n * 1088 + 64 + (size_t)c->max_games * 16;
         if (hipMalloc(&c->xc_block, bytes) != hipSuccess) { c->xc_block = nullptr; cz_set_error("cz_search_set_xcache: hipMalloc(%zu B) failed", bytes); return CZ_ENOMEM; }
         c->xc_log2_entries = log2_entries;
         c->t.xc_base = (char *)c->xc_block;
@@ -320,14 +320,18 @@ int cz_search_set_xcache(cz_ctx *c, int log2_entries) {
     }
     // an empty table (new weights => remembered evaluations are stale): only the keys and the counters need clearing
     CZ_HIP(hipMemsetAsync(c->xc_block, 0, n * 8 + 64, c->stream));
+    CZ_HIP(hipMemsetAsync(czx_tree_stats(c->t), 0, (size_t)c->max_games * 16, c->stream));
     return CZ_OK;
 }
 int cz_search_xcache_stats(cz_ctx *c, unsigned long long *stats4) {
     CZ_REQUIRE(c && stats4, "cz_search_xcache_stats: null argument");
     stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0;
     if (!c->t.xc_base) return CZ_OK;
-    CZ_HIP(hipMemcpyAsync(stats4, czx_stats(c->t), 32, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> per((size_t)c->max_games * 4);
+    CZ_HIP(hipMemcpyAsync(per.data(), czx_tree_stats(c->t), per.size() * 4, hipMemcpyDeviceToHost, c->stream));
     CZ_HIP(hipStreamSynchronize(c->stream));
+    for (size_t g = 0; g < (size_t)c->max_games; ++g)
+        for (int k = 0; k < 4; ++k) stats4[k] += per[g * 4 + k];
     return CZ_OK;
 }
 int cz_search_debug_eval_cache_key_bits(cz_ctx *c, int bits) {

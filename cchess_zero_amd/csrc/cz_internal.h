@@ -65,7 +65,9 @@ struct CzSelfplay {
 
 #define CZ_EC_BUCKETS 128
 #define CZ_EC_ENTRIES (CZ_EC_BUCKETS * 64)
+#ifndef CZ_EC_BUDGET
 #define CZ_EC_BUDGET 4   // evaluation-cache hits a tree may complete inside one select launch (its own budget, beside terminal_extra)
+#endif
 
 // Per-tree scalars: ONE 64-byte record per tree instead of sixteen arrays.  A wave owns a tree, so what it reads at entry
 // (root, counters, status) and leaves behind (the pending leaf) is one cache line, and the kernels hold one base pointer
@@ -173,7 +175,10 @@ struct cz_ctx {
 // cross-tree cache: the arrays inside CzTrees::xc_base
 __host__ __device__ __forceinline__ size_t czx_n(const CzTrees &t) { return ((size_t)t.xc_mask + 1) * 64; }
 __host__ __device__ __forceinline__ unsigned long long *czx_key(const CzTrees &t) { return reinterpret_cast<unsigned long long *>(t.xc_base); }
-__host__ __device__ __forceinline__ unsigned long long *czx_stats(const CzTrees &t) { return reinterpret_cast<unsigned long long *>(t.xc_base + czx_n(t) * 8); }   // hits, lookups, entries written, claims lost
+// statistics: PER TREE, [max_games][4] uint32 (hits, lookups, entries written, claims lost) behind the entries, updated by the
+// tree's own wave without atomics — four counters of the context bumped with same-address atomics by every probe of every tree
+// cost the select launch 95 us of its 167 (profiles/r04x_xcache_stats_atomics.txt); cz_search_xcache_stats sums them
+__host__ __device__ __forceinline__ uint32_t *czx_tree_stats(const CzTrees &t) { return reinterpret_cast<uint32_t *>(t.xc_base + czx_n(t) * 1088 + 64); }
 __host__ __device__ __forceinline__ float *czx_val(const CzTrees &t) { return reinterpret_cast<float *>(t.xc_base + czx_n(t) * 8 + 64); }
 __host__ __device__ __forceinline__ uint32_t *czx_cnt(const CzTrees &t) { return reinterpret_cast<uint32_t *>(t.xc_base + czx_n(t) * 12 + 64); }
 __host__ __device__ __forceinline__ uint32_t *czx_board(const CzTrees &t) { return reinterpret_cast<uint32_t *>(t.xc_base + czx_n(t) * 16 + 64); }

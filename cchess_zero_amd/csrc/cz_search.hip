@@ -311,7 +311,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                             if (__ballot(lb != pk) == 0ull) { xe = (long long)(xb0 + hl); break; }
                         }
                         if (xe >= 0) { pend = czx_val(t)[xe]; hit = true; }
-                        if (lane == 0) { atomicAdd(&czx_stats(t)[1], 1ull); if (xe >= 0) atomicAdd(&czx_stats(t)[0], 1ull); }
+                        if (lane == 0) { uint32_t *xs = czx_tree_stats(t) + (size_t)g * 4; xs[1] += 1u; if (xe >= 0) xs[0] += 1u; }
                     }
                     if (!hit) break;
                     // the lender: an expanded node of this tree (its children's arrays) or a cross-tree entry's arrays
@@ -661,9 +661,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
                                 czx_sd(t)[e * CZD_MAXMOVES + i] = v.sd[cb2 + i];
                             }
                         }
-                        if (lane == 0) { czx_val(t)[e] = val; czx_cnt(t)[e] = (uint32_t)n2; atomicAdd(&czx_stats(t)[2], 1ull); }
+                        if (lane == 0) { czx_val(t)[e] = val; czx_cnt(t)[e] = (uint32_t)n2; czx_tree_stats(t)[(size_t)g * 4 + 2] += 1u; }
                     } else if (lane == 0) {
-                        atomicAdd(&czx_stats(t)[3], 1ull);
+                        czx_tree_stats(t)[(size_t)g * 4 + 3] += 1u;
                     }
                 }
             }
