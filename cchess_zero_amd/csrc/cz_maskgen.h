@@ -98,6 +98,18 @@ CZM_FN CzmSet czm_without(const CzmSet &s, int q) {   // q < 0: unchanged
     return CzmSet{s.lo & ~((q >= 0 && q < 64) ? 1ull << (q & 63) : 0ull), s.hi & ~(q >= 64 ? 1u << (q & 31) : 0u)};
 }
 
+// 64 consecutive squares of a set starting at square `start` (-24 <= start <= 89): bit i = square start + i, zero off the set.
+// A piece's neighbourhood (knight: 39 squares around it, pawn / king: 19, advisor / bishop: 41) then sits at CONSTANT bit
+// positions: one funnel shift per set instead of a bounds-clamped bit test per candidate square.
+CZM_FN uint64_t czm_window(const CzmSet &s, int start) {
+    const uint64_t up = (uint64_t)s.hi;
+    const uint64_t a = s.lo << ((-start) & 63);                                              // start <= 0
+    const uint64_t b = (s.lo >> (start & 63)) | ((up << 1) << ((63 - start) & 63));           // 0 < start < 64 (two shifts: never by 64)
+    const uint64_t c = up >> ((start - 64) & 63);                                            // start >= 64
+    return start <= 0 ? a : (start < 64 ? b : c);
+}
+CZM_FN uint32_t czm_wbit(uint64_t w, int pos) { return (uint32_t)(w >> pos) & 1u; }          // pos is a compile-time constant
+
 // Bit plane b of the 90 piece codes (codes are <= 15) as a square set: bit b of every byte, eight squares per pair of dwords by
 // two v_dot4_u32_u8 with the byte weights (1, 2, 4, 8) / (16, 32, 64, 128) — the bytes are 0 or 1 << b, so the packed byte
 // comes out shifted left by b.  Four planes cost 4 x 72 instructions; every "byte == code" set of the position is then a few
@@ -172,9 +184,10 @@ CZM_FN uint32_t czm_ortho_field(uint32_t rank_d, uint32_t file_d, int x, int y) 
 // or_field(bit, field): OR `field` (<= 25 bits) into the position's mask at bit offset `bit`
 template <typename OrWord>
 CZM_FN void czm_or_field(OrWord &or_word, int bit, uint32_t field) {
-    const int wi = bit >> 5, off = bit & 31;
-    or_word(wi, field << off);
-    or_word(wi + 1, off ? field >> (32 - off) : 0u);     // wi + 1 <= 64 for every base + 25-bit field
+    const int wi = bit >> 5;
+    const uint64_t v = (uint64_t)field << (bit & 31);    // one 64-bit shift; wi + 1 <= 64 for every base + 25-bit field
+    or_word(wi, (uint32_t)v);
+    or_word(wi + 1, (uint32_t)(v >> 32));
 }
 
 struct CzmNo { static constexpr bool value = false; };
@@ -206,7 +219,6 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, O
     const CzmSet enemy = {occ.lo & ~own.lo, occ.hi & ~own.hi};
     bool err = __builtin_popcountll(own.lo) + __builtin_popcount(own.hi) > 16;
     int count = 0;
-    auto notown = [&](int q) { return !czm_tst(own, q < 0 ? 0 : (q > 89 ? 89 : q)); };   // validate_move, main.py:727: empty or enemy
     auto put = [&](int bit, uint32_t f, bool ok) {
         f = ok ? f : 0u;
         count += __builtin_popcount(f);
@@ -233,17 +245,16 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, O
     auto knight = [&](int sq, bool ok) {
         const int q0 = ok ? sq : 0;
         const uint32_t on = T.knon[q0];
+        // the window starts at q0 - 19: jump j = (dx, dy) lands on bit 19 + 9 dy + dx, its leg is bit 18 / 20 (dx = -+2) or 10 / 28
+        // (dy = -+2); squares off the board read as free and empty — `on` has no bit for a jump that leaves the board
+        const uint64_t fr = ~czm_window(own, q0 - 19), em = ~czm_window(occ, q0 - 19);
+        const uint32_t tg = czm_wbit(fr, 8) | (czm_wbit(fr, 0) << 1) | (czm_wbit(fr, 26) << 2) | (czm_wbit(fr, 2) << 3) |
+                            (czm_wbit(fr, 12) << 4) | (czm_wbit(fr, 36) << 5) | (czm_wbit(fr, 30) << 6) | (czm_wbit(fr, 38) << 7);
+        const uint32_t lg = (czm_wbit(em, 18) * 0x05u) | (czm_wbit(em, 10) * 0x0Au) | (czm_wbit(em, 20) * 0x50u) | (czm_wbit(em, 28) * 0xA0u);
+        const uint32_t good = tg & lg & on;
         uint32_t f = 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int dx = (j == 0 || j == 2) ? -2 : (j == 1 || j == 5) ? -1 : (j == 3 || j == 7) ? 1 : 2;
-            const int dy = (j == 1 || j == 3) ? -2 : (j == 0 || j == 4) ? -1 : (j == 2 || j == 6) ? 1 : 2;
-            const int leg = (dx == 2 || dx == -2) ? q0 + dx / 2 : q0 + (dy / 2) * 9;
-            const bool onb = ((on >> j) & 1u) != 0u;
-            const int q = onb ? q0 + dy * 9 + dx : q0, lg = onb ? leg : q0;   // keep the bit tests on the board
-            const bool good = (int)onb & (int)notown(q) & (int)!czm_tst(occ, lg);
-            f |= (uint32_t)good << __builtin_popcount(on & czm_low(j));
-        }
+        for (int j = 0; j < 8; ++j) f |= ((good >> j) & 1u) << __builtin_popcount(on & czm_low(j));   // the vocabulary lists on-board jumps only
         put(T.base[q0] + 17, f, ok);
     };
     {
@@ -260,10 +271,11 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, O
         const int ylo = side ? 7 : 0, yhi = side ? 9 : 2;
         const bool iny = (y >= ylo) & (y <= yhi), inx = (x >= 3) & (x <= 5);
         uint32_t rd = 0u, fd = 0u;
-        rd |= (uint32_t)(iny & (x >= 4) & (x <= 6) & notown(q - 1)) << ((x + 8) % 9);      // x - 1, kept in range
-        rd |= (uint32_t)(iny & (x >= 2) & (x <= 4) & notown(q + 1)) << ((x + 1) % 9);
-        fd |= (uint32_t)(inx & (y - 1 >= ylo) & (y - 1 <= yhi) & notown(q - 9)) << ((y + 9) % 10);   // y - 1
-        fd |= (uint32_t)(inx & (y + 1 >= ylo) & (y + 1 <= yhi) & notown(q + 9)) << ((y + 1) % 10);
+        const uint64_t fr = ~czm_window(own, q - 9);   // bit 0: q - 9, 8: q - 1, 10: q + 1, 18: q + 9
+        rd |= ((uint32_t)(iny & (x >= 4) & (x <= 6)) & czm_wbit(fr, 8)) << ((x + 8) % 9);      // x - 1, kept in range
+        rd |= ((uint32_t)(iny & (x >= 2) & (x <= 4)) & czm_wbit(fr, 10)) << ((x + 1) % 9);
+        fd |= ((uint32_t)(inx & (y - 1 >= ylo) & (y - 1 <= yhi)) & czm_wbit(fr, 0)) << ((y + 9) % 10);   // y - 1
+        fd |= ((uint32_t)(inx & (y + 1 >= ylo) & (y + 1 <= yhi)) & czm_wbit(fr, 18)) << ((y + 1) % 10);
         const int e = eq >= 0 ? eq : 0;
         const int ey = e / 9, ex = e - ey * 9;
         const int lo = y < ey ? y : ey, hi = y < ey ? ey : y;
@@ -281,32 +293,37 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, O
         const int y = q / 9, x = q - y * 9;
         const int fy = side ? y - 1 : y + 1;
         const bool fin = (fy >= 0) & (fy <= 9), river = side ? y < 5 : y > 4;
-        const uint32_t fd = (uint32_t)(fin & notown(fy * 9 + x)) << (fin ? fy : 0);
-        uint32_t rd = (uint32_t)(river & (x <= 7) & notown(q + 1)) << ((x + 1) % 9);
-        rd |= (uint32_t)(river & (x >= 1) & notown(q - 1)) << ((x + 8) % 9);
-        put(T.base[q], czm_ortho_field(rd, fd, x, y), ok);
+        const uint64_t fr = ~czm_window(own, q - 9);   // bit 0: q - 9, 8: q - 1, 10: q + 1, 18: q + 9
+        // the field directly (czm_ortho_field's squeeze of the own file / rank done by hand): the left neighbour is field bit
+        // x - 1, the right one bit x; the forward square is file bit y for red (y + 1 with rank y squeezed out), y - 1 for black
+        const uint32_t lr = ((uint32_t)(river & (x >= 1)) & czm_wbit(fr, 8)) | (((uint32_t)(river & (x <= 7)) & czm_wbit(fr, 10)) << 1);
+        const uint32_t fwd = (uint32_t)fin & (side ? czm_wbit(fr, 0) : czm_wbit(fr, 18));
+        const int gp = side ? (y > 0 ? y - 1 : 0) : y;
+        put(T.base[q], ((lr << x) >> 1) | (fwd << (gp + 8)), ok);
     }
     // ---- advisors (main.py:889-918: one diagonal step inside the palace) and bishops (main.py:857-888: two diagonal steps,
     //      the eye empty, own half of the board); their labels are the 48 literals at the end of the vocabulary
+    uint64_t lits = 0ull;   // the 48 advisor / bishop literals of the position
     auto literal = [&](int sq, bool ok, int kind) {
         const int q0 = ok ? sq : 0;
         const int st = kind ? 2 : 1;
         const int ylo = kind ? (side ? 5 : 0) : (side ? 7 : 0), yhi = kind ? (side ? 9 : 4) : (side ? 9 : 2);
         const int xlo = kind ? 0 : 3, xhi = kind ? 8 : 5;
         const int y = q0 / 9, x = q0 - y * 9;
+        // the window starts at q0 - 20: the target of direction d is bit 20 + st (9 sy + sx), a bishop's eye bit 20 + 9 sy + sx
+        const uint64_t fr = ~czm_window(own, q0 - 20), em = ~czm_window(occ, q0 - 20);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int sy = (d < 2 ? -1 : 1), sx = (d == 0 || d == 3) ? -1 : 1;
             const int ty = y + sy * st, tx = x + sx * st;
             const bool in = (ty >= ylo) & (ty <= yhi) & (tx >= xlo) & (tx <= xhi);
-            const int q = in ? ty * 9 + tx : q0, eye = in ? (y + sy) * 9 + x + sx : q0;
-            const bool good = (int)ok & (int)in & (int)notown(q) & (int)(kind == 0 || !czm_tst(occ, eye));
+            const uint32_t free_t = kind ? czm_wbit(fr, 20 + 2 * (9 * sy + sx)) : czm_wbit(fr, 20 + 9 * sy + sx);
+            const uint32_t open_eye = kind ? czm_wbit(em, 20 + 9 * sy + sx) : 1u;
+            const bool good = ((uint32_t)((int)ok & (int)in) & free_t & open_eye) != 0u;
             const uint32_t l = T.ab[kind][q0 * 4 + d];
             err |= good & (l == 0xFFu);
-            const int bit = CZM_NLIT_BASE + (int)(l & 63u);
             const bool set = good & (l != 0xFFu);
-            or_word(bit >> 5, set ? 1u << (bit & 31) : 0u);
-            count += set ? 1 : 0;
+            lits |= set ? 1ull << (l & 63u) : 0ull;      // literal l = label 2038 + l: OR-ed into the row once, below
         }
     };
     {
@@ -315,6 +332,12 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, O
         for (int it = 0; it < 2; ++it) literal(it ? a1 : a0, it ? a1 > a0 : a0 >= 0, 0);
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) literal(it ? b1 : b0, it ? b1 > b0 : b0 >= 0, 1);
+    }
+    {   // labels 2038 .. 2085 = bits 22 .. of word 63, then words 64 and 65
+        count += __builtin_popcountll(lits);
+        or_word(CZM_NLIT_BASE >> 5, (uint32_t)(lits << (CZM_NLIT_BASE & 31)));
+        or_word((CZM_NLIT_BASE >> 5) + 1, (uint32_t)(lits >> (32 - (CZM_NLIT_BASE & 31))));
+        or_word((CZM_NLIT_BASE >> 5) + 2, (uint32_t)(lits >> (64 - (CZM_NLIT_BASE & 31))));
     }
     return err ? -1 : count;
 }
