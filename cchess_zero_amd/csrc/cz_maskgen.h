@@ -181,9 +181,13 @@ CZM_FN uint32_t czm_ortho_field(uint32_t rank_d, uint32_t file_d, int x, int y) 
     return f | (g << 8);
 }
 
-// or_field(bit, field): OR `field` (<= 25 bits) into the position's mask at bit offset `bit`
+// czm_position hands its results to emit(bit, field): OR `field` (<= 20 bits) into the position's 2086-bit mask at bit offset
+// `bit` — EXACTLY 15 calls per position, in the same order on every lane (4 sliders, 2 knights, the king, 5 pawns, 3 words of
+// advisor / bishop literals; a missing piece emits an empty field), so a caller may store the pairs instead of applying them.
+#define CZM_EMITS 15
+// czm_or_field: what an emit does to a row of 66 words when it is applied at once
 template <typename OrWord>
-CZM_FN void czm_or_field(OrWord &or_word, int bit, uint32_t field) {
+CZM_FN void czm_or_field(OrWord &&or_word, int bit, uint32_t field) {
     const int wi = bit >> 5;
     const uint64_t v = (uint64_t)field << (bit & 31);    // one 64-bit shift; wi + 1 <= 64 for every base + 25-bit field
     or_word(wi, (uint32_t)v);
@@ -198,8 +202,8 @@ struct CzmYes { static constexpr bool value = true; };
 // position is not a Xiangqi position the vocabulary can express (more than 16 pieces of a colour; an advisor / bishop move
 // without a label).  Branch-free apart from the loops: every lane runs every kind's code; a missing piece (square -1) computes
 // on square 0 and its field is zeroed before it is OR-ed in.
-template <typename OrWord>
-CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, OrWord or_word) {
+template <typename Emit>
+CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, Emit emit) {
     // own piece code = kind + (side ? 7 : 0), kind: K 1, A 2, R 3, B 4, N 5, P 6, C 7.  Bit planes p0..p3 of the codes; red's
     // own pieces have bit 3 clear and the kind in the low three bits, black's have bit 3 set and kind - 1 there: a bit-sliced
     // "+ 1 where black moves" (XOR / AND with the lane's side mask, no selects) makes the low bits the kind for both sides.
@@ -222,7 +226,7 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, O
     auto put = [&](int bit, uint32_t f, bool ok) {
         f = ok ? f : 0u;
         count += __builtin_popcount(f);
-        czm_or_field(or_word, bit, f);
+        emit(bit, f);
     };
 
     // ---- rooks, then cannons (main.py:757-833, 947-1062): at most two of each — the kind's lowest and highest square
@@ -333,11 +337,11 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, O
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) literal(it ? b1 : b0, it ? b1 > b0 : b0 >= 0, 1);
     }
-    {   // labels 2038 .. 2085 = bits 22 .. of word 63, then words 64 and 65
+    {   // labels 2038 .. 2085, sixteen per emit
         count += __builtin_popcountll(lits);
-        or_word(CZM_NLIT_BASE >> 5, (uint32_t)(lits << (CZM_NLIT_BASE & 31)));
-        or_word((CZM_NLIT_BASE >> 5) + 1, (uint32_t)(lits >> (32 - (CZM_NLIT_BASE & 31))));
-        or_word((CZM_NLIT_BASE >> 5) + 2, (uint32_t)(lits >> (64 - (CZM_NLIT_BASE & 31))));
+        emit(CZM_NLIT_BASE, (uint32_t)lits & 0xFFFFu);
+        emit(CZM_NLIT_BASE + 16, (uint32_t)(lits >> 16) & 0xFFFFu);
+        emit(CZM_NLIT_BASE + 32, (uint32_t)(lits >> 32) & 0xFFFFu);
     }
     return err ? -1 : count;
 }

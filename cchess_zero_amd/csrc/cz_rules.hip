@@ -77,14 +77,25 @@ __global__ __launch_bounds__(64) void k_movegen(CzTables tab, const uint8_t *__r
 // K1m: the legal-move MASK (and count) without the ordered list — cz_movegen(moves = NULL).  One lane = one position; the rules
 // are cz_maskgen.h's czm_position (register bit sets, no list, no LUT, no divergence on the piece kind).  A wave stages its 64
 // boards (5 760 contiguous bytes) into LDS with coalesced 16-byte loads, every lane pulls its own 90 bytes out as 23 dwords
-// (an odd lane's board starts on a 2-byte boundary: funnel shift), then the same LDS bytes become the wave's 64 mask rows
-// (66 words each, the ABI's layout, so the rows leave as one contiguous 16 896-byte block of 16-byte stores); a lane ORs its
-// <= 16 label fields into its own row with ds_or_b32.  17.9 KB of LDS per wave: 8 waves per CU, persistent (see below).
+// (an odd lane's board starts on a 2-byte boundary: funnel shift).  czm_position's 15 (bit, field) results per position go to
+// a record buffer in LDS (15 x 64 dwords, where the boards were) and from there to registers, transposed: lane l holds record
+// l + 64 k of each half-wave.  The mask rows are then built and written HALF A WAVE AT A TIME: 32 rows of 66 words in the ABI's
+// layout (8 448 bytes, the same LDS again), all 64 lanes applying the half's 480 records with ds_or_b32, then one contiguous
+// block of 16-byte stores.  9.4 KB of LDS per wave instead of 17.9 for 64 rows: 12 waves per CU (3 per SIMD, the VGPR limit)
+// instead of 8 — LDS is handed out in 1 280-byte granules on this chip: a first version with the records in their own 3.8 KB
+// (13.3 KB per wave) got 11 waves per CU, not 12, and ran its 3 072 waves in two rounds.
 // Algorithmic bytes: 90 + 1 in, 264 + 2 out per position (SURVEY 8(d) counts 312 with the board packed to 48 bytes).
+#define CZK_HALF_WORDS (32 * CZ_MASK_WORDS)
+// The workgroup IS one wave: its LDS instructions execute in issue order, so between the phases below the LDS counter has to
+// drain and the compiler must not move memory operations across — but nothing needs the VECTOR-memory counter at zero: a
+// __syncthreads() here waits for the prefetch just issued and for the previous rows' global stores (two exposed HBM round trips
+// per group).
+#define CZK_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
                                                      const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ count,
                                                      uint32_t *__restrict__ mask) {
-    __shared__ __attribute__((aligned(16))) uint32_t rows[64 * CZ_MASK_WORDS + 4];   // first the 64 boards, then the 64 mask rows
+    __shared__ __attribute__((aligned(16))) uint32_t rows[CZK_HALF_WORDS];   // the 64 boards (1 440 words), then the records, then 32 mask rows at a time
+    uint32_t *const rec = rows;                                               // [emit][lane]: field << 12 | bit (960 words) while czm_position runs
     __shared__ __attribute__((aligned(16))) CzmTables T;
     const int lane = threadIdx.x;
     if (lane < (int)(sizeof(CzmTables) / 16)) reinterpret_cast<uint4 *>(&T)[lane] = reinterpret_cast<const uint4 *>(gtab)[lane];   // hipMalloc'ed: 256-byte aligned
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int g0 = grp * 64, np = min(64, G - g0), p = g0 + lane;
         const bool live = lane < np;
-        __syncthreads();   // the previous group's rows have left (and the tables are in place)
+        CZK_WAVE_SYNC();   // the previous group's rows have left (and the tables are in place)
         int sd;
         if (al16) {   // the prefetched bytes -> LDS
 #pragma unroll
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict
             for (int i = lane; i < nbytes; i += 64) dst[i] = src[i];
             sd = (live && side[p]) ? 1 : 0;
         }
-        __syncthreads();
+        CZK_WAVE_SYNC();
         uint32_t w[23];
         {   // the lane's 90 bytes start at byte 90 * lane: 4-aligned for even lanes, 2 (mod 4) for odd ones
             const int b0 = (CZ_NSQ * lane) >> 2, sh = (lane & 1) * 16;
@@ -146,25 +157,51 @@ __global__ __launch_bounds__(64) void k_movegen_mask(const CzmTables *__restrict
                 for (int k = 0; k < 23; ++k) w[k] = 0u;
             }
         }
-        __syncthreads();   // every lane holds its board: the bytes become mask rows
         if (al16 && grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);   // in flight while this group is computed
-        for (int i = lane; i < 64 * CZ_MASK_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(rows)[i] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        uint32_t *row = rows + lane * CZ_MASK_WORDS;
-        const int n = czm_position(w, sd, T, [row](int wi, uint32_t v) { atomicOr(&row[wi], v); });   // ds_or_b32, nothing returned
+        int ne = 0;   // wave-uniform: every lane emits the same CZM_EMITS records in the same order
+        const int n = czm_position(w, sd, T, [&](int bit, uint32_t f) { rec[ne * 64 + lane] = (f << 12) | (uint32_t)bit; ++ne; });
         if (live) count[p] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
-        __syncthreads();
-        if (mask) {
-            uint32_t *dstm = mask + (size_t)g0 * CZ_MASK_WORDS;
-            if (mal16 && np == 64) {   // 1 056 16-byte stores, statically counted (the waits on the prefetch stay counted too)
+        if (!mask) continue;
+        // the records leave LDS for registers (the rows take their place): lane l applies record r = l + 64 k of each half,
+        // i.e. emit r >> 5 of the half's position r & 31
+        CZK_WAVE_SYNC();
+        uint32_t rv[2][8];
 #pragma unroll
-                for (int k = 0; k < 17; ++k)
-                    if (k < 16 || lane < 32) reinterpret_cast<uint4 *>(dstm)[lane + 64 * k] = reinterpret_cast<const uint4 *>(rows)[lane + 64 * k];
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = lane + 64 * k;
+                rv[h][k] = r < 32 * CZM_EMITS ? rec[(r >> 5) * 64 + h * 32 + (r & 31)] : 0u;
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h * 32 >= np) break;   // a ragged last group may have no second half (wave-uniform)
+            CZK_WAVE_SYNC();   // the records are in registers (h = 0) / the first half's rows have left
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (lane + 64 * k < CZK_HALF_WORDS / 4) reinterpret_cast<uint4 *>(rows)[lane + 64 * k] = make_uint4(0, 0, 0, 0);
+            CZK_WAVE_SYNC();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {   // the half's 32 x 15 = 480 records, one per lane and step
+                const int r = lane + 64 * k;
+                if (r < 32 * CZM_EMITS) {
+                    const uint32_t v = rv[h][k];
+                    uint32_t *row = rows + (r & 31) * CZ_MASK_WORDS;
+                    czm_or_field([row](int wi, uint32_t x) { atomicOr(&row[wi], x); }, (int)(v & 0xFFFu), v >> 12);   // ds_or_b32, nothing returned
+                }
+            }
+            CZK_WAVE_SYNC();
+            const int nph = min(32, np - h * 32);
+            uint32_t *dstm = mask + (size_t)(g0 + h * 32) * CZ_MASK_WORDS;
+            if (mal16 && nph == 32) {   // 528 16-byte stores, statically counted (the waits on the prefetch stay counted too)
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (lane + 64 * k < CZK_HALF_WORDS / 4) reinterpret_cast<uint4 *>(dstm)[lane + 64 * k] = reinterpret_cast<const uint4 *>(rows)[lane + 64 * k];
             } else if (mal16) {
-                for (int i = lane; i < np * CZ_MASK_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(dstm)[i] = reinterpret_cast<const uint4 *>(rows)[i];
-                for (int i = (np * CZ_MASK_WORDS / 4) * 4 + lane; i < np * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
+                for (int i = lane; i < nph * CZ_MASK_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(dstm)[i] = reinterpret_cast<const uint4 *>(rows)[i];
+                for (int i = (nph * CZ_MASK_WORDS / 4) * 4 + lane; i < nph * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
             } else {
-                for (int i = lane; i < np * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
+                for (int i = lane; i < nph * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
             }
         }
     }
@@ -232,7 +269,7 @@ int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, ui
     if (G == 0) return CZ_OK;
     if (moves && (reinterpret_cast<uintptr_t>(moves) & 15u)) { cz_set_error("cz_movegen: moves must be 16-byte aligned"); return CZ_EINVAL; }
     if (!moves) {   // the set, not the list: one lane per position (k_movegen_mask); mask may be NULL too (counts only)
-        const int ngroups = (G + 63) / 64, chip = 256 * 8;   // 8 waves per CU fit (17.9 KB LDS, 187 VGPRs each): one resident generation, each walks its groups
+        const int ngroups = (G + 63) / 64, chip = 256 * 12;   // 12 waves per CU fit (13.3 KB LDS, <= 168 VGPRs each): one resident generation, each walks its groups
         hipLaunchKernelGGL(k_movegen_mask, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, count, mask);
     } else {        // the reference's ordered list (+ the mask derived from it): four positions per wave
         hipLaunchKernelGGL(k_movegen, dim3(grid_for((G + 3) / 4)), dim3(64), 0, c->stream, c->tab, boards, side, G, moves, count, mask);

@@ -16,6 +16,11 @@ extern "C" void czm_host_masks(const CzmTables *t, const uint8_t *boards, const 
         memcpy(w, buf, 92);
         uint32_t *row = mask + (size_t)i * 66;
         memset(row, 0, 66 * 4);
-        count[i] = czm_position(w, side[i] ? 1 : 0, *t, [row](int wi, uint32_t v) { if (wi < 66) row[wi] |= v; });
+        int emits = 0;
+        count[i] = czm_position(w, side[i] ? 1 : 0, *t, [row, &emits](int bit, uint32_t field) {
+            ++emits;
+            czm_or_field([row](int wi, uint32_t v) { if (wi < 66) row[wi] |= v; }, bit, field);
+        });
+        if (emits != CZM_EMITS) count[i] = -1000 - emits;   // the kernel's record buffer relies on this number
     }
 }
