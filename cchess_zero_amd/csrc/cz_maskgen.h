@@ -5,18 +5,21 @@
 // order, the staging rows, the prefix sums, the (src, dst) -> label LUT round trips or one LDS atomic per move of
 // k_movegen (249 VALU + 156 SALU instructions per position: issue-bound at 7 % of the kernel's HBM roofline).  Here ONE LANE
 // owns a position and everything is bit arithmetic in its registers:
-//   * the 90 board bytes arrive as 23 dwords; SWAR byte tests + v_dot4_u32_u8 (weights 1, 2, 4, ... 128) turn "byte != 0" /
-//     "byte == code" into 90-bit square sets: occupancy and one set per piece kind of the side to move (+ the enemy king);
+//   * the 90 board bytes arrive as 23 dwords; the four BIT PLANES of the piece codes (v_and + v_dot4_u32_u8 with the byte
+//     weights 1, 2, 4, ... 128) are 90-bit square sets, and occupancy, one set per piece kind of the side to move and the enemy
+//     king are boolean functions of the planes;
 //   * pieces are visited KIND BY KIND (all lanes run the rook code together, then the knight code, ...: no divergence on the
 //     piece type); a piece's squares come off its kind's set by find-first-set;
 //   * the move vocabulary (main.py:30-65) lists, per source square, 8 same-rank destinations, 9 same-file destinations and
 //     the on-board knight jumps CONTIGUOUSLY, so the legal destinations of a rook / cannon / king / pawn are one <= 17-bit
-//     field and a knight's one <= 8-bit field at a per-square base: a ray is find-first-set on the 9 / 10 line bits and two
-//     masks, never a loop over squares; advisor / bishop moves are the 48 literals at the end (a [square][direction] table);
-//   * a field is OR-ed into the lane's private 66-word row with two ds_or_b32; count = popcount of the fields.
+//     field and a knight's one <= 8-bit field at a per-square base: a ray is (o - 2r) ^ o on the 9 / 10 line bits (and on their
+//     bit reversal), never a loop over squares; a leaper's candidate squares are constant bit positions of a 64-square window
+//     around it; advisor / bishop moves are the 48 literals at the end (a [square][direction] table);
+//   * the results leave as exactly 15 (bit offset, field) pairs per position through the caller's emit(); count = popcount of
+//     the fields.  k_movegen_mask (cz_rules.hip) stores them and builds the 66-word rows half a wave at a time.
 // The rules are those of czd_gen_piece (cz_device.h), restated as set operations; tests/test_hip_rules.py holds both kernels
-// to the same 4 381 golden positions and the 20 k oracle-checked corpus, and tools/maskgen_host_check.cpp runs this very
-// function on the CPU against the golden lists (the function is host-compilable on purpose).
+// to the same 4 381 golden positions and the 20 k oracle-checked corpus, and tests/maskgen_host.cpp (tests/test_maskgen_cpu.py) runs this very
+// function on the CPU against the golden lists and the C oracle (the function is host-compilable on purpose).
 #pragma once
 #include <stdint.h>
 
