@@ -186,6 +186,35 @@ def test_movegen_ragged_sizes_and_alignment_raw_abi(rules, rules_golden, G):
                     assert (mk == 0x55).all()
 
 
+@pytest.mark.parametrize("G", [1, 63, 64, 65, 4097, 150001])
+def test_hash_ragged_sizes_and_alignment_raw_abi(rules, rules_golden, G):
+    """cz_hash (one lane = one position, 64 positions staged per wave, persistent waves from 147 456 positions on) through the
+    raw C-ABI on batch sizes around its group size, with the boards at a 16-byte-aligned, an even and an ODD byte address:
+    every key against the C oracle's (sampled for the large batch); keys beyond the batch are not touched."""
+    from oracle import oracle as O
+    from cchess_zero_amd._lib import check, lib
+    from cchess_zero_amd.engine import _ptr
+    g = rules_golden
+    idx = (np.arange(G) * 37) % len(g["boards"])
+    hb, hs = g["boards"][idx], g["side"][idx]
+    sample = np.arange(G) if G <= 4097 else np.unique(np.concatenate([np.arange(200), np.arange(G - 200, G), (np.arange(800) * 187) % G]))
+    exp = np.array([O.zhash(hb[i], int(hs[i])) for i in sample], dtype=np.uint64)
+    for off in (0, 2, 1):
+        raw = torch.zeros(G * 90 + 16, dtype=torch.uint8, device="cuda")
+        raw[off:off + G * 90] = torch.from_numpy(hb.reshape(-1)).cuda()
+        boards = raw[off:off + G * 90]
+        side = torch.from_numpy(hs).cuda()
+        out = torch.full((G + 2,), 0x1234, dtype=torch.int64, device="cuda")
+        check(lib().cz_hash(rules.ctx.h, _ptr(boards), _ptr(side), G, _ptr(out)), "cz_hash")
+        h = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(h[sample], exp)
+        assert (h[G:] == 0x1234).all()
+        if off == 0:
+            first = h[:G].copy()
+        else:
+            assert np.array_equal(h[:G], first)   # every key, not only the sampled ones, is independent of the address
+
+
 def test_movegen_mask_kernel_flags_unexpressible_positions(rules):
     """Both kernels answer 0xFFFF for a position the move vocabulary cannot express: 17 pieces of the side to move; an advisor
     off the palace's diagonal points whose step (e2 -> d1) has no label."""
