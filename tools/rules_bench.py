@@ -44,3 +44,9 @@ t = timed(lambda: rules.encode_planes(boards, side, torch.bfloat16, 16))
 print("K3 planes (bf16 x16)    : %.3f ms = %.2f G positions/s, %.1f GB/s (2971 B/position)" % (t * 1e3, N / t / 1e9, N * 2971 / t / 1e9))
 t = timed(lambda: rules.hash(boards, side))
 print("Zobrist hash            : %.3f ms = %.2f G positions/s" % (t * 1e3, N / t / 1e9))
+mv, cnt, _ = rules.movegen(boards, side, want_mask=False)
+labels = mv[:, 0].contiguous()          # the first legal move of every position (0xFFFF where there is none: left alone)
+b2, s2 = boards.clone(), side.clone()
+h2 = rules.hash(b2, s2)
+t = timed(lambda: rules.apply_move(b2, s2, labels, h2))
+print("K2 apply_move (+ hash, capture, terminal flags): %.3f ms = %.2f G positions/s" % (t * 1e3, N / t / 1e9))
