@@ -616,9 +616,11 @@ def main():
                         "after the timed regions (cz_probe_mfma_peak): what the MFMA pipes sustain on this box under its power governor" % ("f16" if code == 2 else "bf16"))
         return out_
 
-    # MFMA flops ISSUED per algorithmic flop of the tower layers: 96 GEMM rows per 90 cells (padding rows), minus the dy = -1
-    # MFMAs of the all-rank-0 row tiles that the kernels branch around (1/18 of a layer's), times the products per operand pair
-    ISSUE_PER_ALG = (96.0 / 90.0) * (17.0 / 18.0)
+    # MFMA flops ISSUED per algorithmic flop of the tower layers: 96 GEMM rows per 90 cells (padding rows), minus the MFMAs of the
+    # row tiles that are off the board for a tap, which the kernels branch around: 15 of 108 tile-taps in k_tower8_c128 (rank-0,
+    # file-0, file-9 and rank-8 tiles), 1 of 18 in k_trunk_split_c128 (its rank-0 tile), times the products per operand pair
+    ISSUE_FAST = (96.0 / 90.0) * (93.0 / 108.0)
+    ISSUE_SPLIT = 3.0 * (96.0 / 90.0) * (17.0 / 18.0)
 
     def trunk_roofline(conv_ms_, n_launches, issued_factor, kernel_name, clock_, telemetry_):
         nl_ = 2 * args.blocks
@@ -652,7 +654,7 @@ def main():
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
         if net.backend == "hip":
             kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv layers, LDS-resident activations, %s MFMA, fp32 acc)" % (2 * args.blocks + 3, args.dtype))
-            roof = trunk_roofline(conv_ms, len(conv_ev), (3.0 if split else 1.0) * ISSUE_PER_ALG, kname, clock, telemetry)
+            roof = trunk_roofline(conv_ms, len(conv_ev), ISSUE_SPLIT if split else ISSUE_FAST, kname, clock, telemetry)
             roof["net_forward_ms_per_step"] = net_ms
             roof["net_forward_tflops"] = flops / (net_ms * 1e-3) / 1e12
             roof["mfma_peak_measured"] = mfma_peak_measured
@@ -738,7 +740,7 @@ def main():
                       "note": "third barrier-bracketed timed region: the same trees and loop with the strict engine swapped in (same weights)"}
         if s_ev:
             s_ms = float(np.mean([a.elapsed_time(b) for a, b in s_ev]))
-            strict_out["roofline"] = trunk_roofline(s_ms, len(s_ev), 3.0 * ISSUE_PER_ALG, "k_trunk_split_c128", None, None)
+            strict_out["roofline"] = trunk_roofline(s_ms, len(s_ev), ISSUE_SPLIT, "k_trunk_split_c128", None, None)
     # headline: the LONG leg (steady_state) when it ran — the K contract steps (the driver's K = 20 is 47 ms) read a percent
     # or two off it and are kept as contract_steps
     contract = {"steps": args.steps, "seconds": dt, "value": total_sims / dt, "ms_per_step": dt / args.steps * 1e3,

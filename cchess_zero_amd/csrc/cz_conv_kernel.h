@@ -363,17 +363,34 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     const int npos = (B - pos0) < P ? (B - pos0) : P;
     const int nrows = npos * 90;
     const int nslabs = nlayers * Geo::SLABS_PER_LAYER;
-    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
     const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + (unsigned)Geo::THREADS * 16u;   // second DMA piece of a slab
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // Cell order inside the workgroup (round 4): LDS row k of (position p, cell y * 10 + x) is 40 y + 10 p + x — the cells of one
-    // board rank of all four positions are adjacent — and the 384 GEMM rows are the 24 padding rows FIRST, then k = 0 .. 359.  The
-    // first two row tiles then hold nothing but padding and rank-0 cells, whose three dy = -1 taps are off the board: those
-    // MFMAs multiply the zero row and are not issued (T8_SKIP below).  dx = +-1 is still the neighbouring row, dy = +-1 is 40
-    // rows away, a tile's 32 lanes still read 32 consecutive rows (the chunk swizzle stays conflict-free).
-    auto lds_row_of = [](int natural) {   // natural = p * 90 + y * 10 + x
-        const int p = natural / 90, c = natural - p * 90, y = c / 10, x = c - y * 10;
-        return 40 * y + 10 * p + x;
+    // Cell order inside the workgroup (round 4): the 384 GEMM rows are the 24 padding rows, then the 360 cells of the
+    // four positions TILED BY BORDER CLASS, so that whole 32-row tiles are off the board for a tap and their MFMAs are not issued:
+    //   LDS rows   0 ..  39  rank 0 (y = 0): (p, x = 8, 9) x 4, then (p, x = 0..7) x 4      GEMM tiles 0 (with the padding), 1
+    //             40 ..  71  file 0 (x = 0), ranks 1..8: 8 p + (y - 1)                      tile 2   "left":   dx = -1 taps
+    //             72 .. 103  rank 8 (y = 8), files 1..8: 8 p + (x - 1)                      tile 3   "bottom": dy = +1 taps
+    //            104 .. 167  interior cells j = 56 p + 8 (y - 1) + (x - 1), j < 64           tiles 4, 5
+    //            168 .. 199  file 9 (x = 9), ranks 1..8                                     tile 6   "right":  dx = +1 taps
+    //            200 .. 359  interior cells j >= 64                                          tiles 7 .. 11
+    // A cell group (two waves) owns the tiles wr, wr + 4, wr + 8, so per tap the skippable tiles of the wave pair on SIMDs 0 / 1
+    // (groups 0, 2: top, left, right) and of the pair on SIMDs 2 / 3 (groups 1, 3: top, bottom) balance in taps 0, 1, 2, 6, 8.
+    // The order being arbitrary, a cell's 16-byte-chunk swizzle key is no longer its row & 15 but 8 ((y + p) & 1) + ((x + y) & 7):
+    // the 16 lanes of every ds_read_b128 group (two board rows of eight cells, or sixteen cells of one file of two positions) hit
+    // 16 distinct slots for every tap (emulated: tools/experiments/trunk_layout_emulation.py; the 8 rank-0 cells that share tile 0
+    // with the padding are the exception: 2-way).
+    auto row_of = [](int p, int y, int x) -> int {
+        if (y == 0) return x < 8 ? 8 + 8 * p + x : 2 * p + (x - 8);
+        if (x == 0) return 40 + 8 * p + (y - 1);
+        if (x == 9) return 168 + 8 * p + (y - 1);
+        if (y == 8) return 72 + 8 * p + (x - 1);
+        const int j = 56 * p + 8 * (y - 1) + (x - 1);
+        return j < 64 ? 104 + j : 136 + j;
+    };
+    auto key_of = [](int p, int y, int x) -> int { return 8 * ((y + p) & 1) + ((x + y) & 7); };
+    auto lds_of_natural = [&](int natural, int c) -> int {   // natural = p * 90 + y * 10 + x; byte offset of 16-byte chunk c of the cell's row
+        const int p = natural / 90, cc = natural - p * 90, y = cc / 10, x = cc - y * 10;
+        return row_of(p, y, x) * CV_ROWB + ((c ^ key_of(p, y, x)) << 4);
     };
 
     auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             const int r = idx >> 4, c = idx & 15;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < nrows) v = g[idx];
-            *reinterpret_cast<uint4 *>(smem + lds_addr(lds_row_of(r) * CV_ROWB, c)) = v;
+            *reinterpret_cast<uint4 *>(smem + lds_of_natural(r, c)) = v;
         }
     } else {
         const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
@@ -418,33 +435,59 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // a cell group owns the row tiles wr, wr + 4, wr + 8: the two all-rank-0 tiles (0 and 1) then belong to groups 0 and 1, i.e. to
-    // one wave on EACH of the four SIMDs (waves w and w + 4 share a SIMD): the MFMAs they skip are balanced over the SIMDs
-    int rowb[CV_RT], tapmask[CV_RT], natb[CV_RT];
+    // per lane and owned tile: the own cell (row | key << 9 | live << 13), its 32 bytes of input planes, and for each of the nine
+    // taps the neighbour's row (360 = the zero row when it is off the board), 9 bits each, three taps per register.  The neighbour's
+    // KEY needs no table: key(p, y + dy, x + dx) is the own key with bit 3 flipped for dy = +-1 and dx + dy added to its low three
+    // bits — for an off-board neighbour too, which reads the zero row in the slot its (virtual) cell would have used, so every
+    // ds_read_b128 group stays on 16 distinct slots (a padding lane's key is its lane number)
+    int own[CV_RT], natb[CV_RT], nb[CV_RT][3];
 #pragma unroll
     for (int i = 0; i < CV_RT; ++i) {
         const int k = 32 * (wr + 4 * i) + l31 - 24;       // LDS row; k < 0: one of the 24 padding rows
-        const int kk = k < 0 ? 0 : k;
-        const int h = kk / 40, rem = kk - h * 40, pp = rem / 10, w = rem - pp * 10;
-        rowb[i] = kk * CV_ROWB;
-        natb[i] = (pp * 90 + h * 10 + w) * 32;           // the cell's 32 bytes of input planes (natural order)
-        int m = 0;
+        int p = 0, y = 0, x = 0;
+        if (k >= 200 || (k >= 104 && k < 168)) { const int j = k >= 200 ? k - 136 : k - 104; p = j / 56; const int r = j - p * 56; y = (r >> 3) + 1; x = (r & 7) + 1; }
+        else if (k >= 168) { p = (k - 168) >> 3; y = ((k - 168) & 7) + 1; x = 9; }
+        else if (k >= 72) { p = (k - 72) >> 3; y = 8; x = ((k - 72) & 7) + 1; }
+        else if (k >= 40) { p = (k - 40) >> 3; y = ((k - 40) & 7) + 1; x = 0; }
+        else if (k >= 8) { p = (k - 8) >> 3; x = (k - 8) & 7; }
+        else if (k >= 0) { p = k >> 1; x = 8 + (k & 1); }
+        const bool live = k >= 0;
+        own[i] = live ? (k | (key_of(p, y, x) << 9) | (1 << 13)) : ((l31 & 15) << 9);
+        natb[i] = (p * 90 + y * 10 + x) * 32;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) nb[i][q] = 0;
+#pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
-            if (k >= 0 && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool valid = live && yy >= 0 && yy < 9 && xx >= 0 && xx < 10;
+            nb[i][t / 3] |= (valid ? row_of(p, yy, xx) : Geo::ROWS) << (9 * (t % 3));
         }
-        tapmask[i] = m;
     }
-    auto tap_addr = [&](int tap, int (&ab)[CV_RT], int (&key)[CV_RT]) {
-        const int delta = ((tap / 3 - 1) * 40 + (tap - (tap / 3) * 3 - 1)) * CV_ROWB;
+    static_assert(Geo::ZERO_OFF == Geo::ROWS * CV_ROWB, "the zero row is row ROWS");
+    auto nb_row = [&](int i, int tap) -> int {   // tap is a compile-time constant wherever the product path calls this
+        const int sel = tap / 3;
+        int r = nb[i][0];
+        r = sel == 1 ? nb[i][1] : r; r = sel >= 2 ? nb[i][2] : r;
+        return (r >> (9 * (tap - 3 * sel))) & 511;
+    };
+    // everything derived from nb / own is loop-invariant over the layers: without an opaque copy per layer hipcc hoists the 54 tap
+    // addresses and keys out of the layer loop and spills (the same trick as refresh_rb below)
+    auto refresh_nb = [&]() {
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
-            const int a = ((tapmask[i] >> tap) & 1) ? rowb[i] + delta : Geo::ZERO_OFF;
-            ab[i] = a;
-            // a masked lane reads the all-zero row, but in the 16-byte slot its REAL (off-board) neighbour row would have
-            // used: the 16 lanes of a ds_read_b128 group then still hit 16 distinct slots.  With the zero row's own swizzle
-            // key every group containing a border cell paid a 2-way bank conflict (24 % of the LDS cycles).
-            key[i] = (((rowb[i] + delta) >> 8) & 15) ^ khalf;
+            asm volatile("" : "+v"(own[i]));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(nb[i][q]));
+        }
+    };
+    auto tap_addr = [&](int tap_, int (&ab)[CV_RT], int (&key)[CV_RT]) {
+        const int tap = tap_ < 9 ? tap_ : 8;   // the prefetch behind the last tap reads something harmless
+        const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+#pragma unroll
+        for (int i = 0; i < CV_RT; ++i) {
+            const int k4 = (own[i] >> 9) & 15;
+            ab[i] = nb_row(i, tap) * CV_ROWB;
+            key[i] = ((((k4 >> 3) ^ dy) & 1) << 3 | ((k4 + dx + dy) & 7)) ^ khalf;
         }
     };
     const int vb0 = Geo::W_OFF + khalf * 2048 + ((wc * 64 + l31) << 4);
@@ -457,15 +500,14 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
     auto refresh_rb = [&]() {
 #pragma unroll
         for (int i = 0; i < CV_RT; ++i) {
-            const int k = 32 * (wr + 4 * i) + l31 - 24;
-            rb[i] = (k < 0 ? 0 : k) * CV_ROWB;
+            rb[i] = own[i];
             asm volatile("" : "+v"(rb[i]));
         }
     };
     auto cell_ptr = [&](int i, int j, int q, bool &live) -> uint2 * {
-        live = 32 * (wr + 4 * i) + l31 >= 24;
+        live = (rb[i] >> 13) & 1;
         const int n0 = wc * 64 + j * 32 + 8 * q + 4 * khalf;
-        return reinterpret_cast<uint2 *>(smem + lds_addr(rb[i], n0 >> 3) + ((n0 & 4) << 1));
+        return reinterpret_cast<uint2 *>(smem + (rb[i] & 511) * CV_ROWB + (((n0 >> 3) ^ ((rb[i] >> 9) & 15)) << 4) + ((n0 & 4) << 1));
     };
     // acc = bias (+ x): the residual is folded into the initialisation of a block's second conv
     uint2 xreg[CV_RT][CV_CT][4];   // block input x at this lane's accumulator positions (packed bf16)
@@ -523,7 +565,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             bf16x8 af[CV_RT];
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) {
-                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + (natb[i] + shift * 32) : Geo::ZERO_OFF;
+                const int a = nb_row(i, t) != Geo::ROWS ? Geo::PLANES_OFF + (natb[i] + shift * 32) : Geo::ZERO_OFF;
                 af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
             }
 #pragma unroll
@@ -580,12 +622,16 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         }
 
     int g = 0;
-    int skipm;   // cell groups 0 and 1 (waves 0..3): their first row tile skips the dy = -1 taps.  Defined by scalar asm so that it IS a scalar register
-    asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cselect_b32 %0, 1, 0" : "=s"(skipm) : "s"(wave_u) : "scc");
+    // which of the wave's first two tiles (slot 0: tile wr, slot 1: tile wr + 4) is off the board for a tap: two bits per tap.
+    // Groups 0, 1: the rank-0 tiles (taps 0..2); group 2: the file-0 tile (taps 0, 3, 6) and the file-9 tile (slot 1: taps 2, 5, 8);
+    // group 3: the rank-8 tile (taps 6..8).  The slab bodies branch around those tiles' MFMAs (adding 0 * w is exact: the outputs
+    // are bit-identical); per SIMD the skipped MFMAs balance in taps 0, 1, 2, 6 and 8 (1/6 of the slab's) — 5/54 of a layer's.
+    const int skiptab = __builtin_amdgcn_readfirstlane(wr < 2 ? 0x15 : (wr == 2 ? 0x21861 : 0x15000));
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
         f32x16 acc[CV_RT][CV_CT];
         CZ_T8_STAMP(0);
+        refresh_nb();
         refresh_rb();
         if (!(layer & 1)) {   // first conv of a block: remember x, start from the bias
 #pragma unroll
@@ -606,11 +652,11 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
             TW_LOADSET(0, 0, 512, f0, ab, key, vb);   // waited for by the first k-step itself
         }
         CZ_T8_STAMP(1);
-        int tap = 0;
 #if defined(CZ_T8_SKIPTEST)   // measurement only (tools/experiments/tower_skip_ubench.hip; never defined in the library): the first
         // CZ_T8_SKIPTEST taps of every layer run a slab body WITHOUT the MFMAs of the wave's third cell tile — wrong results;
         // what issuing 1/9 .. 1/3 fewer MFMAs buys in wall time under the power governor (zero-work removal).  A
         // loop of its own: the two slab bodies under one branch made hipcc copy the accumulators at the join
+        int tap = 0;
 #pragma unroll 1
         for (; tap < CZ_T8_SKIPTEST; ++tap) {
             T8_RUN(TW8_SKIP_ASM_H0, TW8F_SKIP_ASM_H0, ab, key)
@@ -619,31 +665,36 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
         }
-#else
-        // taps 0..2 (dy = -1): cell groups 0 and 1 (waves 0..3) own a first row tile of rank-0 cells and padding only — all its
-        // inputs are the zero row — and branch around that tile's MFMAs inside the slab body (scalar branches on VCC = skipm);
-        // groups 2 and 3 fall through them.  One wave of each kind sits on every SIMD, so every SIMD issues 1/12 fewer MFMAs in
-        // these six slabs (5.6 % of a layer's MFMAs; adding 0 * w is exact: the outputs are bit-identical)
 #pragma unroll 1
-        for (; tap < 3; ++tap) {
-            T8_RUNV(TW8_SKIP0_ASM_H0, TW8F_SKIP0_ASM_H0, ab, key)
+        for (; tap < 9; ++tap) {
+            T8_RUN(TW8_SLAB_ASM_H0, TW8F_SLAB_ASM_H0, ab, key)
             tap_addr(tap + 1, nab, nkey);
-            T8_RUNV(TW8_SKIP0_ASM_H1, TW8F_SKIP0_ASM_H1, nab, nkey)
+            T8_RUN(TW8_SLAB_ASM_H1, TW8F_SLAB_ASM_H1, nab, nkey)
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
         }
-#endif
-#pragma unroll 1
-        for (; tap < 9; ++tap) {
-            T8_RUN(TW8_SLAB_ASM_H0, TW8F_SLAB_ASM_H0, ab, key)      // two 16 KB slabs per tap
-            tap_addr(tap + 1, nab, nkey);
-            T8_RUN(TW8_SLAB_ASM_H1, TW8F_SLAB_ASM_H1, nab, nkey)
+#else
+        // the nine taps unrolled: the neighbour fields come out of their registers with constant shifts, the skip bits of a tap are
+        // one s_bfe.  Two 16 KB slabs per tap; tap 4 (the centre) has nothing to skip and runs the plain bodies
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 4) {
+                T8_RUN(TW8_SLAB_ASM_H0, TW8F_SLAB_ASM_H0, ab, key)
+                tap_addr(tap + 1, nab, nkey);
+                T8_RUN(TW8_SLAB_ASM_H1, TW8F_SLAB_ASM_H1, nab, nkey)
+            } else {
+                const int skipm = __builtin_amdgcn_readfirstlane((skiptab >> (2 * tap)) & 3);
+                T8_RUNV(TW8_SKIPG_ASM_H0, TW8F_SKIPG_ASM_H0, ab, key)
+                tap_addr(tap + 1, nab, nkey);
+                T8_RUNV(TW8_SKIPG_ASM_H1, TW8F_SKIPG_ASM_H1, nab, nkey)
+            }
 #pragma unroll
             for (int i = 0; i < CV_RT; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; }
 #if defined(CZ_T8_TRACE) && CZ_T8_TRACE >= 2
             CZ_T8_STAMP(4 + tap);
 #endif
         }
+#endif
         // the last k-step prefetched garbage for a non-existent next slab; drain it, let the MFMAs retire, and make
         // sure every wave is done reading U before anyone overwrites it in place
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -666,7 +717,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         uint4 *go = reinterpret_cast<uint4 *>(out + (size_t)pos0 * 90 * 128);
         for (int idx = tid; idx < nrows * 16; idx += Geo::THREADS) {
             const int r = idx >> 4, c = idx & 15;
-            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_addr(lds_row_of(r) * CV_ROWB, c));
+            go[idx] = *reinterpret_cast<const uint4 *>(smem + lds_of_natural(r, c));
         }
     }
     if (head_out) {
@@ -676,7 +727,7 @@ __global__ __launch_bounds__(P * 128, 2) void k_tower8_c128(const uint16_t *__re
         // The summation order per (cell, channel) is unchanged — chunks in a fixed order, eight products left to right —
         // so the outputs are bit-identical to the earlier kernel and do not depend on the row's position in the batch.
         for (int r = tid; r < nrows; r += Geo::THREADS) {
-            const int rowoff = lds_row_of(r) * CV_ROWB, key = (rowoff >> 8) & 15;
+            const int l0 = lds_of_natural(r, 0), rowoff = l0 & ~(CV_ROWB - 1), key = (l0 >> 4) & 15;   // chunk 0 sits in slot key
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
 #pragma unroll 4
             for (int c = 0; c < 16; ++c) {

@@ -144,9 +144,22 @@ def main():
             else:
                 out.append(l)
         return out
-    txt += "\n// slab bodies whose first-row-tile MFMAs sit behind a scalar branch (dy = -1 taps), bf16 and fp16\n"
-    txt += emit("TW8_SKIP0_ASM_H0", branchy(slab8(0))) + "\n" + emit("TW8_SKIP0_ASM_H1", branchy(slab8(1))) + "\n"
-    txt += emit("TW8F_SKIP0_ASM_H0", f16(branchy(slab8(0)))) + "\n" + emit("TW8F_SKIP0_ASM_H1", f16(branchy(slab8(1))))
+    # the general form: bit 0 of %[skipm] skips the wave's FIRST row tile (c00, c01: branch on VCC, set once at the top), bit 1 its
+    # SECOND (c10, c11: s_bitcmp1 + branch on SCC in front of each MFMA; nothing between the two reads or writes SCC)
+    def branchy2(L):
+        out = ["s_bitcmp1_b32 %[skipm], 0", "s_cselect_b64 vcc, -1, 0"]
+        for l in L:
+            acc = l.split()[1] if l.startswith("v_mfma") else ""
+            if acc in ("%[c00],", "%[c01],"):
+                out += ["s_cbranch_vccnz 1f", l, "1:"]
+            elif acc in ("%[c10],", "%[c11],"):
+                out += ["s_bitcmp1_b32 %[skipm], 1", "s_cbranch_scc1 2f", l, "2:"]
+            else:
+                out.append(l)
+        return out
+    txt += "\n// slab bodies whose first / second row-tile MFMAs sit behind scalar branches (off-board tiles of a tap), bf16 and fp16\n"
+    txt += emit("TW8_SKIPG_ASM_H0", branchy2(slab8(0))) + "\n" + emit("TW8_SKIPG_ASM_H1", branchy2(slab8(1))) + "\n"
+    txt += emit("TW8F_SKIPG_ASM_H0", f16(branchy2(slab8(0)))) + "\n" + emit("TW8F_SKIPG_ASM_H1", f16(branchy2(slab8(1))))
     open(os.path.join(csrc, "cz_tower_slab_asm.inc"), "w").write(txt)
     txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
     txt += "// k_trunk_split_c128: 8 waves / 2 positions, operands split into hi + lo halves, 9 MFMAs per k-step, bf16 and fp16\n"
