@@ -1,6 +1,7 @@
 """Emulation of the class-tiled cell order of k_tower8_c128 (4 positions) with explicit swizzle keys (cz_conv_kernel.h): the
 row map is a bijection, its inverse is the kernel's decode, which (tile, tap) pairs are off the board, and how many lanes of each
-16-lane ds_read_b128 group share a slot (bank conflicts) per tile and tap.  usage: python tools/experiments/trunk_layout_emulation.py"""
+16-lane ds_read_b128 group share a slot (bank conflicts) per tile and tap.  A "group" here is 16 consecutive GEMM rows of a tile:
+the kernel relabels its lanes (m31) so that the hardware's lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} own exactly those.  usage: python tools/experiments/trunk_layout_emulation.py"""
 import itertools
 def row_of(p,y,x):
     if y==0: return 8+8*p+x if x<8 else 2*p+(x-8)
