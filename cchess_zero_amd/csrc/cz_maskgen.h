@@ -200,145 +200,177 @@ CZM_FN void czm_or_field(OrWord &&or_word, int bit, uint32_t field) {
 struct CzmNo { static constexpr bool value = false; };
 struct CzmYes { static constexpr bool value = true; };
 
+// ---- the pieces of a position, shared by the set form (czm_position) and the ordered list (czm_list) ------------------------
 // w: the 90 board bytes (sq = y * 9 + x, code = 1 + index in "KARBNPCkarbnpc"; bytes 90, 91 of w[22] must be zero);
-// side 0 = red ('w', codes 1..7, home ranks 0..4) to move, 1 = black.  Returns the number of legal moves, or -1 when the
-// position is not a Xiangqi position the vocabulary can express (more than 16 pieces of a colour; an advisor / bishop move
-// without a label).  Branch-free apart from the loops: every lane runs every kind's code; a missing piece (square -1) computes
-// on square 0 and its field is zeroed before it is OR-ed in.
-template <typename Emit>
-CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, Emit emit) {
+// side 0 = red ('w', codes 1..7, home ranks 0..4) to move, 1 = black.
+struct CzmSets { CzmSet occ, own, enemy, K, A, R, B, N, C, P, EK; };
+
+CZM_FN CzmSets czm_sets(const uint32_t (&w)[23], int side) {
     // own piece code = kind + (side ? 7 : 0), kind: K 1, A 2, R 3, B 4, N 5, P 6, C 7.  Bit planes p0..p3 of the codes; red's
     // own pieces have bit 3 clear and the kind in the low three bits, black's have bit 3 set and kind - 1 there: a bit-sliced
     // "+ 1 where black moves" (XOR / AND with the lane's side mask, no selects) makes the low bits the kind for both sides.
     const CzmSet p0 = czm_plane<0>(w), p1 = czm_plane<1>(w), p2 = czm_plane<2>(w), p3 = czm_plane<3>(w);
-    const CzmSet occ = {p0.lo | p1.lo | p2.lo | p3.lo, p0.hi | p1.hi | p2.hi | p3.hi};
+    CzmSets S;
+    S.occ = CzmSet{p0.lo | p1.lo | p2.lo | p3.lo, p0.hi | p1.hi | p2.hi | p3.hi};
     const CzmSet sm = {side ? ~0ull : 0ull, side ? 0x03FFFFFFu : 0u};
     const CzmSet n0 = czm_xor(p0, sm), c0 = czm_and(p0, sm), n1 = czm_xor(p1, c0), c1 = czm_and(p1, c0), n2 = czm_xor(p2, c1);
-    const CzmSet mine = czm_and(czm_xor(p3, czm_not(sm)), occ);    // bit 3 == side, not empty
+    const CzmSet mine = czm_and(czm_xor(p3, czm_not(sm)), S.occ);    // bit 3 == side, not empty
     const CzmSet i0 = czm_not(n0), i1 = czm_not(n1), i2 = czm_not(n2);
-    const CzmSet K = czm_and(mine, czm_and(n0, czm_and(i1, i2))), A = czm_and(mine, czm_and(i0, czm_and(n1, i2)));
-    const CzmSet R = czm_and(mine, czm_and(n0, czm_and(n1, i2))), B = czm_and(mine, czm_and(i0, czm_and(i1, n2)));
-    const CzmSet N = czm_and(mine, czm_and(n0, czm_and(i1, n2))), C = czm_and(mine, czm_and(n0, czm_and(n1, n2)));
-    CzmSet P = czm_and(mine, czm_and(i0, czm_and(n1, n2)));
+    S.K = czm_and(mine, czm_and(n0, czm_and(i1, i2))); S.A = czm_and(mine, czm_and(i0, czm_and(n1, i2)));
+    S.R = czm_and(mine, czm_and(n0, czm_and(n1, i2))); S.B = czm_and(mine, czm_and(i0, czm_and(i1, n2)));
+    S.N = czm_and(mine, czm_and(n0, czm_and(i1, n2))); S.C = czm_and(mine, czm_and(n0, czm_and(n1, n2)));
+    S.P = czm_and(mine, czm_and(i0, czm_and(n1, n2)));
     // the enemy king: code 8 (bit 3 only) when red moves, code 1 (bit 0 only) when black moves
-    const CzmSet EK = czm_and(czm_and(czm_xor(p3, sm), czm_xor(p0, czm_not(sm))), czm_and(czm_not(p1), czm_not(p2)));
-    const CzmSet own = {K.lo | A.lo | R.lo | B.lo | N.lo | P.lo | C.lo, K.hi | A.hi | R.hi | B.hi | N.hi | P.hi | C.hi};
-    const CzmSet enemy = {occ.lo & ~own.lo, occ.hi & ~own.hi};
-    bool err = __builtin_popcountll(own.lo) + __builtin_popcount(own.hi) > 16;
+    S.EK = czm_and(czm_and(czm_xor(p3, sm), czm_xor(p0, czm_not(sm))), czm_and(czm_not(p1), czm_not(p2)));
+    S.own = CzmSet{S.K.lo | S.A.lo | S.R.lo | S.B.lo | S.N.lo | S.P.lo | S.C.lo, S.K.hi | S.A.hi | S.R.hi | S.B.hi | S.N.hi | S.P.hi | S.C.hi};
+    S.enemy = CzmSet{S.occ.lo & ~S.own.lo, S.occ.hi & ~S.own.hi};
+    return S;
+}
+// rook / cannon on square q (main.py:757-833, 947-1062): the 17-bit field of its destinations
+template <bool cannon>
+CZM_FN uint32_t czm_slider_field(const CzmSets &S, int q) {
+    const int y = q / 9, x = q - y * 9;
+    const uint32_t rd = czm_line_dests<cannon>(czm_rank(S.occ, y), czm_rank(S.enemy, y), x, 9);
+    const uint32_t fd = czm_line_dests<cannon>(czm_file(S.occ, x), czm_file(S.enemy, x), y, 10);
+    return czm_ortho_field(rd, fd, x, y);
+}
+// knight on q (main.py:835-856): bit j = jump j of the vocabulary order ((dx,dy) = (-2,-1) (-1,-2) (-2,1) (1,-2) (2,-1) (-1,2) (2,1)
+// (1,2)) is legal.  The window starts at q - 19: jump j lands on bit 19 + 9 dy + dx, its leg is bit 18 / 20 (dx = -+2) or 10 / 28
+// (dy = -+2); squares off the board read as free and empty — `on` has no bit for a jump that leaves the board
+CZM_FN uint32_t czm_knight_good(const CzmSets &S, int q, uint32_t on) {
+    const uint64_t fr = ~czm_window(S.own, q - 19), em = ~czm_window(S.occ, q - 19);
+    const uint32_t tg = czm_wbit(fr, 8) | (czm_wbit(fr, 0) << 1) | (czm_wbit(fr, 26) << 2) | (czm_wbit(fr, 2) << 3) |
+                        (czm_wbit(fr, 12) << 4) | (czm_wbit(fr, 36) << 5) | (czm_wbit(fr, 30) << 6) | (czm_wbit(fr, 38) << 7);
+    const uint32_t lg = (czm_wbit(em, 18) * 0x05u) | (czm_wbit(em, 10) * 0x0Au) | (czm_wbit(em, 20) * 0x50u) | (czm_wbit(em, 28) * 0xA0u);
+    return tg & lg & on;
+}
+// king on q (main.py:919-946): the field of its steps inside the palace; *fg = the file-field bit of the flying general
+// (main.py:1097-1107: kings on one file, nothing between), which the reference appends to its list LAST
+CZM_FN uint32_t czm_king_field(const CzmSets &S, int side, int q, int eq, uint32_t *fg) {
+    const int y = q / 9, x = q - y * 9;
+    const int ylo = side ? 7 : 0, yhi = side ? 9 : 2;
+    const bool iny = (y >= ylo) & (y <= yhi), inx = (x >= 3) & (x <= 5);
+    uint32_t rd = 0u, fd = 0u;
+    const uint64_t fr = ~czm_window(S.own, q - 9);   // bit 0: q - 9, 8: q - 1, 10: q + 1, 18: q + 9
+    rd |= ((uint32_t)(iny & (x >= 4) & (x <= 6)) & czm_wbit(fr, 8)) << ((x + 8) % 9);      // x - 1, kept in range
+    rd |= ((uint32_t)(iny & (x >= 2) & (x <= 4)) & czm_wbit(fr, 10)) << ((x + 1) % 9);
+    fd |= ((uint32_t)(inx & (y - 1 >= ylo) & (y - 1 <= yhi)) & czm_wbit(fr, 0)) << ((y + 9) % 10);   // y - 1
+    fd |= ((uint32_t)(inx & (y + 1 >= ylo) & (y + 1 <= yhi)) & czm_wbit(fr, 18)) << ((y + 1) % 10);
+    const int e = eq >= 0 ? eq : 0;
+    const int ey = e / 9, ex = e - ey * 9;
+    const int lo = y < ey ? y : ey, hi = y < ey ? ey : y;
+    const uint32_t between = czm_low(hi) & ~czm_low(lo + 1);
+    const uint32_t fgd = (uint32_t)((eq >= 0) & (ex == x) & ((czm_file(S.occ, x) & between) == 0u)) << ey;
+    *fg = czm_ortho_field(0u, fgd, x, y);
+    return czm_ortho_field(rd, fd, x, y);
+}
+// pawn on q (main.py:1063-1095): black advances to y - 1, red to y + 1; sideways once past the river.  The field directly
+// (czm_ortho_field's squeeze of the own file / rank done by hand): the left neighbour is field bit x - 1, the right one bit x;
+// the forward square is file bit y for red (y + 1 with rank y squeezed out), y - 1 for black
+CZM_FN uint32_t czm_pawn_field(const CzmSets &S, int side, int q) {
+    const int y = q / 9, x = q - y * 9;
+    const int fy = side ? y - 1 : y + 1;
+    const bool fin = (fy >= 0) & (fy <= 9), river = side ? y < 5 : y > 4;
+    const uint64_t fr = ~czm_window(S.own, q - 9);   // bit 0: q - 9, 8: q - 1, 10: q + 1, 18: q + 9
+    const uint32_t lr = ((uint32_t)(river & (x >= 1)) & czm_wbit(fr, 8)) | (((uint32_t)(river & (x <= 7)) & czm_wbit(fr, 10)) << 1);
+    const uint32_t fwd = (uint32_t)fin & (side ? czm_wbit(fr, 0) : czm_wbit(fr, 18));
+    const int gp = side ? (y > 0 ? y - 1 : 0) : y;
+    return ((lr << x) >> 1) | (fwd << (gp + 8));
+}
+// advisor (kind 0; main.py:889-918: one diagonal step inside the palace) / bishop (kind 1; main.py:857-888: two diagonal steps,
+// the eye empty, own half of the board) on q: bit d = direction d ((dy,dx) = (-s,-s) (-s,+s) (+s,+s) (+s,-s)) is legal.  The
+// window starts at q - 20: the target of direction d is bit 20 + st (9 sy + sx), a bishop's eye bit 20 + 9 sy + sx
+template <int kind>
+CZM_FN uint32_t czm_diag_good(const CzmSets &S, int side, int q) {
+    const int st = kind ? 2 : 1;
+    const int ylo = kind ? (side ? 5 : 0) : (side ? 7 : 0), yhi = kind ? (side ? 9 : 4) : (side ? 9 : 2);
+    const int xlo = kind ? 0 : 3, xhi = kind ? 8 : 5;
+    const int y = q / 9, x = q - y * 9;
+    const uint64_t fr = ~czm_window(S.own, q - 20), em = ~czm_window(S.occ, q - 20);
+    uint32_t good = 0u;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int sy = (d < 2 ? -1 : 1), sx = (d == 0 || d == 3) ? -1 : 1;
+        const int ty = y + sy * st, tx = x + sx * st;
+        const bool in = (ty >= ylo) & (ty <= yhi) & (tx >= xlo) & (tx <= xhi);
+        const uint32_t free_t = kind ? czm_wbit(fr, 20 + 2 * (9 * sy + sx)) : czm_wbit(fr, 20 + 9 * sy + sx);
+        const uint32_t open_eye = kind ? czm_wbit(em, 20 + 9 * sy + sx) : 1u;
+        good |= ((uint32_t)in & free_t & open_eye) << d;
+    }
+    return good;
+}
+
+// ---- the SET: czm_position.  Returns the number of legal moves, or -1 when the position is not a Xiangqi position the
+// vocabulary can express (more than 16 pieces of a colour; an advisor / bishop move without a label).  Branch-free apart from
+// the loops: every lane runs every kind's code; a missing piece (square -1) computes on square 0 and its field is zeroed before
+// it is handed out.
+template <typename Emit>
+CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, Emit emit) {
+    const CzmSets S = czm_sets(w, side);
+    bool err = __builtin_popcountll(S.own.lo) + __builtin_popcount(S.own.hi) > 16;
     int count = 0;
     auto put = [&](int bit, uint32_t f, bool ok) {
         f = ok ? f : 0u;
         count += __builtin_popcount(f);
         emit(bit, f);
     };
-
-    // ---- rooks, then cannons (main.py:757-833, 947-1062): at most two of each — the kind's lowest and highest square
-    auto slider = [&](int sq, bool ok, auto is_cannon) {
-        constexpr bool cannon = decltype(is_cannon)::value;
-        const int q = ok ? sq : 0;
-        const int y = q / 9, x = q - y * 9;
-        const uint32_t rd = czm_line_dests<cannon>(czm_rank(occ, y), czm_rank(enemy, y), x, 9);
-        const uint32_t fd = czm_line_dests<cannon>(czm_file(occ, x), czm_file(enemy, x), y, 10);
-        put(T.base[q], czm_ortho_field(rd, fd, x, y), ok);
-    };
-    {
-        const int r0 = czm_lowest(R), r1 = czm_highest(R), c0 = czm_lowest(C), c1 = czm_highest(C);
+    {   // rooks, then cannons: at most two of each — the kind's lowest and highest square
+        const int r0 = czm_lowest(S.R), r1 = czm_highest(S.R), c0 = czm_lowest(S.C), c1 = czm_highest(S.C);
 #pragma unroll 1
-        for (int it = 0; it < 2; ++it) slider(it ? r1 : r0, it ? r1 > r0 : r0 >= 0, CzmNo{});
+        for (int it = 0; it < 2; ++it) { const int sq = it ? r1 : r0; const bool ok = it ? r1 > r0 : r0 >= 0; const int q = ok ? sq : 0; put(T.base[q], czm_slider_field<false>(S, q), ok); }
 #pragma unroll 1
-        for (int it = 0; it < 2; ++it) slider(it ? c1 : c0, it ? c1 > c0 : c0 >= 0, CzmYes{});
+        for (int it = 0; it < 2; ++it) { const int sq = it ? c1 : c0; const bool ok = it ? c1 > c0 : c0 >= 0; const int q = ok ? sq : 0; put(T.base[q], czm_slider_field<true>(S, q), ok); }
     }
-    // ---- knights (main.py:835-856): jump j lands on (x + dx, y + dy); the leg is the orthogonal neighbour on the long side
-    auto knight = [&](int sq, bool ok) {
-        const int q0 = ok ? sq : 0;
-        const uint32_t on = T.knon[q0];
-        // the window starts at q0 - 19: jump j = (dx, dy) lands on bit 19 + 9 dy + dx, its leg is bit 18 / 20 (dx = -+2) or 10 / 28
-        // (dy = -+2); squares off the board read as free and empty — `on` has no bit for a jump that leaves the board
-        const uint64_t fr = ~czm_window(own, q0 - 19), em = ~czm_window(occ, q0 - 19);
-        const uint32_t tg = czm_wbit(fr, 8) | (czm_wbit(fr, 0) << 1) | (czm_wbit(fr, 26) << 2) | (czm_wbit(fr, 2) << 3) |
-                            (czm_wbit(fr, 12) << 4) | (czm_wbit(fr, 36) << 5) | (czm_wbit(fr, 30) << 6) | (czm_wbit(fr, 38) << 7);
-        const uint32_t lg = (czm_wbit(em, 18) * 0x05u) | (czm_wbit(em, 10) * 0x0Au) | (czm_wbit(em, 20) * 0x50u) | (czm_wbit(em, 28) * 0xA0u);
-        const uint32_t good = tg & lg & on;
-        uint32_t f = 0u;
+    {   // knights: the vocabulary lists on-board jumps only
+        const int n0 = czm_lowest(S.N), n1 = czm_highest(S.N);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {
+            const int sq = it ? n1 : n0; const bool ok = it ? n1 > n0 : n0 >= 0; const int q = ok ? sq : 0;
+            const uint32_t on = T.knon[q], good = czm_knight_good(S, q, on);
+            uint32_t f = 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f |= ((good >> j) & 1u) << __builtin_popcount(on & czm_low(j));   // the vocabulary lists on-board jumps only
-        put(T.base[q0] + 17, f, ok);
-    };
-    {
-        const int n0 = czm_lowest(N), n1 = czm_highest(N);
-#pragma unroll 1
-        for (int it = 0; it < 2; ++it) knight(it ? n1 : n0, it ? n1 > n0 : n0 >= 0);
+            for (int j = 0; j < 8; ++j) f |= ((good >> j) & 1u) << __builtin_popcount(on & czm_low(j));
+            put(T.base[q] + 17, f, ok);
+        }
     }
-    // ---- king (main.py:919-946) + the flying general (main.py:1097-1107: kings on one file, nothing between)
-    {
-        const int sq = czm_lowest(K), eq = czm_lowest(EK);
+    {   // king + the flying general
+        const int sq = czm_lowest(S.K), eq = czm_lowest(S.EK);
         const bool ok = sq >= 0;
         const int q = ok ? sq : 0;
-        const int y = q / 9, x = q - y * 9;
-        const int ylo = side ? 7 : 0, yhi = side ? 9 : 2;
-        const bool iny = (y >= ylo) & (y <= yhi), inx = (x >= 3) & (x <= 5);
-        uint32_t rd = 0u, fd = 0u;
-        const uint64_t fr = ~czm_window(own, q - 9);   // bit 0: q - 9, 8: q - 1, 10: q + 1, 18: q + 9
-        rd |= ((uint32_t)(iny & (x >= 4) & (x <= 6)) & czm_wbit(fr, 8)) << ((x + 8) % 9);      // x - 1, kept in range
-        rd |= ((uint32_t)(iny & (x >= 2) & (x <= 4)) & czm_wbit(fr, 10)) << ((x + 1) % 9);
-        fd |= ((uint32_t)(inx & (y - 1 >= ylo) & (y - 1 <= yhi)) & czm_wbit(fr, 0)) << ((y + 9) % 10);   // y - 1
-        fd |= ((uint32_t)(inx & (y + 1 >= ylo) & (y + 1 <= yhi)) & czm_wbit(fr, 18)) << ((y + 1) % 10);
-        const int e = eq >= 0 ? eq : 0;
-        const int ey = e / 9, ex = e - ey * 9;
-        const int lo = y < ey ? y : ey, hi = y < ey ? ey : y;
-        const uint32_t between = czm_low(hi) & ~czm_low(lo + 1);
-        fd |= (uint32_t)((eq >= 0) & (ex == x) & ((czm_file(occ, x) & between) == 0u)) << ey;
-        put(T.base[q], czm_ortho_field(rd, fd, x, y), ok);
+        uint32_t fg;
+        const uint32_t f = czm_king_field(S, side, q, eq, &fg);
+        put(T.base[q], f | fg, ok);
     }
-    // ---- pawns (main.py:1063-1095): black advances to y-1, red to y+1; sideways once past the river; at most five
+    {   // pawns: at most five
+        CzmSet P = S.P;
 #pragma unroll 1
-    for (int it = 0; it < 5; ++it) {
-        const int sq = czm_lowest(P);
-        P = czm_without(P, sq);
-        const bool ok = sq >= 0;
-        const int q = ok ? sq : 0;
-        const int y = q / 9, x = q - y * 9;
-        const int fy = side ? y - 1 : y + 1;
-        const bool fin = (fy >= 0) & (fy <= 9), river = side ? y < 5 : y > 4;
-        const uint64_t fr = ~czm_window(own, q - 9);   // bit 0: q - 9, 8: q - 1, 10: q + 1, 18: q + 9
-        // the field directly (czm_ortho_field's squeeze of the own file / rank done by hand): the left neighbour is field bit
-        // x - 1, the right one bit x; the forward square is file bit y for red (y + 1 with rank y squeezed out), y - 1 for black
-        const uint32_t lr = ((uint32_t)(river & (x >= 1)) & czm_wbit(fr, 8)) | (((uint32_t)(river & (x <= 7)) & czm_wbit(fr, 10)) << 1);
-        const uint32_t fwd = (uint32_t)fin & (side ? czm_wbit(fr, 0) : czm_wbit(fr, 18));
-        const int gp = side ? (y > 0 ? y - 1 : 0) : y;
-        put(T.base[q], ((lr << x) >> 1) | (fwd << (gp + 8)), ok);
+        for (int it = 0; it < 5; ++it) {
+            const int sq = czm_lowest(P);
+            P = czm_without(P, sq);
+            const bool ok = sq >= 0;
+            const int q = ok ? sq : 0;
+            put(T.base[q], czm_pawn_field(S, side, q), ok);
+        }
     }
-    // ---- advisors (main.py:889-918: one diagonal step inside the palace) and bishops (main.py:857-888: two diagonal steps,
-    //      the eye empty, own half of the board); their labels are the 48 literals at the end of the vocabulary
-    uint64_t lits = 0ull;   // the 48 advisor / bishop literals of the position
-    auto literal = [&](int sq, bool ok, int kind) {
-        const int q0 = ok ? sq : 0;
-        const int st = kind ? 2 : 1;
-        const int ylo = kind ? (side ? 5 : 0) : (side ? 7 : 0), yhi = kind ? (side ? 9 : 4) : (side ? 9 : 2);
-        const int xlo = kind ? 0 : 3, xhi = kind ? 8 : 5;
-        const int y = q0 / 9, x = q0 - y * 9;
-        // the window starts at q0 - 20: the target of direction d is bit 20 + st (9 sy + sx), a bishop's eye bit 20 + 9 sy + sx
-        const uint64_t fr = ~czm_window(own, q0 - 20), em = ~czm_window(occ, q0 - 20);
+    uint64_t lits = 0ull;   // the 48 advisor / bishop literals of the position (labels 2038 + l)
+    auto literal = [&](int sq, bool ok, auto kind_tag) {
+        constexpr int kind = decltype(kind_tag)::value ? 1 : 0;
+        const int q = ok ? sq : 0;
+        const uint32_t good = ok ? czm_diag_good<kind>(S, side, q) : 0u;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int sy = (d < 2 ? -1 : 1), sx = (d == 0 || d == 3) ? -1 : 1;
-            const int ty = y + sy * st, tx = x + sx * st;
-            const bool in = (ty >= ylo) & (ty <= yhi) & (tx >= xlo) & (tx <= xhi);
-            const uint32_t free_t = kind ? czm_wbit(fr, 20 + 2 * (9 * sy + sx)) : czm_wbit(fr, 20 + 9 * sy + sx);
-            const uint32_t open_eye = kind ? czm_wbit(em, 20 + 9 * sy + sx) : 1u;
-            const bool good = ((uint32_t)((int)ok & (int)in) & free_t & open_eye) != 0u;
-            const uint32_t l = T.ab[kind][q0 * 4 + d];
-            err |= good & (l == 0xFFu);
-            const bool set = good & (l != 0xFFu);
-            lits |= set ? 1ull << (l & 63u) : 0ull;      // literal l = label 2038 + l: OR-ed into the row once, below
+            const uint32_t l = T.ab[kind][q * 4 + d];
+            const bool g = ((good >> d) & 1u) != 0u;
+            err |= g & (l == 0xFFu);
+            lits |= (g & (l != 0xFFu)) ? 1ull << (l & 63u) : 0ull;
         }
     };
     {
-        const int a0 = czm_lowest(A), a1 = czm_highest(A), b0 = czm_lowest(B), b1 = czm_highest(B);
+        const int a0 = czm_lowest(S.A), a1 = czm_highest(S.A), b0 = czm_lowest(S.B), b1 = czm_highest(S.B);
 #pragma unroll 1
-        for (int it = 0; it < 2; ++it) literal(it ? a1 : a0, it ? a1 > a0 : a0 >= 0, 0);
+        for (int it = 0; it < 2; ++it) literal(it ? a1 : a0, it ? a1 > a0 : a0 >= 0, CzmNo{});
 #pragma unroll 1
-        for (int it = 0; it < 2; ++it) literal(it ? b1 : b0, it ? b1 > b0 : b0 >= 0, 1);
+        for (int it = 0; it < 2; ++it) literal(it ? b1 : b0, it ? b1 > b0 : b0 >= 0, CzmYes{});
     }
     {   // labels 2038 .. 2085, sixteen per emit
         count += __builtin_popcountll(lits);
@@ -347,4 +379,155 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, E
         emit(CZM_NLIT_BASE + 32, (uint32_t)(lits >> 32) & 0xFFFFu);
     }
     return err ? -1 : count;
+}
+
+// ---- the ORDERED LIST: czm_list — GameBoard.get_legal_moves' list (main.py:743-1109) as labels, in the reference's order:
+// pieces in scan order (ascending square: y outer, x inner, main.py:754-755); a rook / cannon its four rays -x, +x, -y, +y, each
+// from the piece outwards (for a cannon the capture behind the screen ends its ray); a knight (2i, j) then (i, 2j) for i, j in
+// (-1, +1)^2; the king x - 1, x + 1, y - 1, y + 1; a pawn forward, x + 1, x - 1; advisors / bishops their four diagonals (-,-)
+// (-,+) (+,+) (+,-); the flying general LAST (main.py:1097-1107).  One lane = one position here too, and no divergence on the
+// piece kind: the pieces are generated KIND BY KIND into 16 payload registers (the same fields as czm_position's), their counts
+// are summed in SQUARE order through 16 words of per-position scratch (a piece's rank = the number of own pieces below its
+// square), and then every piece writes its moves at its offset — label = the square's base + the index of the field bit.
+//   put(n, label, cond): the n-th move of the list is `label` (when cond);   scr(i): the i-th scratch word (i varies per lane);
+//   mid(): called once between the last use of the scratch and the first put (a caller may keep both in the same memory)
+// Returns the number of moves, or -1 like czm_position.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CZM_ANY(c) (__ballot(c) != 0ull)
+#else
+#define CZM_ANY(c) (c)
+#endif
+CZM_FN int czm_rank_below(const CzmSet &own, int q) {   // own pieces on squares < q
+    const uint64_t ml = q >= 64 ? ~0ull : ((1ull << (q & 63)) - 1ull);
+    const uint32_t mh = q >= 64 ? ((1u << ((q - 64) & 31)) - 1u) : 0u;
+    return __builtin_popcountll(own.lo & ml) + __builtin_popcount(own.hi & mh);
+}
+template <typename Put, typename Scr, typename Mid>
+CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put put, Scr scr, Mid mid) {
+    const CzmSets S = czm_sets(w, side);
+    bool err = __builtin_popcountll(S.own.lo) + __builtin_popcount(S.own.hi) > 16;
+    // slots in kind order: 0, 1 rooks; 2, 3 cannons; 4, 5 knights; 6 king; 7 .. 11 pawns; 12, 13 advisors; 14, 15 bishops
+    int q[16];
+    uint32_t pay[16];
+    auto slot = [&](int s, int sq, bool ok, uint32_t p) { q[s] = ok ? sq : 0; pay[s] = ok ? p : 0u; };
+    {
+        const int r0 = czm_lowest(S.R), r1 = czm_highest(S.R), c0 = czm_lowest(S.C), c1 = czm_highest(S.C);
+        slot(0, r0, r0 >= 0, czm_slider_field<false>(S, r0 >= 0 ? r0 : 0));
+        slot(1, r1, r1 > r0, czm_slider_field<false>(S, r1 > r0 ? r1 : 0));
+        slot(2, c0, c0 >= 0, czm_slider_field<true>(S, c0 >= 0 ? c0 : 0));
+        slot(3, c1, c1 > c0, czm_slider_field<true>(S, c1 > c0 ? c1 : 0));
+        const int n0 = czm_lowest(S.N), n1 = czm_highest(S.N);
+        slot(4, n0, n0 >= 0, czm_knight_good(S, n0 >= 0 ? n0 : 0, T.knon[n0 >= 0 ? n0 : 0]));
+        slot(5, n1, n1 > n0, czm_knight_good(S, n1 > n0 ? n1 : 0, T.knon[n1 > n0 ? n1 : 0]));
+    }
+    uint32_t fg = 0u;
+    const int kq = czm_lowest(S.K);
+    {
+        uint32_t f = czm_king_field(S, side, kq >= 0 ? kq : 0, czm_lowest(S.EK), &fg);
+        slot(6, kq, kq >= 0, f);
+        fg = kq >= 0 ? fg : 0u;
+    }
+    {
+        CzmSet P = S.P;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int sq = czm_lowest(P);
+            P = czm_without(P, sq);
+            slot(7 + it, sq, sq >= 0, czm_pawn_field(S, side, sq >= 0 ? sq : 0));
+        }
+    }
+    {
+        const int a0 = czm_lowest(S.A), a1 = czm_highest(S.A), b0 = czm_lowest(S.B), b1 = czm_highest(S.B);
+        slot(12, a0, a0 >= 0, czm_diag_good<0>(S, side, a0 >= 0 ? a0 : 0));
+        slot(13, a1, a1 > a0, czm_diag_good<0>(S, side, a1 > a0 ? a1 : 0));
+        slot(14, b0, b0 >= 0, czm_diag_good<1>(S, side, b0 >= 0 ? b0 : 0));
+        slot(15, b1, b1 > b0, czm_diag_good<1>(S, side, b1 > b0 ? b1 : 0));
+    }
+    // the counts in square order: scratch word r collects the count of the piece of rank r (a missing piece adds 0 to word 0)
+    int rk[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) scr(s) = 0u;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        rk[s] = czm_rank_below(S.own, q[s]) & 15;
+        scr(rk[s]) += (uint32_t)__builtin_popcount(pay[s]);
+    }
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int t = (int)scr(r); scr(r) = (uint32_t)total; total += t; }
+    int off[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) off[s] = (int)scr(rk[s]);
+    mid();
+    // every piece writes its moves at its offset
+    auto emit_desc = [&](uint32_t bits, int label0, int &n) {   // set bits from the highest down
+        while (CZM_ANY(bits != 0u)) {
+            const bool c = bits != 0u;
+            const int i = c ? 31 - __builtin_clz(bits) : 0;
+            put(n, label0 + i, c);
+            n += c ? 1 : 0;
+            bits &= ~(1u << i);
+        }
+    };
+    auto emit_asc = [&](uint32_t bits, int label0, int &n) {    // set bits from the lowest up
+        while (CZM_ANY(bits != 0u)) {
+            const bool c = bits != 0u;
+            const int i = c ? __builtin_ctz(bits) : 0;
+            put(n, label0 + i, c);
+            n += c ? 1 : 0;
+            bits &= bits - 1u;
+        }
+    };
+    auto ortho = [&](int s, bool pawn) {
+        const int y = q[s] / 9, x = q[s] - y * 9, base = T.base[q[s]];
+        const uint32_t rkf = pay[s] & 0xFFu, flf = pay[s] >> 8;
+        int n = off[s];
+        if (pawn) {   // forward, x + 1, x - 1
+            emit_asc(flf, base + 8, n);
+            emit_asc(rkf & ~czm_low(x), base, n);
+            emit_desc(rkf & czm_low(x), base, n);
+        } else {      // -x, +x, -y, +y, each from the piece outwards
+            emit_desc(rkf & czm_low(x), base, n);
+            emit_asc(rkf & ~czm_low(x), base, n);
+            emit_desc(flf & czm_low(y), base + 8, n);
+            emit_asc(flf & ~czm_low(y), base + 8, n);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ortho(s, false);
+#pragma unroll
+    for (int s = 4; s < 6; ++s) {   // knights: (2i, j) then (i, 2j) for i, j in (-1, +1)^2 = vocabulary jumps 1, 0, 3, 4, 5, 2, 7, 6
+        const uint32_t on = T.knon[q[s]];
+        const int base = T.base[q[s]] + 17;
+        int n = off[s];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int j = o == 0 ? 1 : o == 1 ? 0 : o == 2 ? 3 : o == 3 ? 4 : o == 4 ? 5 : o == 5 ? 2 : o == 6 ? 7 : 6;
+            const bool c = ((pay[s] >> j) & 1u) != 0u;
+            put(n, base + __builtin_popcount(on & czm_low(j)), c);
+            n += c ? 1 : 0;
+        }
+    }
+    ortho(6, false);
+#pragma unroll
+    for (int s = 7; s < 12; ++s) ortho(s, true);
+#pragma unroll
+    for (int s = 12; s < 16; ++s) {
+        const int kind = s >= 14 ? 1 : 0;
+        int n = off[s];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t l = T.ab[kind][q[s] * 4 + d];
+            const bool g = ((pay[s] >> d) & 1u) != 0u;
+            err |= g & (l == 0xFFu);
+            put(n, CZM_NLIT_BASE + (int)(l & 63u), g);
+            n += g ? 1 : 0;
+        }
+    }
+    {   // the flying general, last
+        const bool c = fg != 0u;
+        put(total, (int)T.base[kq >= 0 ? kq : 0] + (c ? __builtin_ctz(fg) : 0), c);
+        total += c ? 1 : 0;
+    }
+    return err ? -1 : total;
 }

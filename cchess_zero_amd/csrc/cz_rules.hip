@@ -1,6 +1,7 @@
-// cz_rules.hip — stand-alone rules kernels K1 (move generation: four positions per wave64), K2 (make move + hash +
-// flags), K3 (input planes: one wave per position).  Boards are staged in LDS, results leave with coalesced stores.  These are HBM/issue-bound byte
-// kernels: no MFMA here by design.
+// cz_rules.hip — stand-alone rules kernels: K1 move generation (one lane = one position: the ordered list k_movegen_list, the set
+// k_movegen_mask), K2 (make move + hash + flags), the Zobrist key (one lane = one position), K3 (input planes: one wave per
+// position).  Boards are staged in LDS, results leave with coalesced stores.  These are HBM / issue-bound byte kernels: no MFMA
+// here by design.
 #include "cz_internal.h"
 #include "cz_maskgen.h"
 
@@ -16,62 +17,6 @@ __device__ __forceinline__ void load_board(const uint8_t *__restrict__ g, uint8_
         lds[2 * lane + 1] = 0;
     }
     __syncthreads();
-}
-
-// K1: FOUR positions per wave64 (czd_group_movegen: lane = (position, piece of the side to move)); boards come in with
-// 2-byte loads (the ABI only promises byte alignment), the ordered lists leave as one 16-byte store per lane.
-__global__ __launch_bounds__(64) void k_movegen(CzTables tab, const uint8_t *__restrict__ boards,
-                                                const uint8_t *__restrict__ side, int G,
-                                                uint16_t *__restrict__ moves, uint16_t *__restrict__ count,
-                                                uint32_t *__restrict__ mask) {
-    __shared__ __attribute__((aligned(16))) uint8_t b[4 * CZ_NSQ + 8];   // four boards, packed (stride 90)
-    __shared__ uint16_t stage[64 * CZD_STAGE_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint16_t out[4 * CZD_MAXMOVES];
-    __shared__ CzdGroupLds GL;
-    __shared__ uint32_t m[4 * (CZ_MASK_WORDS + 2)];
-    __shared__ uint8_t sd[4];
-    const int lane = threadIdx.x, q = lane >> 4, s = lane & 15;
-    const int ngroups = (G + 3) >> 2;
-    const bool aligned4 = (reinterpret_cast<uintptr_t>(boards) & 3u) == 0;   // 4 boards = 360 bytes = 90 dwords
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int g0 = grp * 4;
-        const int np = min(4, G - g0);
-        if (aligned4 && np == 4) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(boards + (size_t)g0 * CZ_NSQ);
-            reinterpret_cast<uint32_t *>(b)[lane] = src[lane];
-            if (lane < 26) reinterpret_cast<uint32_t *>(b)[lane + 64] = src[lane + 64];
-        } else {
-            for (int j = lane; j < 4 * CZ_NSQ; j += 64) {
-                const int p = j / CZ_NSQ;
-                b[j] = p < np ? boards[(size_t)g0 * CZ_NSQ + j] : (uint8_t)0;
-            }
-        }
-        if (lane < 4) sd[lane] = (lane < np && side[g0 + lane]) ? 1 : 0;
-        __syncthreads();
-        const int n = czd_group_movegen<4, CZ_NSQ>(b, [&](int p) { return (int)sd[p]; }, tab.lut, GL, stage, out, lane);
-        const int nn = n < 0 ? 0 : n;
-        if (s == 0 && q < np) count[g0 + q] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
-        if (moves) {
-            for (int i = s; i < CZD_MAXMOVES; i += 16)
-                if (i >= nn) out[q * CZD_MAXMOVES + i] = (uint16_t)0xFFFF;
-            __syncthreads();
-            if (q < np) reinterpret_cast<uint4 *>(moves + (size_t)g0 * CZD_MAXMOVES)[lane] = reinterpret_cast<const uint4 *>(out)[lane];
-        }
-        if (mask) {
-            for (int i = lane; i < 4 * (CZ_MASK_WORDS + 2); i += 64) m[i] = 0;
-            __syncthreads();
-            for (int i = s; i < nn; i += 16) {
-                const int l = out[q * CZD_MAXMOVES + i];
-                atomicOr(&m[q * (CZ_MASK_WORDS + 2) + (l >> 5)], 1u << (l & 31));
-            }
-            __syncthreads();
-            for (int i = lane; i < np * CZ_MASK_WORDS; i += 64) {
-                const int p = i / CZ_MASK_WORDS, w = i - p * CZ_MASK_WORDS;
-                mask[(size_t)g0 * CZ_MASK_WORDS + i] = m[p * (CZ_MASK_WORDS + 2) + w];
-            }
-        }
-        __syncthreads();
-    }
 }
 
 // K1m: the legal-move MASK (and count) without the ordered list — cz_movegen(moves = NULL).  One lane = one position; the rules
@@ -239,6 +184,98 @@ __global__ void k_apply_move(CzTables tab, uint8_t *__restrict__ boards, uint8_t
     }
 }
 
+// K1 (ordered): GameBoard.get_legal_moves' list as labels in the reference's order — cz_movegen(moves != NULL).  One lane = one
+// position, czm_list (cz_maskgen.h): the pieces kind by kind into payload registers, their counts summed in square order through
+// 16 words of per-position scratch, then every piece writes its labels at its offset into the lane's row of the list buffer in
+// LDS (64 rows of 128 labels; 260-byte stride: the 64 lanes' 2-byte writes spread over the banks) — the boards, the scratch and
+// the list rows share the same LDS; the rows leave as 16-byte stores.  The lane = piece kernel this replaces (four positions per
+// wave, staging rows, a segmented prefix sum, one LUT round trip and one LDS atomic per move) ran at 1.9 G positions/s.
+#define CZK_LROW 65   /* dwords per list row in LDS: 64 + 1 */
+__global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
+                                                     const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ moves,
+                                                     uint16_t *__restrict__ count) {
+    __shared__ __attribute__((aligned(16))) uint32_t rows[64 * CZK_LROW + 4];
+    __shared__ __attribute__((aligned(16))) CzmTables T;
+    const int lane = threadIdx.x;
+    if (lane < (int)(sizeof(CzmTables) / 16)) reinterpret_cast<uint4 *>(&T)[lane] = reinterpret_cast<const uint4 *>(gtab)[lane];
+    const int ngroups = (G + 63) >> 6;
+    const bool al16 = (reinterpret_cast<uintptr_t>(boards) & 15u) == 0;
+    uint4 pre[6];
+    int presd = 0;
+    auto prefetch = [&](int grp) {
+        const int g0 = grp * 64, np = min(64, G - g0), nbytes = np * CZ_NSQ;
+        const uint8_t *src = boards + (size_t)g0 * CZ_NSQ;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = lane + 64 * k;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i * 16 + 16 <= nbytes) v = reinterpret_cast<const uint4 *>(src)[i];
+            pre[k] = v;
+        }
+        presd = (lane < np && side[g0 + lane]) ? 1 : 0;
+    };
+    if (al16 && (int)blockIdx.x < ngroups) prefetch(blockIdx.x);
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int g0 = grp * 64, np = min(64, G - g0), p = g0 + lane;
+        const bool live = lane < np;
+        CZK_WAVE_SYNC();   // the previous group's rows have left (and the tables are in place)
+        int sd;
+        if (al16) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (lane + 64 * k < 64 * CZ_NSQ / 16) reinterpret_cast<uint4 *>(rows)[lane + 64 * k] = pre[k];
+            if (np < 64) {
+                const int nbytes = np * CZ_NSQ, full = nbytes & ~15;
+                if (lane < nbytes - full) reinterpret_cast<uint8_t *>(rows)[full + lane] = boards[(size_t)g0 * CZ_NSQ + full + lane];
+            }
+            sd = presd;
+        } else {
+            const uint8_t *src = boards + (size_t)g0 * CZ_NSQ;
+            uint8_t *dst = reinterpret_cast<uint8_t *>(rows);
+            const int nbytes = np * CZ_NSQ;
+            for (int i = lane; i < nbytes; i += 64) dst[i] = src[i];
+            sd = (live && side[p]) ? 1 : 0;
+        }
+        CZK_WAVE_SYNC();
+        uint32_t w[23];
+        {
+            const int b0 = (CZ_NSQ * lane) >> 2, sh = (lane & 1) * 16;
+            uint32_t d[24];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) d[k] = rows[b0 + k];
+#pragma unroll
+            for (int k = 0; k < 23; ++k) w[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], (uint32_t)sh);
+            w[22] &= 0x0000FFFFu;
+            if (!live) {
+#pragma unroll
+                for (int k = 0; k < 23; ++k) w[k] = 0u;
+            }
+        }
+        if (al16 && grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+        CZK_WAVE_SYNC();   // every lane holds its board: the bytes become scratch, then list rows
+        uint16_t *row16 = reinterpret_cast<uint16_t *>(rows) + lane * (2 * CZK_LROW);
+        const int n = czm_list(w, sd, T,
+            [row16](int k, int label, bool c) { if (c) row16[k & 127] = (uint16_t)label; },
+            [&](int i) -> uint32_t & { return rows[(i & 15) * 64 + lane]; },
+            [&]() {   // the scratch has been read: fill the rows with the 0xFFFF padding of the ABI
+                CZK_WAVE_SYNC();
+                for (int i = lane; i < 64 * CZK_LROW; i += 64) rows[i] = 0xFFFFFFFFu;
+                CZK_WAVE_SYNC();
+            });
+        if (live) count[p] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
+        CZK_WAVE_SYNC();
+        uint4 *dst = reinterpret_cast<uint4 *>(moves + (size_t)g0 * CZD_MAXMOVES);
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int idx = lane + 64 * k, pp = idx >> 4, j = idx & 15;
+            if (pp < np) {
+                const uint32_t *src = rows + pp * CZK_LROW + 4 * j;
+                dst[idx] = make_uint4(src[0], src[1], src[2], src[3]);
+            }
+        }
+    }
+}
+
 // Zobrist key of a position (the oracle's cz_zhash): one lane = one position, as in k_movegen_mask — a wave stages
 // its 64 boards through LDS with 16-byte loads, every lane pulls its 90 bytes out as 23 dwords, and the 15 x 90 + 1 keys live
 // in LDS (10.8 KB, copied once per persistent wave): 90 ds_read_b64 per position instead of 90 dependent byte loads and 64-bit
@@ -307,11 +344,14 @@ inline int grid_for(int G) { return G < 65536 ? G : 65536; }
 int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves, uint16_t *count, uint32_t *mask) {
     if (G == 0) return CZ_OK;
     if (moves && (reinterpret_cast<uintptr_t>(moves) & 15u)) { cz_set_error("cz_movegen: moves must be 16-byte aligned"); return CZ_EINVAL; }
-    if (!moves) {   // the set, not the list: one lane per position (k_movegen_mask); mask may be NULL too (counts only)
-        const int ngroups = (G + 63) / 64, chip = 256 * 12;   // 12 waves per CU fit (13.3 KB LDS, <= 168 VGPRs each): one resident generation, each walks its groups
+    const int ngroups = (G + 63) / 64;
+    if (moves) {    // the reference's ordered list: one lane per position (k_movegen_list), 9 persistent waves per CU (17.7 KB LDS each)
+        const int chip = 256 * 9;
+        hipLaunchKernelGGL(k_movegen_list, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count);
+    }
+    if (!moves || mask) {   // the set (k_movegen_mask: mask and count; mask may be NULL: counts only): 12 persistent waves per CU
+        const int chip = 256 * 12;
         hipLaunchKernelGGL(k_movegen_mask, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, count, mask);
-    } else {        // the reference's ordered list (+ the mask derived from it): four positions per wave
-        hipLaunchKernelGGL(k_movegen, dim3(grid_for((G + 3) / 4)), dim3(64), 0, c->stream, c->tab, boards, side, G, moves, count, mask);
     }
     CZ_HIP(hipGetLastError());
     return CZ_OK;

@@ -24,3 +24,19 @@ extern "C" void czm_host_masks(const CzmTables *t, const uint8_t *boards, const 
         if (emits != CZM_EMITS) count[i] = -1000 - emits;   // the kernel's record buffer relies on this number
     }
 }
+
+// boards [n][90], side [n] -> moves [n][128] labels in the reference's order (0xFFFF padding), count [n] (-1: error)
+extern "C" void czm_host_lists(const CzmTables *t, const uint8_t *boards, const uint8_t *side, int n, uint16_t *moves, int *count) {
+    for (int i = 0; i < n; ++i) {
+        uint32_t w[23];
+        unsigned char buf[92];
+        memcpy(buf, boards + (size_t)i * 90, 90);
+        buf[90] = buf[91] = 0;
+        memcpy(w, buf, 92);
+        uint16_t *row = moves + (size_t)i * 128;
+        for (int k = 0; k < 128; ++k) row[k] = 0xFFFF;
+        uint32_t scratch[16];
+        count[i] = czm_list(w, side[i] ? 1 : 0, *t, [row](int k, int label, bool c) { if (c && k >= 0 && k < 128) row[k] = (uint16_t)label; },
+                            [&scratch](int k) -> uint32_t & { return scratch[k & 15]; }, [] {});
+    }
+}

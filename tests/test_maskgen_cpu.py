@@ -30,6 +30,16 @@ def host(tmp_path_factory):
         c = np.zeros(n, np.int32)
         lib.czm_host_masks(tab, boards.ctypes.data_as(C.c_void_p), side.ctypes.data_as(C.c_void_p), n, m.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
         return m, c
+
+    def lists(boards, side):
+        boards = np.ascontiguousarray(boards, np.uint8).reshape(-1, 90)
+        side = np.ascontiguousarray(side, np.uint8)
+        n = len(boards)
+        mv = np.zeros((n, 128), np.uint16)
+        c = np.zeros(n, np.int32)
+        lib.czm_host_lists(tab, boards.ctypes.data_as(C.c_void_p), side.ctypes.data_as(C.c_void_p), n, mv.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+        return mv, c
+    masks.lists = lists
     return masks
 
 
@@ -70,3 +80,33 @@ def test_maskgen_matches_oracle_on_random_playouts(host):
     for i in range(len(boards)):
         assert c[i] == len(want[i]), i
         assert np.array_equal(m[i], _mask_of(want[i])), i
+
+
+def test_listgen_matches_reference_golden_lists(host, rules_golden):
+    """czm_list (the ordered list, one lane = one position) against the reference's 4 381 ordered lists, 0xFFFF padding included."""
+    g = rules_golden
+    mv, c = host.lists(g["boards"], g["side"])
+    assert np.array_equal(c, g["counts"].astype(np.int32))
+    bad = np.nonzero((mv != g["moves"]).any(axis=1))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], mv[bad[0]][:int(c[bad[0]])], g["moves"][bad[0]][:int(c[bad[0]])])
+
+
+def test_listgen_matches_oracle_on_random_playouts(host):
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    boards, sides, want = [], [], []
+    for game in range(120):
+        b, s = O.fen_to_board(O.START_FEN), 0
+        for ply in range(110):
+            mv = O.legal_moves(b, s)
+            boards.append(b.copy()); sides.append(s); want.append(mv)
+            if len(mv) == 0 or not (b == 1).any() or not (b == 8).any():
+                break
+            b = O.apply_move(b, int(mv[rng.integers(len(mv))]))[0]
+            s ^= 1
+    mv, c = host.lists(np.stack(boards), np.array(sides, np.uint8))
+    assert len(boards) > 6000
+    for i in range(len(boards)):
+        assert c[i] == len(want[i]), i
+        assert np.array_equal(mv[i, :c[i]], np.asarray(want[i], np.uint16)), (i, mv[i, :c[i]], want[i])
+        assert (mv[i, c[i]:] == 0xFFFF).all()
