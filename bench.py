@@ -162,7 +162,7 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
     """K1 on its own (48 B board in + 264 B mask out = 312 B/position, HBM-bound in principle): cz_movegen over n
     positions (the run's synthetic positions, tiled), HIP events around `reps` launches.  Headline: the mask-only kernel
     (moves = NULL: k_movegen_mask, one position per lane) — what §8(d)'s 312 B describe; beside it the ordered-list kernel
-    (k_movegen_list + k_movegen_mask, list + mask: the reference's get_legal_moves contract)."""
+    (k_movegen_list, list + mask: the reference's get_legal_moves contract)."""
     G = boards.shape[0]
     b = boards.repeat((n + G - 1) // G, 1)[:n].contiguous()
     sd = side.repeat((n + G - 1) // G)[:n].contiguous()
@@ -186,7 +186,7 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
             "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "positions": n, "positions_per_s": n / sec, "us_per_launch": sec * 1e6, "algorithmic_bytes_per_position": 312,
             "abi_bytes_per_position": abi / n, "abi_GBps": abi / sec / 1e9,
-            "ordered_list_kernel": {"kernel": "k_movegen_list + k_movegen_mask (ordered move list in the reference's generation order, then the mask: one position per lane in both)",
+            "ordered_list_kernel": {"kernel": "k_movegen_list<MASK> (ordered move list in the reference's generation order and the mask from one launch: one position per lane)",
                                     "positions_per_s": n / sec_list, "us_per_launch": sec_list * 1e6, "achieved": alg / sec_list / 1e9,
                                     "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "abi_bytes_per_position": abi_list / n, "abi_GBps": abi_list / sec_list / 1e9,
                                     "note": "issue-bound (VALU: the per-kind generation, the ordering by square, one LDS write per move), not bandwidth-bound: see DESIGN.md 4.6b"}}

@@ -390,7 +390,8 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, E
 // are summed in SQUARE order through 16 words of per-position scratch (a piece's rank = the number of own pieces below its
 // square), and then every piece writes its moves at its offset — label = the square's base + the index of the field bit.
 //   put(n, label, cond): the n-th move of the list is `label` (when cond);   scr(i): the i-th scratch word (i varies per lane);
-//   mid(): called once between the last use of the scratch and the first put (a caller may keep both in the same memory)
+//   mid(): called once between the last use of the scratch and the first put (a caller may keep both in the same memory);
+//   emit(bit, field): the position's SET as well — the same 15 pairs, in the same order, as czm_position hands out
 // Returns the number of moves, or -1 like czm_position.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CZM_ANY(c) (__ballot(c) != 0ull)
@@ -402,8 +403,8 @@ CZM_FN int czm_rank_below(const CzmSet &own, int q) {   // own pieces on squares
     const uint32_t mh = q >= 64 ? ((1u << ((q - 64) & 31)) - 1u) : 0u;
     return __builtin_popcountll(own.lo & ml) + __builtin_popcount(own.hi & mh);
 }
-template <typename Put, typename Scr, typename Mid>
-CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put put, Scr scr, Mid mid) {
+template <typename Put, typename Scr, typename Mid, typename Emit>
+CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put put, Scr scr, Mid mid, Emit emit) {
     const CzmSets S = czm_sets(w, side);
     bool err = __builtin_popcountll(S.own.lo) + __builtin_popcount(S.own.hi) > 16;
     // slots in kind order: 0, 1 rooks; 2, 3 cannons; 4, 5 knights; 6 king; 7 .. 11 pawns; 12, 13 advisors; 14, 15 bishops
@@ -442,6 +443,32 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
         slot(13, a1, a1 > a0, czm_diag_good<0>(S, side, a1 > a0 ? a1 : 0));
         slot(14, b0, b0 >= 0, czm_diag_good<1>(S, side, b0 >= 0 ? b0 : 0));
         slot(15, b1, b1 > b0, czm_diag_good<1>(S, side, b1 > b0 ? b1 : 0));
+    }
+    {   // the set: czm_position's 15 (bit, field) pairs from the same payloads
+#pragma unroll
+        for (int s = 0; s < 4; ++s) emit((int)T.base[q[s]], pay[s]);
+#pragma unroll
+        for (int s = 4; s < 6; ++s) {
+            const uint32_t on = T.knon[q[s]];
+            uint32_t f = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f |= ((pay[s] >> j) & 1u) << __builtin_popcount(on & czm_low(j));
+            emit((int)T.base[q[s]] + 17, f);
+        }
+        emit((int)T.base[q[6]], pay[6] | fg);
+#pragma unroll
+        for (int s = 7; s < 12; ++s) emit((int)T.base[q[s]], pay[s]);
+        uint64_t lits = 0ull;
+#pragma unroll
+        for (int s = 12; s < 16; ++s)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t l = T.ab[s >= 14 ? 1 : 0][q[s] * 4 + d];
+                lits |= (((pay[s] >> d) & 1u) != 0u && l != 0xFFu) ? 1ull << (l & 63u) : 0ull;
+            }
+        emit(CZM_NLIT_BASE, (uint32_t)lits & 0xFFFFu);
+        emit(CZM_NLIT_BASE + 16, (uint32_t)(lits >> 16) & 0xFFFFu);
+        emit(CZM_NLIT_BASE + 32, (uint32_t)(lits >> 32) & 0xFFFFu);
     }
     // the counts in square order: scratch word r collects the count of the piece of rank r (a missing piece adds 0 to word 0)
     int rk[16];

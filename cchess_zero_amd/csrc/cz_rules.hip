@@ -191,9 +191,13 @@ __global__ void k_apply_move(CzTables tab, uint8_t *__restrict__ boards, uint8_t
 // the list rows share the same LDS; the rows leave as 16-byte stores.  The lane = piece kernel this replaces (four positions per
 // wave, staging rows, a segmented prefix sum, one LUT round trip and one LDS atomic per move) ran at 1.9 G positions/s.
 #define CZK_LROW 65   /* dwords per list row in LDS: 64 + 1 */
+// With mask != NULL the same launch writes the 2086-bit masks too: czm_list hands out the set's 15 (bit, field) pairs beside the
+// list (registers), and once the list rows have left the LDS holds 32 mask rows at a time, as in k_movegen_mask (here each
+// lane applies its own position's pairs while its half-wave has the rows).
+template <bool MASK>
 __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
                                                      const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ moves,
-                                                     uint16_t *__restrict__ count) {
+                                                     uint16_t *__restrict__ count, uint32_t *__restrict__ mask) {
     __shared__ __attribute__((aligned(16))) uint32_t rows[64 * CZK_LROW + 4];
     __shared__ __attribute__((aligned(16))) CzmTables T;
     const int lane = threadIdx.x;
@@ -254,6 +258,8 @@ __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict
         if (al16 && grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
         CZK_WAVE_SYNC();   // every lane holds its board: the bytes become scratch, then list rows
         uint16_t *row16 = reinterpret_cast<uint16_t *>(rows) + lane * (2 * CZK_LROW);
+        uint32_t recs[CZM_EMITS];
+        int ne = 0;   // compile-time after unrolling: the emits sit in straight-line code
         const int n = czm_list(w, sd, T,
             [row16](int k, int label, bool c) { if (c) row16[k & 127] = (uint16_t)label; },
             [&](int i) -> uint32_t & { return rows[(i & 15) * 64 + lane]; },
@@ -261,7 +267,8 @@ __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict
                 CZK_WAVE_SYNC();
                 for (int i = lane; i < 64 * CZK_LROW; i += 64) rows[i] = 0xFFFFFFFFu;
                 CZK_WAVE_SYNC();
-            });
+            },
+            [&](int bit, uint32_t f) { if (MASK) recs[ne] = (f << 12) | (uint32_t)bit; ++ne; });
         if (live) count[p] = n < 0 ? (uint16_t)0xFFFF : (uint16_t)n;
         CZK_WAVE_SYNC();
         uint4 *dst = reinterpret_cast<uint4 *>(moves + (size_t)g0 * CZD_MAXMOVES);
@@ -271,6 +278,34 @@ __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict
             if (pp < np) {
                 const uint32_t *src = rows + pp * CZK_LROW + 4 * j;
                 dst[idx] = make_uint4(src[0], src[1], src[2], src[3]);
+            }
+        }
+        if constexpr (MASK) {
+            const bool mal16 = (reinterpret_cast<uintptr_t>(mask) & 15u) == 0;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if (h * 32 >= np) break;
+                CZK_WAVE_SYNC();   // the list rows / the first half's mask rows have left
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (lane + 64 * k < CZK_HALF_WORDS / 4) reinterpret_cast<uint4 *>(rows)[lane + 64 * k] = make_uint4(0, 0, 0, 0);
+                CZK_WAVE_SYNC();
+                if ((lane >> 5) == h) {
+                    uint32_t *row = rows + (lane & 31) * CZ_MASK_WORDS;
+#pragma unroll
+                    for (int k = 0; k < CZM_EMITS; ++k)
+                        czm_or_field([row](int wi, uint32_t x) { atomicOr(&row[wi], x); }, (int)(recs[k] & 0xFFFu), recs[k] >> 12);
+                }
+                CZK_WAVE_SYNC();
+                const int nph = min(32, np - h * 32);
+                uint32_t *dstm = mask + (size_t)(g0 + h * 32) * CZ_MASK_WORDS;
+                if (mal16 && nph == 32) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        if (lane + 64 * k < CZK_HALF_WORDS / 4) reinterpret_cast<uint4 *>(dstm)[lane + 64 * k] = reinterpret_cast<const uint4 *>(rows)[lane + 64 * k];
+                } else {
+                    for (int i = lane; i < nph * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
+                }
             }
         }
     }
@@ -345,11 +380,11 @@ int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, ui
     if (G == 0) return CZ_OK;
     if (moves && (reinterpret_cast<uintptr_t>(moves) & 15u)) { cz_set_error("cz_movegen: moves must be 16-byte aligned"); return CZ_EINVAL; }
     const int ngroups = (G + 63) / 64;
-    if (moves) {    // the reference's ordered list: one lane per position (k_movegen_list), 9 persistent waves per CU (17.7 KB LDS each)
-        const int chip = 256 * 9;
-        hipLaunchKernelGGL(k_movegen_list, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count);
-    }
-    if (!moves || mask) {   // the set (k_movegen_mask: mask and count; mask may be NULL: counts only): 12 persistent waves per CU
+    if (moves) {    // the reference's ordered list (and, from the same launch, the set): one lane per position, 8-9 persistent waves per CU
+        const int chip = 256 * 8;
+        if (mask) hipLaunchKernelGGL(k_movegen_list<true>, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
+        else hipLaunchKernelGGL(k_movegen_list<false>, dim3(ngroups < 256 * 9 ? ngroups : 256 * 9), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
+    } else {        // the set alone (k_movegen_mask: mask and count; mask may be NULL: counts only): 12 persistent waves per CU
         const int chip = 256 * 12;
         hipLaunchKernelGGL(k_movegen_mask, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, count, mask);
     }

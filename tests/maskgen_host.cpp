@@ -25,8 +25,9 @@ extern "C" void czm_host_masks(const CzmTables *t, const uint8_t *boards, const 
     }
 }
 
-// boards [n][90], side [n] -> moves [n][128] labels in the reference's order (0xFFFF padding), count [n] (-1: error)
-extern "C" void czm_host_lists(const CzmTables *t, const uint8_t *boards, const uint8_t *side, int n, uint16_t *moves, int *count) {
+// boards [n][90], side [n] -> moves [n][128] labels in the reference's order (0xFFFF padding), count [n] (-1: error), and the
+// mask [n][66] czm_list emits beside the list (NULL: not wanted)
+extern "C" void czm_host_lists(const CzmTables *t, const uint8_t *boards, const uint8_t *side, int n, uint16_t *moves, int *count, uint32_t *mask) {
     for (int i = 0; i < n; ++i) {
         uint32_t w[23];
         unsigned char buf[92];
@@ -35,8 +36,13 @@ extern "C" void czm_host_lists(const CzmTables *t, const uint8_t *boards, const 
         memcpy(w, buf, 92);
         uint16_t *row = moves + (size_t)i * 128;
         for (int k = 0; k < 128; ++k) row[k] = 0xFFFF;
-        uint32_t scratch[16];
+        uint32_t scratch[16], dummy[66];
+        uint32_t *mrow = mask ? mask + (size_t)i * 66 : dummy;
+        memset(mrow, 0, 66 * 4);
+        int emits = 0;
         count[i] = czm_list(w, side[i] ? 1 : 0, *t, [row](int k, int label, bool c) { if (c && k >= 0 && k < 128) row[k] = (uint16_t)label; },
-                            [&scratch](int k) -> uint32_t & { return scratch[k & 15]; }, [] {});
+                            [&scratch](int k) -> uint32_t & { return scratch[k & 15]; }, [] {},
+                            [mrow, &emits](int bit, uint32_t field) { ++emits; czm_or_field([mrow](int wi, uint32_t v) { if (wi < 66) mrow[wi] |= v; }, bit, field); });
+        if (emits != CZM_EMITS) count[i] = -1000 - emits;
     }
 }

@@ -37,7 +37,10 @@ def host(tmp_path_factory):
         n = len(boards)
         mv = np.zeros((n, 128), np.uint16)
         c = np.zeros(n, np.int32)
-        lib.czm_host_lists(tab, boards.ctypes.data_as(C.c_void_p), side.ctypes.data_as(C.c_void_p), n, mv.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+        m = np.zeros((n, 66), np.uint32)
+        lib.czm_host_lists(tab, boards.ctypes.data_as(C.c_void_p), side.ctypes.data_as(C.c_void_p), n, mv.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+                           m.ctypes.data_as(C.c_void_p))
+        lists.last_mask = m
         return mv, c
     masks.lists = lists
     return masks
@@ -89,6 +92,8 @@ def test_listgen_matches_reference_golden_lists(host, rules_golden):
     assert np.array_equal(c, g["counts"].astype(np.int32))
     bad = np.nonzero((mv != g["moves"]).any(axis=1))[0]
     assert len(bad) == 0, (len(bad), bad[:5], mv[bad[0]][:int(c[bad[0]])], g["moves"][bad[0]][:int(c[bad[0]])])
+    m2, c2 = host(g["boards"], g["side"])     # the set czm_list emits beside the list == czm_position's
+    assert np.array_equal(host.lists.last_mask, m2) and np.array_equal(c, c2)
 
 
 def test_listgen_matches_oracle_on_random_playouts(host):
@@ -110,3 +115,4 @@ def test_listgen_matches_oracle_on_random_playouts(host):
         assert c[i] == len(want[i]), i
         assert np.array_equal(mv[i, :c[i]], np.asarray(want[i], np.uint16)), (i, mv[i, :c[i]], want[i])
         assert (mv[i, c[i]:] == 0xFFFF).all()
+        assert np.array_equal(host.lists.last_mask[i], _mask_of(want[i])), i
