@@ -319,9 +319,9 @@ __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict
 __global__ __launch_bounds__(64) void k_hash(CzTables tab, const uint8_t *__restrict__ boards, const uint8_t *__restrict__ side, int G,
                                              uint64_t *__restrict__ hash) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[64 * CZ_NSQ / 4 + 4];
-    __shared__ uint64_t Z[15 * CZ_NSQ + 1];
+    __shared__ uint64_t Z[16 * CZ_NSQ];   // 15 x 90 keys + the side key at [15 * 90]; the rest of row 15 is zero: a byte above 14 (not a piece code) hashes as an empty square instead of reading past the table
     const int lane = threadIdx.x;
-    for (int i = lane; i < 15 * CZ_NSQ + 1; i += 64) Z[i] = tab.zob[i];
+    for (int i = lane; i < 16 * CZ_NSQ; i += 64) Z[i] = i <= 15 * CZ_NSQ ? tab.zob[i] : 0ull;
     const int ngroups = (G + 63) >> 6;
     const bool al16 = (reinterpret_cast<uintptr_t>(boards) & 15u) == 0;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void k_hash(CzTables tab, const uint8_t *__rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int q = 4 * k + j;
-                    if (q < CZ_NSQ) h ^= Z[((w >> (8 * j)) & 0xFFu) * CZ_NSQ + q];
+                    if (q < CZ_NSQ) { const uint32_t c = (w >> (8 * j)) & 0xFFu; h ^= Z[(c < 15u ? c : 0u) * CZ_NSQ + q]; }
                 }
             }
             hash[g0 + lane] = h;
