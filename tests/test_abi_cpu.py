@@ -94,3 +94,26 @@ def test_generated_slab_asm_is_in_sync(tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tower_asm.py"), str(tmp_path)], check=True, stdout=subprocess.DEVNULL)
     for f in ("cz_tower_slab_asm.inc", "cz_trunk_split_asm.inc"):
         assert open(str(tmp_path / f)).read() == open(os.path.join(ROOT, "cchess_zero_amd", "csrc", f)).read(), f
+
+
+def test_trunk_kernel_layout_constants_match_the_emulation():
+    """k_tower8_c128's class-tiled cell order (cz_conv_kernel.h): the skip tables in the kernel source are the ones the emulation
+    derives from the row map (every off-board (tile, tap) pair, nothing else), the row map is a bijection with the kernel's
+    decode as its inverse, and with the kernel's lane relabelling every ds_read_b128 lane group is conflict-free except the one
+    that shares tile 0 with the padding rows (tools/experiments/trunk_layout_emulation.py)."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("trunk_layout_emulation", os.path.join(ROOT, "tools", "experiments", "trunk_layout_emulation.py"))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    conflicts, skippable = emu.analyse()
+    assert len(skippable) == 15
+    assert {t for (t, _, _) in conflicts} <= {0}
+    tabs = emu.skiptab_of(skippable)
+    src = open(os.path.join(ROOT, "cchess_zero_amd", "csrc", "cz_conv_kernel.h")).read()
+    m = re.search(r"skiptab = __builtin_amdgcn_readfirstlane\(wr < 2 \? (0x[0-9A-Fa-f]+) : \(wr == 2 \? (0x[0-9A-Fa-f]+) : (0x[0-9A-Fa-f]+)\)\)", src)
+    assert m, "skiptab expression not found in cz_conv_kernel.h"
+    assert [tabs[0], tabs[1], tabs[2], tabs[3]] == [int(m.group(1), 16), int(m.group(1), 16), int(m.group(2), 16), int(m.group(3), 16)]
+    # the kernel's row map and key function, literally
+    assert "return x < 8 ? 8 + 8 * p + x : 2 * p + (x - 8);" in src and "return 8 * ((y + p) & 1) + ((x + y) & 7);" in src
+    assert "l31 < 4 ? l31 : l31 < 12 ? l31 + 12 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 12 : l31" in src
