@@ -81,6 +81,7 @@ _SIGS = {
     "cz_net_trunk_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_net_trunk_f16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_net_trunk_split": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "cz_net_trunk_mx": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "cz_fc_heads_f32": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "cz_tower_heads_c128_bf16": (C.c_int, [C.c_void_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
 }

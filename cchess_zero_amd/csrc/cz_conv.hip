@@ -2,6 +2,7 @@
 #include "cz_internal.h"
 #include "cz_conv_kernel.h"
 #include "cz_trunk_split.h"
+#include "cz_trunk_mx.h"
 
 extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, const void *residual,
                                     void *out, int B, int relu) {
@@ -104,6 +105,27 @@ extern "C" int cz_net_trunk_split(cz_ctx *c, const void *planes16, const void *w
         hipLaunchKernelGGL((k_trunk_split_c128<false>), dim3(grid), dim3(XS_THREADS), XS_LDS_BYTES, c->stream, (const uint16_t *)wpk, bias,
                            trunk_out, head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks,
                            c->batch_count, clock_probe(c, grid));
+    CZ_HIP(hipGetLastError());
+    return CZ_OK;
+}
+
+extern "C" int cz_net_trunk_mx(cz_ctx *c, const void *planes16, const void *w0, const float *b0, const void *wpk, const float *bias,
+                               float *trunk_out, const float *head_w, const float *head_b, float *head_out, int B, int nblocks) {
+    using namespace czconv;
+    CZ_REQUIRE(c && planes16 && w0 && b0 && wpk && bias && B >= 0 && nblocks >= 1 && (trunk_out || head_out),
+               "cz_net_trunk_mx: null argument / nblocks < 1");
+    CZ_REQUIRE(!head_out || (head_w && head_b), "cz_net_trunk_mx: head_out needs head_w and head_b");
+    if (head_w && (reinterpret_cast<uintptr_t>(head_w) & 15u)) { cz_set_error("cz_net_trunk_mx: head_w must be 16-byte aligned"); return CZ_EINVAL; }
+    if (reinterpret_cast<uintptr_t>(wpk) & 15u) { cz_set_error("cz_net_trunk_mx: wpk must be 16-byte aligned"); return CZ_EINVAL; }
+    if (B == 0) return CZ_OK;
+    if (!c->mx_attr_set) {
+        CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trunk_mx_c128), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
+        c->mx_attr_set = true;
+    }
+    const int grid = (B + MX_P - 1) / MX_P;
+    hipLaunchKernelGGL(k_trunk_mx_c128, dim3(grid), dim3(MX_THREADS), MX_LDS_BYTES, c->stream, (const unsigned char *)wpk, bias, trunk_out,
+                       head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count,
+                       clock_probe(c, grid));
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }

@@ -155,7 +155,7 @@ struct cz_ctx {
     void *pool_block;
     bool adv_attr_set;   // dynamic-LDS opt-in of k_advance_lds done
     bool adv_force_global;   // cz_search_debug_advance_in_global_memory (tests): take the path of pools whose bitmap exceeds LDS
-    bool conv_attr_set, tower_attr_set, split_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
+    bool conv_attr_set, tower_attr_set, split_attr_set, mx_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1
     int terminal_extra;   // cz_search_set_terminal_extra: terminal simulations a tree may complete inside one select launch

@@ -1,0 +1,410 @@
+// cz_trunk_mx.h — N1m: the strict-precision net trunk at half the matrix work of k_trunk_split_c128 (round 5).
+//
+// k_trunk_split_c128 carries every weight and stored activation as hi + lo fp16 halves and spends three fp16 MFMAs per
+// product: a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi.  The two CROSS terms are 2^-12 of the product, so their operands need
+// only a few significant bits — and gfx950 has a matrix instruction for exactly that: v_mfma_scale_f32_32x32x64_f8f6f4 with
+// fp6 (E2M3) operands does K = 64 in 8 passes (an fp16 32x32x16 takes 8 passes for K = 16) and applies one power-of-two scale
+// per lane = per 32 K-elements.  K-order is free (both operands use the same one), so a lane's 32-element block holds BOTH
+// cross terms of 16 input channels:
+//     B (cell n, half h):    [ q6(a_hi[c_j]) , q6(2^11 a_lo[c_j]) ]  j = 0..15     scale 2^sa(cell, group)
+//     A (channel co, half h): [ q6(2^11 w_lo[c_j]) , q6(w_hi[c_j]) ]               scale 2^(sw(co, tap, group) - 11)
+// and ONE such MFMA adds a_hi*w_lo + a_lo*w_hi of 32 input channels to the accumulator the two fp16 MFMAs of those channels
+// (a_hi*w_hi) go to: 9 MFMAs per slab and wave instead of 18, 1.5 instead of 3 fp16-MFMA-equivalents per product.
+// Precision (tools/precision_mx_schemes.py, tests/mxemu.py): the cross terms keep 4 significant bits of each operand, i.e.
+// ~2^-16 of a product — 30-40x closer to fp32 than the one-value-per-operand fp16 engine, 15x further than three fp16 MFMAs:
+// |dlogit| 4.9e-4 / |dvalue| 2.2e-4 on trained-like weights at 7 blocks, 1.0e-3 / 1.1e-3 at 19 (so precision "strict" uses
+// this kernel up to 8 blocks and k_trunk_split_c128 beyond).
+// What was measured before this was built (tools/experiments/mx_probe.hip, profiles/r05a_mx_probe.txt): the fp6 conversion
+// v_cvt_scalef32_2xpk16_fp6_f32 d, s0, s1, scale puts q(s0[i] / 2^floor(log2 scale)) in slot 2i and q(s1[i] / ...) in slot
+// 2i+1 (RNE, saturating at 7.5) — and hipcc lets its builtin's destination overlap the sources (garbage from slot 12 on): it is
+// used through inline asm with an early-clobber destination; the MFMA pairs slot s of lane m + 32 kb of A with slot s of
+// lane n + 32 kb of B and multiplies by 2^(byteA - 127) 2^(byteB - 127), bytes chosen by op_sel; on the power-limited chip an
+// fp6 MFMA costs 1.27x an fp16 MFMA's time (4x the MACs), so 6 fp16 + 3 fp6 take 0.55 of 18 fp16.
+//
+// Same launch structure as k_trunk_split_c128 (2 positions per workgroup, 8 waves = 2 cell groups x 4 channel tiles, rank-major
+// cells with the 12 padding rows first, ring of four 16 KB weight slabs filled by LDS-DMA, one barrier per slab, the dy = -1
+// skip of cell group 0's first row tile).  LDS (bytes):
+//   X   [8 groups][224][16]  first 16 bytes of the fp6 block of (cell, group g = 2 (c / 32) + ((c % 8) / 4))        0 .. 28,672
+//   Y   [8][224][8]          its last 8 bytes                                                                       .. 43,008
+//   SC  [2 halves][224][4]   E8M0 scale bytes: dword (h, cell) = the four 32-channel quarters' groups of half h        .. 44,800
+//       entries 192 + (r & 31) of every plane are zero blocks / scale 127: a lane whose tap is off the board reads the alias
+//       of the row it would have read (same banks: conflict-free like the real rows), one address for X, Y and SC
+//   HI  [181][256]           fp16 hi halves, chunk c of a row at c ^ ((byte offset >> 8) & 15); row 180 = zeros           .. 91,136
+//   W   4 x 16 KB            weight ring                                                                              .. 156,672
+//   head weights [3][128] f32                                                                                          .. 158,208
+// The last layer's values are written as fp32 (over everything but the head weights) and the head 1x1 convs / the trunk
+// dump read those; the block input of a residual block stays in registers as fp32.
+#pragma once
+#include "cz_conv_kernel.h"
+
+namespace czconv {
+
+#include "cz_trunk_mx_asm.inc"
+
+struct MXGeo {
+    static constexpr int P = 2;
+    static constexpr int ROWS = P * 90;
+    static constexpr int THREADS = 512;
+    static constexpr int ENT = 224;                            // entries per plane: 180 cells, 12 unused, 32 zero aliases
+    static constexpr int XPLANE = ENT * 16, YPLANE = ENT * 8, SPLANE = ENT * 4;
+    static constexpr int X_OFF = 0, Y_OFF = 8 * XPLANE, S_OFF = Y_OFF + 8 * YPLANE;
+    static constexpr int HI_OFF = S_OFF + 2 * SPLANE;          // 44,800 = 175 * 256
+    static constexpr int ZERO_OFF = HI_OFF + ROWS * CV_ROWB;   // the zero row of the hi halves
+    static constexpr int W_OFF = ZERO_OFF + CV_ROWB;           // 91,136
+    static constexpr int SLAB_BYTES = 16384;                   // [hi 8192][X 4096][Y 2048][scale dwords 1024][pad 1024]
+    static constexpr int SLAB_SHIFT = 14;
+    static constexpr int SLABS_PER_LAYER = 36;
+    static constexpr int LDS_BYTES = W_OFF + TW_NBUF * SLAB_BYTES;
+    static constexpr int PLANES_OFF = W_OFF + 3 * SLAB_BYTES;  // the input planes (32 B per cell) borrow ring buffer 3
+    static constexpr int HEADW_OFF = LDS_BYTES;
+    static constexpr int LDS_TOTAL = LDS_BYTES + 3 * 128 * 4;  // 158,208 of the CU's 163,840
+    static constexpr int F32_ROWB = 512;                       // the last layer's fp32 rows (from LDS byte 0)
+};
+static_assert(MXGeo::HI_OFF % 256 == 0 && MXGeo::W_OFF % 16 == 0, "hi rows are swizzled by their absolute 256-byte row");
+static_assert(MXGeo::Y_OFF == 28672 && MXGeo::S_OFF == 43008, "tools/gen_tower_asm.py: MX_Y_OFF / MX_S_OFF");
+static_assert(MXGeo::ROWS * MXGeo::F32_ROWB <= MXGeo::HEADW_OFF, "fp32 trunk rows must leave the head weights alone");
+constexpr int MX_P = MXGeo::P, MX_THREADS = MXGeo::THREADS, MX_LDS_BYTES = MXGeo::LDS_TOTAL;
+
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// the compiler's builtin may allocate the destination over the sources (see the header comment)
+__device__ __forceinline__ u32x6 mx_cvt6(f32x16 a, f32x16 b, float scale) {
+    u32x6 r;
+    asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(scale));
+    return r;
+}
+
+// planes [B][90][16] fp16 (0/1), w0 [9 taps][hi, lo][2 = ci/8][128 co][8] fp16 (the strict engine's first-layer pack),
+// wpk [L][36 slabs][16384 B] (net.py: mx_pack_layer), bias / b0 fp32; out: trunk [B][90][128] FP32 or NULL; head_out [B][90][3].
+__global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *__restrict__ wpk,
+                                                           const float *__restrict__ bias,
+                                                           float *__restrict__ out,
+                                                           const float *__restrict__ head_w,
+                                                           const float *__restrict__ head_b,
+                                                           float *__restrict__ head_out,
+                                                           const uint16_t *__restrict__ planes,
+                                                           const uint16_t *__restrict__ w0,
+                                                           const float *__restrict__ b0,
+                                                           int B, int nlayers,
+                                                           const int *__restrict__ bcount,
+                                                           unsigned long long *__restrict__ clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Geo = MXGeo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, ct = wave & 3;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int pos0 = blockIdx.x * Geo::P;
+    if (bcount) {
+        const int live = *bcount;
+        B = live < B ? live : B;
+    }
+    if (pos0 >= B) return;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    const int npos = (B - pos0) < Geo::P ? (B - pos0) : Geo::P;
+    const int nrows = npos * 90;
+    const int nslabs = nlayers * Geo::SLABS_PER_LAYER;
+    auto lds_addr = [](int row_byte_off, int c) { return row_byte_off + ((c ^ ((row_byte_off >> 8) & 15)) << 4); };
+    const unsigned voff0 = (unsigned)tid << 4, voff1 = voff0 + (unsigned)Geo::THREADS * 16u;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto lds_row_of = [](int natural) {   // natural = p * 90 + y * 10 + x  ->  rank-major row 20 y + 10 p + x
+        const int p = natural / 90, c = natural - p * 90, y = c / 10, x = c - y * 10;
+        return 20 * y + 10 * p + x;
+    };
+
+    auto dma_slab = [&](int slab) {   // prologue only; the loop issues its DMAs from the slab asm
+        const unsigned char *src = wpk + (size_t)slab * Geo::SLAB_BYTES;
+        unsigned char *dst = smem + Geo::W_OFF + ((unsigned)slab & 3u) * Geo::SLAB_BYTES + (wave_u << 10);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff0),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff1),
+                                         (__attribute__((address_space(3))) void *)(dst + Geo::THREADS * 16), 16, 0, 0);
+    };
+    for (int q = 0; q < 3; ++q) dma_slab(q < nslabs ? q : nslabs - 1);
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(planes + (size_t)pos0 * 90 * 16);
+        for (int idx = tid; idx < Geo::ROWS * 2; idx += Geo::THREADS) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < nrows * 2) v = g[idx];
+            *reinterpret_cast<uint4 *>(smem + Geo::PLANES_OFF + (idx << 4)) = v;
+        }
+    }
+    // zero row of the hi halves; zero aliases 192 .. 223 of the X / Y planes; scale 127 (= 2^0) in the aliases of SC
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + Geo::ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
+    if (tid < 256) *reinterpret_cast<uint4 *>(smem + Geo::X_OFF + (tid >> 5) * Geo::XPLANE + (192 + (tid & 31)) * 16) = make_uint4(0, 0, 0, 0);
+    else *reinterpret_cast<uint2 *>(smem + Geo::Y_OFF + ((tid - 256) >> 5) * Geo::YPLANE + (192 + (tid & 31)) * 8) = make_uint2(0, 0);
+    if (tid < 64) *reinterpret_cast<uint32_t *>(smem + Geo::S_OFF + (tid >> 5) * Geo::SPLANE + (192 + (tid & 31)) * 4) = 0x7f7f7f7fu;
+    if (head_out && tid < 3 * 128 / 4)
+        reinterpret_cast<float4 *>(smem + Geo::HEADW_OFF)[tid] = reinterpret_cast<const float4 *>(head_w)[tid];
+    bf16x8 wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+            wf[t][part] = *reinterpret_cast<const bf16x8 *>(w0 + ((size_t)(((t * 2 + part) * 2 + khalf) * 128 + ct * 32 + l31) << 3));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int rowk[3], tapmask[3], natb[3];   // rowk: the lane's LDS row in tile i (-1: padding row)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = 32 * (wr * 3 + i) + l31 - 12;
+        const int kk = k < 0 ? 0 : k;
+        const int h = kk / 20, rem = kk - h * 20, pp = rem / 10, w = rem - pp * 10;
+        rowk[i] = k;
+        natb[i] = (pp * 90 + h * 10 + w) * 32;
+        int m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int y = h + t / 3 - 1, x = w + t % 3 - 1;
+            if (k >= 0 && y >= 0 && y < 9 && x >= 0 && x < 10) m |= 1 << t;
+        }
+        tapmask[i] = m;
+    }
+    // per tap: ab / key = hi row address and swizzle key (cz_trunk_split.h); xr = khalf * XPLANE + 16 * (row or its zero alias):
+    // X block at xr + quarter * 2 XPLANE, Y at Y_OFF + xr / 2 + ..., scale dword at S_OFF + xr / 4
+    auto tap_addr = [&](int tap, int (&ab)[3], int (&key)[3], int (&xr)[3], int (&yr)[3]) {
+        const int delta = (tap / 3 - 1) * 20 + (tap - (tap / 3) * 3 - 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int kk = (rowk[i] < 0 ? 0 : rowk[i]) + delta;
+            const bool on = (tapmask[i] >> tap) & 1;
+            const int rb = Geo::HI_OFF + kk * CV_ROWB;
+            ab[i] = on ? rb : Geo::ZERO_OFF;
+            key[i] = ((rb >> 8) & 15) ^ khalf;
+            xr[i] = khalf * Geo::XPLANE + ((on ? kk : 192 + (kk & 31)) << 4);
+            yr[i] = xr[i] >> 1;
+        }
+    };
+    const int vb0 = Geo::W_OFF + khalf * 2048 + ((ct * 32 + l31) << 4);
+    const int vy0 = Geo::W_OFF + 12288 + khalf * 1024 + ((ct * 32 + l31) << 3);
+    const int vs0 = Geo::W_OFF + 14336 + khalf * 512 + ((ct * 32 + l31) << 2);
+    int keep;
+
+    int rkk[3];
+    auto refresh_rk = [&]() {   // opaque copies: keeps the epilogue addresses out of registers across the slab loop
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            rkk[i] = rowk[i] < 0 ? 0 : rowk[i];
+            asm volatile("" : "+v"(rkk[i]));
+        }
+    };
+    f32x16 xreg[3];   // block input x (fp32) at this lane's accumulator positions
+    auto init_acc = [&](f32x16 (&acc)[3], const float *bl, bool add_x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *reinterpret_cast<const float4 *>(bl + ct * 32 + 8 * q + 4 * khalf);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                acc[i][4 * q + 0] = bq.x + (add_x ? xreg[i][4 * q + 0] : 0.0f);
+                acc[i][4 * q + 1] = bq.y + (add_x ? xreg[i][4 * q + 1] : 0.0f);
+                acc[i][4 * q + 2] = bq.z + (add_x ? xreg[i][4 * q + 2] : 0.0f);
+                acc[i][4 * q + 3] = bq.w + (add_x ? xreg[i][4 * q + 3] : 0.0f);
+            }
+        }
+    };
+    // epilogue of one tile: ReLU + clamp, hi = rn16(v) to the HI row, the fp6 block [hi | 2^11 (v - hi)] under the scale
+    // 2^(exponent(max v) - 2) to the X / Y planes of group 2 ct + khalf, the scale byte to SC; keep_x: v is a block input
+    auto store_tile = [&](f32x16 a, int i, bool keep_x) {
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_fmed3f(a[r], 0.0f, 65504.0f);
+        if (keep_x) xreg[i] = v;
+        uint32_t pk[8];
+        f32x16 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            pk[r >> 1] = pack_pair<true>(f32x2{v[r], v[r + 1]});
+            const f32x2 u = unpack_pair<true>(pk[r >> 1]);
+            hi[r] = u[0]; hi[r + 1] = u[1];
+            lo[r] = (v[r] - u[0]) * 2048.0f; lo[r + 1] = (v[r + 1] - u[1]) * 2048.0f;
+        }
+        float m = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, v[r]);
+        int byte = (int)(__float_as_uint(m) >> 23) - 2;
+        byte = byte < 1 ? 1 : byte;
+        const u32x6 blk = mx_cvt6(hi, lo, __uint_as_float((uint32_t)byte << 23));
+        const bool live = rowk[i] >= 0;
+        if (live) {
+            const int rowb = Geo::HI_OFF + rkk[i] * CV_ROWB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = ct * 32 + 8 * q + 4 * khalf;
+                *reinterpret_cast<uint2 *>(smem + lds_addr(rowb, n0 >> 3) + ((n0 & 4) << 1)) = make_uint2(pk[2 * q], pk[2 * q + 1]);
+            }
+            const int g = 2 * ct + khalf;
+            *reinterpret_cast<uint4 *>(smem + Geo::X_OFF + g * Geo::XPLANE + (rkk[i] << 4)) = make_uint4(blk[0], blk[1], blk[2], blk[3]);
+            *reinterpret_cast<uint2 *>(smem + Geo::Y_OFF + g * Geo::YPLANE + (rkk[i] << 3)) = make_uint2(blk[4], blk[5]);
+            smem[Geo::S_OFF + khalf * Geo::SPLANE + (rkk[i] << 2) + ct] = (unsigned char)byte;
+        }
+    };
+    // the last layer: fp32 rows for the heads / the trunk dump, 16-byte chunk c of a row at c ^ (row & 31)
+    auto store_tile_f32 = [&](f32x16 a, int i) {
+        if (rowk[i] < 0) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 8 * ct + 2 * q + khalf;
+            *reinterpret_cast<float4 *>(smem + rkk[i] * Geo::F32_ROWB + ((c ^ (rkk[i] & 31)) << 4)) =
+                make_float4(fmaxf(a[4 * q + 0], 0.0f), fmaxf(a[4 * q + 1], 0.0f), fmaxf(a[4 * q + 2], 0.0f), fmaxf(a[4 * q + 3], 0.0f));
+        }
+    };
+
+    {   // first layer: conv3x3(14 -> 128) + BN + ReLU; the planes are exact in 16 bits, the weights are hi + lo (two fp16 MFMAs)
+        f32x16 acc[3];
+        init_acc(acc, b0, false);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
+            bf16x8 af[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int a = ((tapmask[i] >> t) & 1) ? Geo::PLANES_OFF + (natb[i] + shift * 32) : Geo::ZERO_OFF;
+                af[i] = *reinterpret_cast<const bf16x8 *>(smem + a + khalf * 16);
+            }
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    acc[i] = mfma_32x32x16<true>(wf[t][part], af[i], acc[i]);
+        }
+        refresh_rk();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) store_tile(acc[i], i, true);
+        __syncthreads();
+    }
+
+#define MX_OPERANDS(NAB, NKEY)                                                                                       \
+            : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]),                                                 \
+              [a0h0] "+v"(fa.a[0]), [a0h1] "+v"(fa.a[1]), [a0h2] "+v"(fa.a[2]), [w0] "+v"(fa.w),                      \
+              [a1h0] "+v"(fb.a[0]), [a1h1] "+v"(fb.a[1]), [a1h2] "+v"(fb.a[2]), [w1] "+v"(fb.w),                      \
+              [sb0] "+v"(sb[0]), [sb1] "+v"(sb[1]), [sb2] "+v"(sb[2]),                                                \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [ws] "=&v"(wsr), [keep] "=&s"(keep)                      \
+            : [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [key0] "v"(key[0]), [key1] "v"(key[1]),            \
+              [key2] "v"(key[2]), [nab0] "v"(NAB[0]), [nab1] "v"(NAB[1]), [nab2] "v"(NAB[2]), [nkey0] "v"(NKEY[0]),     \
+              [nkey1] "v"(NKEY[1]), [nkey2] "v"(NKEY[2]), [xr0] "v"(xr[0]), [xr1] "v"(xr[1]), [xr2] "v"(xr[2]),        \
+              [yr0] "v"(yr[0]), [yr1] "v"(yr[1]), [yr2] "v"(yr[2]), [vb] "v"(vb), [vy] "v"(vy), [vs] "v"(vs),          \
+              [vbn] "v"(vbn), [voff0] "v"(voff0), [voff1] "v"(voff1), [sbase] "s"(sbase), [ldst] "s"(ldst)
+#define MX_CLOBBERS "memory", "scc", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", \
+                    "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define MX_ARGS()                                                                                                    \
+            const int slot = ((unsigned)g & 3u) << Geo::SLAB_SHIFT;                                                  \
+            const int vb = vb0 + slot, vy = vy0 + slot, vs = vs0 + slot;                                             \
+            const int vbn = vb0 + ((((unsigned)g + 1u) & 3u) << Geo::SLAB_SHIFT);                                    \
+            const int gn = g + 3 < nslabs ? g + 3 : nslabs - 1;                                                      \
+            const unsigned char *sbase = wpk + (size_t)gn * Geo::SLAB_BYTES;                                         \
+            const int ldst = Geo::W_OFF + ((((unsigned)g + 3u) & 3u) << Geo::SLAB_SHIFT) + (wave_u << 10);
+#define MX_RUN(ASMSTR, NAB, NKEY)                                                                                    \
+        {                                                                                                            \
+            MX_ARGS()                                                                                                \
+            asm volatile(ASMSTR MX_OPERANDS(NAB, NKEY) : MX_CLOBBERS);                                               \
+            ++g;                                                                                                     \
+        }
+#define MX_RUNV(ASMSTR, NAB, NKEY)   /* the same + the wave-uniform skip mask; clobbers VCC */                        \
+        {                                                                                                            \
+            MX_ARGS()                                                                                                \
+            asm volatile(ASMSTR MX_OPERANDS(NAB, NKEY), [skipm] "s"(skipm) : MX_CLOBBERS, "vcc");                    \
+            ++g;                                                                                                     \
+        }
+
+    struct MxFrag { bf16x8 a[3], w; };
+    int g = 0;
+    int skipm;   // cell group 0 (waves 0..3): its first row tile skips the dy = -1 taps
+    asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cselect_b32 %0, 1, 0" : "=s"(skipm) : "s"(wave_u) : "scc");
+#pragma unroll 1
+    for (int layer = 0; layer < nlayers; ++layer) {
+        f32x16 acc[3];
+        init_acc(acc, bias + layer * 128, (layer & 1) != 0);
+        int ab[3], key[3], nab[3], nkey[3], xr[3], yr[3], nxr[3], nyr[3], t0, t1, t2, wsr;
+        int sb[3] = {0, 0, 0};
+        MxFrag fa, fb;
+        tap_addr(0, ab, key, xr, yr);
+        {   // the first slab's two fp16 operand sets (waited for by its steps A and B)
+            const int vb = vb0 + (((unsigned)g & 3u) << Geo::SLAB_SHIFT);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                fa.a[i] = *reinterpret_cast<const bf16x8 *>(smem + ab[i] + ((0 ^ key[i]) << 4));
+                fb.a[i] = *reinterpret_cast<const bf16x8 *>(smem + ab[i] + ((2 ^ key[i]) << 4));
+            }
+            fa.w = *reinterpret_cast<const bf16x8 *>(smem + vb);
+            fb.w = *reinterpret_cast<const bf16x8 *>(smem + vb + 4096);
+            asm volatile("" : "+v"(fa.a[0]), "+v"(fa.a[1]), "+v"(fa.a[2]), "+v"(fa.w), "+v"(fb.a[0]), "+v"(fb.a[1]), "+v"(fb.a[2]), "+v"(fb.w));
+        }
+        int tap = 0;
+#pragma unroll 1
+        for (; tap < 3; ++tap) {   // dy = -1: cell group 0 branches around the MFMAs of its all-rank-0 row tile
+            MX_RUNV(MX_SKIP0_ASM_Q0, ab, key)
+            MX_RUNV(MX_SKIP0_ASM_Q1, ab, key)
+            MX_RUNV(MX_SKIP0_ASM_Q2, ab, key)
+            tap_addr(tap + 1, nab, nkey, nxr, nyr);
+            MX_RUNV(MX_SKIP0_ASM_Q3, nab, nkey)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; xr[i] = nxr[i]; yr[i] = nyr[i]; }
+        }
+#pragma unroll 1
+        for (; tap < 9; ++tap) {
+            MX_RUN(MX_SLAB_ASM_Q0, ab, key)
+            MX_RUN(MX_SLAB_ASM_Q1, ab, key)
+            MX_RUN(MX_SLAB_ASM_Q2, ab, key)
+            tap_addr(tap + 1, nab, nkey, nxr, nyr);
+            MX_RUN(MX_SLAB_ASM_Q3, nab, nkey)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; xr[i] = nxr[i]; yr[i] = nyr[i]; }
+        }
+        // the last slab requested operands of a slab that does not exist: drain them, let the MFMAs retire, and make sure
+        // every wave is done reading the activations before anyone overwrites them in place
+        const bool last = layer + 1 == nlayers;
+        if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fp32 rows reach into the weight ring
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        __syncthreads();
+        refresh_rk();
+        if (last) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) store_tile_f32(acc[i], i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) store_tile(acc[i], i, (layer & 1) != 0);
+        }
+        __syncthreads();
+    }
+    if (clk && tid == 0) {
+        clk[blockIdx.x * 4 + 0] = clk_c0; clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
+        clk[blockIdx.x * 4 + 2] = clk_r0; clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (out) {   // trunk activations as fp32, 4 channels per thread and step
+        float4 *go = reinterpret_cast<float4 *>(out + (size_t)pos0 * 90 * 128);
+        for (int idx = tid; idx < nrows * 32; idx += Geo::THREADS) {
+            const int r = idx >> 5, c = idx & 31, k = lds_row_of(r);
+            go[idx] = *reinterpret_cast<const float4 *>(smem + k * Geo::F32_ROWB + ((c ^ (k & 31)) << 4));
+        }
+    }
+    if (head_out) {
+        const float *hw = reinterpret_cast<const float *>(smem + Geo::HEADW_OFF);
+        // one thread per board cell, all three head channels; chunks in a fixed order: a position's outputs do not depend on
+        // the row / workgroup it lands on
+        for (int r = tid; r < nrows; r += Geo::THREADS) {
+            const int k = lds_row_of(r);
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < 32; ++c) {
+                const float4 e = *reinterpret_cast<const float4 *>(smem + k * Geo::F32_ROWB + ((c ^ (k & 31)) << 4));
+                const float *w0_ = hw + c * 4, *w1_ = hw + 128 + c * 4, *w2_ = hw + 256 + c * 4;
+                acc0 += e.x * w0_[0] + e.y * w0_[1] + e.z * w0_[2] + e.w * w0_[3];
+                acc1 += e.x * w1_[0] + e.y * w1_[1] + e.z * w1_[2] + e.w * w1_[3];
+                acc2 += e.x * w2_[0] + e.y * w2_[1] + e.z * w2_[2] + e.w * w2_[3];
+            }
+            float *o = head_out + ((size_t)pos0 * 90 + r) * 3;
+            o[0] = fmaxf(acc0 + head_b[0], 0.f);
+            o[1] = fmaxf(acc1 + head_b[1], 0.f);
+            o[2] = fmaxf(acc2 + head_b[2], 0.f);
+        }
+    }
+}
+#undef MX_OPERANDS
+#undef MX_CLOBBERS
+#undef MX_ARGS
+#undef MX_RUN
+#undef MX_RUNV
+
+}  // namespace czconv

@@ -204,6 +204,67 @@ def to_tf_variables(module, global_step=None):
     return out
 
 
+MX_DEPTH_LIMIT = 8   # precision "strict": k_trunk_mx_c128 up to this many residual blocks, k_trunk_split_c128 beyond
+
+
+def _e2m3_codes(x):
+    """already-scaled values -> 6-bit E2M3 codes (sign, 2 exponent bits, 3 mantissa bits): round to nearest even, saturating
+    at +-7.5 — what v_cvt_scalef32_2xpk16_fp6_f32 does to the activations (tools/experiments/mx_probe_check.py)"""
+    a = x.abs().clamp(max=7.5)
+    e = torch.floor(torch.log2(a.clamp(min=1.0)))                  # 0, 1, 2: the binade; below 1 the format is subnormal
+    q = (torch.round(a / torch.exp2(e - 3)) * torch.exp2(e - 3)).clamp(max=7.5)   # torch.round: half to even
+    e = torch.floor(torch.log2(q.clamp(min=1.0)))                  # rounding may have carried into the next binade
+    normal = q >= 1.0
+    mant = torch.where(normal, (q / torch.exp2(e) - 1.0) * 8.0, q * 8.0).round().to(torch.int64)
+    ebits = torch.where(normal, e.to(torch.int64) + 1, torch.zeros_like(mant))
+    return (torch.signbit(x).to(torch.int64) << 5) | (ebits << 3) | mant
+
+
+def _pack_fp6(codes):
+    """[..., 32] six-bit codes -> [..., 24] uint8, slot i at bits 6 i .. 6 i + 5"""
+    c = codes.to(torch.int64)
+    words = torch.zeros(c.shape[:-1] + (3,), dtype=torch.int64, device=c.device)   # three 64-bit words hold 10 + 2/3 slots each
+    out = torch.zeros(c.shape[:-1] + (24,), dtype=torch.int64, device=c.device)
+    for i in range(32):
+        bit = 6 * i
+        byte, sh = bit // 8, bit % 8
+        v = c[..., i] << sh
+        out[..., byte] |= v & 255
+        if sh > 2:
+            out[..., byte + 1] |= (v >> 8) & 255
+    del words
+    return out.to(torch.uint8)
+
+
+def mx_pack_layer(w):
+    """Folded fp32 conv weights [128 co][128 ci][3][3] -> the 36 slabs of k_trunk_mx_c128 (include/cchess_hip.h:
+    cz_net_trunk_mx), uint8 [36][16384].  Per 32-input-channel quarter of a tap: fp16 w_hi in the strict engine's hi layout,
+    then per (co, half h) the fp6 block of the 16 channels c_j = 32 quarter + 8 (j / 4) + 4 h + j % 4: slot 2j = q6(2^11 w_lo),
+    slot 2j+1 = q6(w_hi) under the block scale 2^(exponent(amax) - 2); the E8M0 byte handed to the MFMA has the 2^-11 folded
+    in."""
+    dev = w.device
+    t = w.permute(2, 3, 1, 0).reshape(9, 4, 4, 8, FILTERS).permute(0, 1, 2, 4, 3).contiguous()    # [tap][quarter][ci8][co][ci%8]
+    hi16 = t.to(torch.float16)
+    hi_bytes = hi16.contiguous().view(torch.uint8).reshape(9, 4, 8192)
+    wq = w.permute(2, 3, 0, 1).reshape(9, FILTERS, 4, 4, 2, 4)              # [tap][co][quarter][q][h][i], ci = 32 Q + 8 q + 4 h + i
+    whi = wq.to(torch.float16).float()
+    wlo = (wq - whi).to(torch.float16).float() * 2048.0
+    whi = whi.permute(0, 2, 4, 1, 3, 5).reshape(9, 4, 2, FILTERS, 16)        # [tap][quarter][h][co][j = 4 q + i]
+    wlo = wlo.permute(0, 2, 4, 1, 3, 5).reshape(9, 4, 2, FILTERS, 16)
+    amax = torch.maximum(whi.abs().amax(-1), wlo.abs().amax(-1))
+    _, e = torch.frexp(amax.clamp(min=1e-30))
+    byte = (e + 124).clamp(min=12, max=254)                                  # biased exponent(amax) - 2
+    sc = torch.exp2((byte - 127).float()).unsqueeze(-1)
+    slots = torch.stack([_e2m3_codes(wlo / sc), _e2m3_codes(whi / sc)], dim=-1).reshape(9, 4, 2, FILTERS, 32)
+    blk = _pack_fp6(slots)                                                   # [9][4][2][128][24]
+    xb = blk[..., :16].reshape(9, 4, 4096)
+    yb = blk[..., 16:].reshape(9, 4, 2048)
+    sdw = torch.zeros((9, 4, 2, FILTERS, 4), dtype=torch.uint8, device=dev)
+    sdw[..., 0] = (byte - 11).to(torch.uint8)
+    pad = torch.zeros((9, 4, 1024), dtype=torch.uint8, device=dev)
+    return torch.cat([hi_bytes, xb, yb, sdw.reshape(9, 4, 1024), pad], dim=-1).reshape(36, 16384).contiguous()
+
+
 class PolicyValueNet:
     """Inference engine around PolicyValueModule: BN folded, tower in `dtype` (bf16/fp16/fp32, fp32
     accumulate on MFMA), heads in fp32.  forward_device() is the device-to-device path the search
@@ -225,6 +286,18 @@ class PolicyValueNet:
         16-bit engine's rate.  hip backend only."""
         self.device = torch.device(device)
         self.dtype = dtype
+        # split: False | True (= "x3": k_trunk_split_c128, three MFMAs per product) | "mx" (k_trunk_mx_c128: fp16 hi halves +
+        # both cross terms on one block-scaled fp6 MFMA, 1.5 MFMA-equivalents per product, fp16 only) | "strict" (the cheaper
+        # of the two that holds 1e-3 with a factor of two to spare at this depth: mx up to MX_DEPTH_LIMIT blocks)
+        if split == "strict":
+            split = "mx" if (module.res_block_nums if module is not None else res_block_nums) <= MX_DEPTH_LIMIT and dtype == torch.float16 else True
+        if split == "x3":
+            split = True
+        if split not in (False, True, "mx"):
+            raise ValueError("split must be False, True / 'x3', 'mx' or 'strict'")
+        self.mx = split == "mx"
+        if self.mx and dtype != torch.float16:
+            raise ValueError("the mx engine (k_trunk_mx_c128) computes with fp16 hi halves: dtype must be torch.float16")
         self.split = bool(split)
         self.module = (module or PolicyValueModule(res_block_nums, seed)).to(self.device)
         self.res_block_nums = self.module.res_block_nums
@@ -272,6 +345,9 @@ class PolicyValueNet:
             layers = [x for blk in self.hip_blocks for x in blk]
             self.hip_tower_w = torch.stack([w for w, _ in layers]).contiguous() if layers else torch.zeros((0,), dtype=hdt, device=self.device)
             self.hip_tower_b = torch.stack([b for _, b in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.float32, device=self.device)
+            if self.mx:
+                sl = [mx_pack_layer(cb.folded()[0]) for blk in m.blocks for cb in blk]
+                self.hip_mx_w = torch.stack(sl).contiguous() if sl else torch.zeros((0,), dtype=torch.uint8, device=self.device)
             if self.split:
                 # strict engine: w = hi + lo, two values of hdt.  Tower layer: [tap][32-channel quarter of the tap = one 16 KB
                 # slab][hi, lo][ci/8 within the quarter][co][ci%8]; first layer: [tap][hi, lo][ci/8][co][ci%8]
@@ -284,7 +360,7 @@ class PolicyValueNet:
                     t = w.permute(2, 3, 1, 0).reshape(9, 4, 4, 8, FILTERS).permute(0, 1, 2, 4, 3)   # [tap][quarter][ci8][co][ci%8]
                     hi, lo = halves(t)
                     return torch.stack([hi, lo], dim=2).contiguous()                                 # [9][4][2][4][128][8]
-                sl = [split_pack(cb) for blk in m.blocks for cb in blk]
+                sl = [] if self.mx else [split_pack(cb) for blk in m.blocks for cb in blk]
                 self.hip_split_w = torch.stack(sl).contiguous() if sl else torch.zeros((0,), dtype=hdt, device=self.device)
                 hi0, lo0 = halves(w0p.reshape(9, 2, 8, FILTERS).permute(0, 1, 3, 2))
                 self.hip_split_w0 = torch.stack([hi0, lo0], dim=1).contiguous()                      # [9][2][2][128][8]
@@ -363,7 +439,13 @@ class PolicyValueNet:
         if self.conv_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if self.split:
+        if self.mx:
+            check(lib().cz_net_trunk_mx(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_split_w0.data_ptr()),
+                                        C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_mx_w.data_ptr()),
+                                        C.c_void_p(self.hip_tower_b.data_ptr()), C.c_void_p(z.data_ptr()) if trunk else None,
+                                        C.c_void_p(self.head_w_rows.data_ptr()), C.c_void_p(self.head_b.data_ptr()),
+                                        None if trunk else C.c_void_p(z.data_ptr()), B, self.res_block_nums), "cz_net_trunk_mx")
+        elif self.split:
             check(lib().cz_net_trunk_split(self._hip_ctx().h, C.c_void_p(p16.data_ptr()), C.c_void_p(self.hip_split_w0.data_ptr()),
                                            C.c_void_p(self.hip_b0.data_ptr()), C.c_void_p(self.hip_split_w.data_ptr()),
                                            C.c_void_p(self.hip_tower_b.data_ptr()), C.c_void_p(z.data_ptr()) if trunk else None,

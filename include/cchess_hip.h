@@ -351,6 +351,25 @@ int cz_net_trunk_split(cz_ctx *, const void *planes16, const void *w0, const flo
                        const float *bias, float *trunk_out, const float *head_w, const float *head_b,
                        float *head_out, int B, int nblocks, int halves_dtype);
 
+/* The strict-precision trunk at half the matrix work (round 5; k_trunk_mx_c128, csrc/cz_trunk_mx.h): a*w = a_hi*w_hi on fp16
+ * MFMAs + BOTH cross terms (a_hi*w_lo + a_lo*w_hi) of 32 input channels on ONE block-scaled fp6 MFMA
+ * (v_mfma_scale_f32_32x32x64_f8f6f4, E2M3 operands, one E8M0 scale per cell / output channel and 16 input channels):
+ * 1.5 instead of 3 fp16-MFMA-equivalents per product, the cross terms to 4 significant bits per operand (~2^-16 of a product).
+ * Replaces the same fp32 sess.run (policy_value_network.py:202-214); |dlogit|, |dvalue| <= 1e-3 against it on trained-like
+ * weights up to 8 blocks with a factor of two to spare (tests/test_net.py, tests/mxemu.py is its CPU emulation); deeper nets
+ * keep cz_net_trunk_split.
+ *   planes16 : [B][90][16] fp16; w0 / b0 : as cz_net_trunk_split with CZ_F16 (the first layer is two fp16 MFMAs per tap)
+ *   wpk  : [2*nblocks][9 taps][4 quarters][16384 bytes]: per 32-input-channel quarter of a tap (one LDS-DMA slab)
+ *          [fp16 w_hi: 4 = ci/8][128 co][8] (8192 B) [fp6 blocks, first 16 bytes: 2 halves][128 co][16] (4096 B)
+ *          [last 8 bytes: 2][128 co][8] (2048 B) [E8M0 scale in byte 0 of a dword: 2][128 co] (1024 B) [1024 B unused];
+ *          block (co, half h) = 32 six-bit slots, slot 2j = q6(2^11 w_lo[c_j]), slot 2j+1 = q6(w_hi[c_j]),
+ *          c_j = 32 quarter + 8 (j / 4) + 4 h + j % 4, under 2^(exponent(max |w_hi|) - 2); the stored byte is that exponent
+ *          - 11 (cchess_zero_amd/net.py: mx_pack_layer); 16-byte aligned.  bias [2*nblocks][128] f32, BN folded.
+ *   trunk_out : [B][90][128] FLOAT32 or NULL; head_w / head_b / head_out as cz_net_trunk_bf16. */
+int cz_net_trunk_mx(cz_ctx *, const void *planes16, const void *w0, const float *b0, const void *wpk,
+                    const float *bias, float *trunk_out, const float *head_w, const float *head_b,
+                    float *head_out, int B, int nblocks);
+
 /* Measurement hook for bench.py (roofline.effective_clock_GHz): while buf_dev is set, every workgroup w of the following
  * cz_net_trunk_* launches (grids up to max_workgroups) writes buf_dev[4w .. 4w+3] = {shader-clock cycle counter at its start,
  * at the end of its last layer, 100 MHz reference clock at the same two points}: cycles / (ticks * 10 ns) is the clock the

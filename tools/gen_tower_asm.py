@@ -4,6 +4,8 @@
   cchess_zero_amd/csrc/cz_tower_slab_asm.inc   k_tower8_c128 (cz_conv_kernel.h): 4 positions / 8 waves, 16-bit operands
   cchess_zero_amd/csrc/cz_trunk_split_asm.inc  k_trunk_split_c128 (cz_trunk_split.h): 2 positions / 8 waves, every
                                                operand split into two 16-bit halves, three MFMAs per product
+  cchess_zero_amd/csrc/cz_trunk_mx_asm.inc     k_trunk_mx_c128 (cz_trunk_mx.h): the same tiling, fp16 hi halves + both cross
+                                               terms on one block-scaled fp6 MFMA (1.5 MFMA-equivalents per product)
 
 k_tower8_c128: one slab = 64 input channels of one 3x3 tap = 4 k-steps x 6 v_mfma_f32_32x32x16 per wave; two fragment
 sets; each k-step first waits for its own set (the partner wave on the SIMD covers the wait), then interleaves its 6
@@ -113,6 +115,65 @@ def slabX(hs, LO):
 
 XS_LO_OFF = 181 * 256   # cz_trunk_split.h: XSGeo::LO_OFF (180 activation rows + the zero row)
 
+# ---- k_trunk_mx_c128 (cz_trunk_mx.h): a*w = a_hi*w_hi on two fp16 MFMAs per 32 input channels + BOTH cross terms of those 32
+# channels on ONE block-scaled fp6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, 8 passes): 9 MFMAs per slab and wave instead of 18.
+MX_XPLANE, MX_YPLANE = 224 * 16, 224 * 8      # MXGeo: one plane per 16-channel group, 224 entries (180 cells + the zero aliases)
+MX_Y_OFF, MX_S_OFF = 8 * MX_XPLANE, 8 * MX_XPLANE + 8 * MX_YPLANE
+MX_AX = ["v[232:237]", "v[238:243]", "v[244:249]"]   # fp6 activation blocks of the three cell tiles: loaded and consumed inside
+MX_WX = "v[250:255]"                                  # one slab body, so they are hard registers (the body clobbers v232..v255)
+
+
+def slabMX(hs):
+    """One 16 KB slab = 32 input channels of one tap: [fp16 hi: 2 k-steps x 2 halves x 128 co x 8][fp6 blocks: X 2 x 128 x 16 B,
+    Y 2 x 128 x 8 B][E8M0 scale dwords 2 x 128].  Three steps of three MFMAs; operands are requested TWO steps ahead:
+      A (k-step 0, set a0*/w0)  waits for its set (the next step's 4 reads may be in flight), requests this slab's fp6 set
+      B (k-step 1, set a1*/w1)  vmcnt(2) + barrier first (slab g+1 published, slab g-1's buffer free), requests the NEXT slab's
+                                set A (after the fourth slab of a tap: at the next tap's addresses)
+      C (fp6, hard registers)   requests the next slab's set B, issues the wave's 2 DMA pieces of slab g+3."""
+    nab, nkey = ("nab", "nkey") if hs == 3 else ("ab", "key")
+    ca = ((hs + 1) % 4) * 4
+    f = lambda i, w, a: "v_mfma_f32_32x32x16_f16 %%[c%d], %%[%s], %%[%s%d], %%[c%d]" % (i, w, a, i, i)
+    mx = lambda i: ("v_mfma_scale_f32_32x32x64_f8f6f4 %%[c%d], %s, %s, %%[c%d], %%[ws], %%[sb%d] op_sel:[0,%d,0] op_sel_hi:[0,%d,0] cbsz:2 blgp:2"
+                    % (i, MX_WX, MX_AX[i], i, i, hs & 1, hs >> 1))
+    sub = lambda r, lo, hi: "v[%d:%d]" % (int(r[2:].split(":")[0]) + lo, int(r[2:].split(":")[0]) + hi)
+    xo, yo = hs * 2 * MX_XPLANE, MX_Y_OFF + hs * 2 * MX_YPLANE
+    L = ["s_mov_b32 %[keep], m0"]
+    # step A
+    L += ["s_waitcnt lgkmcnt(4)", f(0, "w0", "a0h")]
+    L += ["ds_read_b128 %s, %%[xr0] offset:%d" % (sub(MX_AX[0], 0, 3), xo), "ds_read_b64 %s, %%[yr0] offset:%d" % (sub(MX_AX[0], 4, 5), yo),
+          "ds_read_b128 %s, %%[xr1] offset:%d" % (sub(MX_AX[1], 0, 3), xo), "ds_read_b64 %s, %%[yr1] offset:%d" % (sub(MX_AX[1], 4, 5), yo)]
+    if hs == 0:
+        L += ["v_lshrrev_b32 %[t0], 1, %[yr0]", "v_lshrrev_b32 %[t1], 1, %[yr1]", "v_lshrrev_b32 %[t2], 1, %[yr2]"]
+    L += [f(1, "w0", "a0h")]
+    L += ["ds_read_b128 %s, %%[xr2] offset:%d" % (sub(MX_AX[2], 0, 3), xo), "ds_read_b64 %s, %%[yr2] offset:%d" % (sub(MX_AX[2], 4, 5), yo)]
+    nc = 9
+    if hs == 0:   # the tap's activation scales: one dword per cell = the four 32-channel quarters' E8M0 bytes of this lane's half
+        L += ["ds_read_b32 %%[sb%d], %%[t%d] offset:%d" % (i, i, MX_S_OFF) for i in range(3)]
+        nc = 12
+    L += [f(2, "w0", "a0h")]
+    L += ["ds_read_b128 %s, %%[vb] offset:8192" % sub(MX_WX, 0, 3), "ds_read_b64 %s, %%[vy]" % sub(MX_WX, 4, 5), "ds_read_b32 %[ws], %[vs]"]
+    # step B
+    L += ["s_waitcnt vmcnt(2)", "s_barrier", "s_waitcnt lgkmcnt(%d)" % nc]
+    L += [f(0, "w1", "a1h")]
+    L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca, nkey, i) for i in range(3)]
+    L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(3)]
+    L += [f(1, "w1", "a1h")]
+    L += ["ds_read_b128 %[a0h0], %[t0]", "ds_read_b128 %[a0h1], %[t1]"]
+    L += [f(2, "w1", "a1h")]
+    L += ["ds_read_b128 %[a0h2], %[t2]", "ds_read_b128 %[w0], %[vbn]"]
+    # step C
+    L += ["s_waitcnt lgkmcnt(4)", mx(0)]
+    L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca + 2, nkey, i) for i in range(3)]
+    L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(3)]
+    L += ["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]
+    L += [mx(1)]
+    L += ["ds_read_b128 %[a1h0], %[t0]", "ds_read_b128 %[a1h1], %[t1]"]
+    L += ["s_add_u32 m0, %[ldst], 0x2000", "s_nop 0", "global_load_lds_dwordx4 %[voff1], %[sbase]"]
+    L += [mx(2)]
+    L += ["ds_read_b128 %[a1h2], %[t2]", "ds_read_b128 %[w1], %[vbn] offset:4096"]
+    L += ["s_mov_b32 m0, %[keep]"]
+    return L
+
 
 def emit(name, lines):
     out = ["#define %s \\" % name]
@@ -171,7 +232,16 @@ def main():
         b = branchy(slabX(hs, XS_LO_OFF), ("%[c0],",))
         txt += emit("XS_SKIP0_ASM_Q%d" % hs, b) + "\n" + emit("XSF_SKIP0_ASM_Q%d" % hs, f16(b)) + "\n"
     open(os.path.join(csrc, "cz_trunk_split_asm.inc"), "w").write(txt)
-    print("wrote cz_tower_slab_asm.inc (%d instructions per slab), cz_trunk_split_asm.inc (%d)" % (len(slab8(0)), len(slabX(0, XS_LO_OFF))))
+    txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
+    txt += "// k_trunk_mx_c128: 8 waves / 2 positions, 6 fp16 MFMAs + 3 block-scaled fp6 MFMAs per slab and wave\n"
+    for hs in range(4):
+        txt += emit("MX_SLAB_ASM_Q%d" % hs, slabMX(hs)) + "\n"
+    txt += "// the same with the first-row-tile MFMAs (3 of 9) behind a scalar branch (dy = -1 taps, cell group 0)\n"
+    for hs in range(4):
+        txt += emit("MX_SKIP0_ASM_Q%d" % hs, branchy(slabMX(hs), ("%[c0],",))) + "\n"
+    open(os.path.join(csrc, "cz_trunk_mx_asm.inc"), "w").write(txt)
+    print("wrote cz_tower_slab_asm.inc (%d instructions per slab), cz_trunk_split_asm.inc (%d), cz_trunk_mx_asm.inc (%d)" %
+          (len(slab8(0)), len(slabX(0, XS_LO_OFF)), len(slabMX(1))))
 
 
 if __name__ == "__main__":
