@@ -39,7 +39,10 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp16x2": 2500.0, "bf16x2": 2500.0}  # dense peaks, same guide (x2: the strict engine, 16-bit MFMAs)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp16x2": 2500.0, "bf16x2": 2500.0, "mx6": 2500.0}  # dense peaks, same guide (x2 / mx6: the strict engines; algorithmic flops of the fp32 graph against the 16-bit MFMA peak)
+MX_DEPTH_LIMIT = 8           # cchess_zero_amd.net.MX_DEPTH_LIMIT: precision "strict" = mx6 up to this depth, fp16x2 beyond
+TRUNK_KERNEL = {"fp16": "k_tower8_c128", "bf16": "k_tower8_c128", "fp16x2": "k_trunk_split_c128", "bf16x2": "k_trunk_split_c128", "mx6": "k_trunk_mx_c128"}
+TRAFFIC_FILE = {"k_tower8_c128": "pmc_traffic.json", "k_trunk_split_c128": "pmc_traffic_strict.json", "k_trunk_mx_c128": "pmc_traffic_mx.json"}
 
 START = np.array([3, 5, 4, 2, 1, 2, 4, 5, 3] + [0] * 9 + [0, 7, 0, 0, 0, 0, 0, 7, 0] + [6, 0, 6, 0, 6, 0, 6, 0, 6] + [0] * 18 +
                  [13, 0, 13, 0, 13, 0, 13, 0, 13] + [0, 14, 0, 0, 0, 0, 0, 14, 0] + [0] * 9 + [10, 12, 11, 9, 8, 9, 11, 12, 10], np.uint8)
@@ -106,12 +109,30 @@ def _cpu_workers(specs):
     return out
 
 
+def reference_python_now(timeout=90):
+    """SURVEY 8(d) items 1-2 when the unmodified reference is importable (this container; never on the GPU box): its own
+    MCTS_tree.main with a constant-time forward, 50 and 400 playouts, one core — tools/time_reference.py --json in a subprocess."""
+    if not os.path.exists("/root/reference/main.py"):
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_reference.py"), "--json"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=timeout)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def cpu_baseline(blocks, seconds_target=12.0):
     """The CPU port timed on this host, single core and all cores: C oracle search + fp32 torch-CPU
     net, a bounded sample of the same workload family.  Test infrastructure used as the *baseline being measured*, never
     as the product path.  `value` is the all-core figure."""
     cores = os.cpu_count() or 1
-    out = {"unit": "sims/s", "kind": "port", "reference_python": REFERENCE_PYTHON}
+    out = {"unit": "sims/s", "kind": "port", "reference_python": dict(REFERENCE_PYTHON, measured_in_this_run=False)}
+    live = reference_python_now()
+    if live and "error" not in live:
+        out["reference_python"] = dict(live, measured_in_this_run=True, static_record=REFERENCE_PYTHON)
+    elif live:
+        out["reference_python"]["live_attempt"] = live
     # a container may see every host CPU and still be throttled to a few of them by its cgroup CPU quota: report it, and do
     # not oversubscribe it (measured on the GPU box: 256 visible CPUs, all-core throughput of ~4 cores)
     quota = None
@@ -192,6 +213,93 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
                                     "note": "issue-bound (VALU: the per-kind generation, the ordering by square, one LDS write per move), not bandwidth-bound: see DESIGN.md 4.6b"}}
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full):
+    """The ONE line rank 0 prints: every number the bench contract, the judge's roofline check and the 1e-3 contract need, under
+    8 KB (the driver's record keeps the top-level keys and an 8 KB tail); the complete record — notes, telemetry, clock probe,
+    per-kernel explanations — goes to the side file named in `detail_file` (tools/jline.py reads either)."""
+    out = _pick(full, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data", "engine", "value_source"])
+    st = full.get("strict_engine")
+    if st:
+        se = _pick(st, ["dtype", "kernel", "value", "unit", "ms_per_step", "steps", "meets_target_1e6_sims_per_s_per_gpu"])
+        r = st.get("roofline") or {}
+        se.update({"frac": r.get("frac"), "achieved_TFLOPs": r.get("achieved"), "us_per_launch": r.get("us_per_launch"), "traffic": r.get("traffic")})
+        ne = st.get("net_error") or {}
+        for k in ("as_benchmarked_glorot", "trained_like"):
+            if k in ne:
+                se["dlogit_" + k] = ne[k].get("dlogit")
+                se["dvalue_" + k] = ne[k].get("dvalue")
+        se["meets_1e-3_abs_logit_and_value"] = ne.get("meets_1e-3_abs_logit_and_value")
+        out["strict_engine"] = se
+    else:
+        out["strict_engine"] = None
+    for k in ("steady_state", "contract_steps"):
+        out[k] = _pick(full.get(k) or {}, ["steps", "seconds", "value", "ms_per_step", "simulations_per_net_row", "per_rank_sims_per_s"]) or None
+    if st and full.get("n_gpus", 1) > 1:
+        out["strict_engine"]["per_rank_sims_per_s"] = st.get("per_rank_sims_per_s")
+    c = full.get("config") or {}
+    out["config"] = _pick(c, ["workload", "games_per_gpu", "playout", "res_block_nums", "world_size", "dist_backend", "per_rank_sims_per_s",
+                              "efficiency_vs_min_rank", "efficiency_vs_max_rank", "per_rank_spread", "per_rank_busy_seconds", "rank_cpus", "search_threads", "simulations_per_net_row", "net_rows_per_step",
+                              "terminal_extra", "record_gather", "trees_with_error_status", "mean_leaf_depth", "node_pool_GB"])
+    if c.get("selfplay"):
+        out["config"]["selfplay"] = _pick(c["selfplay"], ["games_finished", "records", "dropped_records", "stalled_games", "timed_gather", "gathers",
+                                                          "gathered_records", "pending_after_flush"])
+    r = full.get("roofline") or {}
+    ro = _pick(r, ["bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "launches_timed", "flops_per_launch", "effective_clock_GHz",
+                   "clock_scaled_peak", "frac_of_clock_scaled_peak", "mfma_flops_issued_per_algorithmic_flop", "power_W"])
+    ro["kernel"] = str(r.get("kernel", "")).split(" (")[0]
+    mp = r.get("mfma_peak_measured") or {}
+    if "dense_random_operands" in mp:
+        ro["mfma_peak_measured_TFLOPs"] = {k: mp[k]["tflops"] for k in ("dense_random_operands", "half_zero_operands") if k in mp}
+    out["roofline"] = ro
+    t = full.get("roofline_tree")
+    out["roofline_tree"] = (dict(_pick(t, ["bound", "achieved", "peak", "unit", "frac", "traffic", "us_select", "us_expand_backup"]),
+                                 kernel="k_select + k_expand_backup") if t else None)
+    rr = full.get("roofline_rules")
+    if rr and "achieved" in rr:
+        o = dict(_pick(rr, ["bound", "achieved", "peak", "unit", "frac", "traffic", "positions", "positions_per_s", "us_per_launch"]), kernel="k_movegen_mask")
+        ol = rr.get("ordered_list_kernel")
+        if ol:
+            o["ordered_list_kernel"] = dict(_pick(ol, ["positions_per_s", "frac", "us_per_launch"]), kernel="k_movegen_list<MASK>")
+        out["roofline_rules"] = o
+    else:
+        out["roofline_rules"] = rr
+    ne = full.get("net_error")
+    if ne and "as_benchmarked_glorot" in ne:
+        out["net_error"] = {k: _pick(ne[k], ["dlogit", "dvalue", "max_abs_logit", "argmax_agree"]) for k in ("as_benchmarked_glorot", "trained_like") if k in ne}
+        out["net_error"].update(_pick(ne, ["meets_1e-3_abs_logit_and_value_as_benchmarked", "meets_1e-3_abs_logit_and_value_trained_like"]))
+    else:
+        out["net_error"] = ne
+    cb = full.get("cpu_baseline")
+    if cb:
+        o = _pick(cb, ["value", "unit", "cores", "kind", "sample", "visible_cpus", "cgroup_cpu_quota", "error"])
+        if cb.get("single_core"):
+            o["single_core_value"] = cb["single_core"].get("value")
+        rp = cb.get("reference_python") or {}
+        o["reference_python"] = _pick(rp, ["measured_in_this_run", "search_only_sims_per_s_per_core", "search_only_400_playouts_sims_per_s",
+                                           "end_to_end_2block_sims_per_s", "end_to_end_7block_sims_per_s"])
+        out["cpu_baseline"] = o
+    else:
+        out["cpu_baseline"] = None
+    return out
+
+
+def write_detail(full, tag):
+    """the complete record next to the line: gpurun_out/ when it exists (it is what travels back from a GPU box), else the cwd"""
+    d = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.getcwd()
+    path = os.path.join(d, "bench_detail_%s.json" % tag)
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        return "not written: %r" % (e,)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a bare shell: start the N ranks through torch.distributed.run."""
     s = socket.socket()
@@ -213,11 +321,11 @@ def main():
     ap.add_argument("--games", type=int, default=8192, help="game trees per GPU")
     ap.add_argument("--playout", type=int, default=1600)
     ap.add_argument("--blocks", type=int, default=7)
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp16x2", "bf16x2", "strict"],
-                    help="MFMA operand type of the tower (fp32 accumulate).  fp16 (default): the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output).  fp16x2 (= strict) / bf16x2: the STRICT engine, every weight and stored activation as hi + lo halves of that type and three MFMAs per product (k_trunk_split_c128): north_star's 1e-3 against fp32 also on trained-like weights and at 19 blocks, at a third of the rate")
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp16x2", "bf16x2", "mx6", "strict"],
+                    help="engine of the tower (fp32 accumulate).  fp16 (default): one fp16 per operand (k_tower8_c128), the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output).  The STRICT engines keep north_star's 1e-3 against fp32 on trained-like weights: mx6 = fp16 hi halves + both cross terms of the hi + lo split on one block-scaled fp6 MFMA (k_trunk_mx_c128, 1.5 MFMA-equivalents per product; holds 1e-3 with a factor of two to spare up to 8 blocks); fp16x2 / bf16x2 = hi + lo halves of that type, three MFMAs per product (k_trunk_split_c128; also 19 blocks); strict = mx6 up to 8 blocks, fp16x2 beyond (the default of policy_value_network() and main.py)")
     ap.add_argument("--age-steps", type=int, default=800, help="untimed lock-steps BEFORE --warmup that bring every tree to a representative phase of its search: each tree's first search is cut at its own threshold (uniform in [8, age-steps] simulations), so when the timed region starts the trees are spread over the phases of a playout-long search on subtrees kept from a previous ply — the state of a long run — instead of all standing 25 simulations into a fresh search")
     ap.add_argument("--steady-steps", type=int, default=2000, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
-    ap.add_argument("--strict-steps", type=int, default=240, help="lock-steps of a third timed region in which the SAME trees are searched with the strict engine (k_trunk_split_c128, fp16 hi + lo halves, 1e-3 of fp32 on every weight set) — the strict_engine block of the output; 0 = off; ignored when --dtype already names a strict engine")
+    ap.add_argument("--strict-steps", type=int, default=240, help="lock-steps of a third timed region in which the SAME trees are searched with the strict engine of this depth (k_trunk_mx_c128 up to 8 blocks, k_trunk_split_c128 beyond: 1e-3 of fp32 on trained-like weights) — the strict_engine block of the output; 0 = off; ignored when --dtype already names a strict engine")
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
@@ -239,8 +347,9 @@ def main():
     ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
     args = ap.parse_args()
     if args.dtype == "strict":
-        args.dtype = "fp16x2"
-    split = args.dtype.endswith("x2")
+        args.dtype = "mx6" if args.blocks <= MX_DEPTH_LIMIT else "fp16x2"
+    mx = args.dtype == "mx6"
+    split = args.dtype.endswith("x2") or mx
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -282,17 +391,17 @@ def main():
         torch.set_num_threads(max(1, min(4, len(cpus) if cpus else 2)))
 
     G, playout = args.games, args.playout
-    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp16x2": torch.float16, "bf16x2": torch.bfloat16}[args.dtype]
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp16x2": torch.float16, "bf16x2": torch.bfloat16, "mx6": torch.float16}[args.dtype]
     cap = args.nodes_per_tree or default_nodes_per_tree(playout)
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
     # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
-    fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16", "fp16x2", "bf16x2")
+    fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16", "fp16x2", "bf16x2", "mx6")
     K = max(1, args.search_threads)
     if args.selfplay and K != 1:
         ap.error("--selfplay runs one simulation in flight per tree")
     eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx, width=K)
-    net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split=split)
+    net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split="mx" if mx else split)
     if args.full_policy_fc:
         net.fuse_policy_fc = False
     fused_fc = net.fused_search and K == 1
@@ -466,6 +575,8 @@ def main():
     else:
         run(8, False)
 
+    busy_log = []   # per timed region: seconds of this rank's own work (the barrier-bracketed time is the slowest rank's)
+
     def timed_region(nsteps):
         """barrier + synchronize, EXACTLY nsteps lock-steps, synchronize + barrier: -> (max-over-ranks seconds, this rank's
         seconds, this rank's completed simulations, net rows of this rank [compact mode: measured])."""
@@ -481,11 +592,13 @@ def main():
         else:
             run(nsteps, True)
         torch.cuda.synchronize()
+        busy = time.perf_counter() - t0      # this rank's own work, before it waits for the others
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         dtm = PL.max_over_ranks(mine, cdev) if dist_on else mine
+        busy_log.append(busy)
         rows = float(G * K) * nsteps
         rpl = float(G * K)
         if compact:
@@ -528,8 +641,8 @@ def main():
     strict_leg = None
     if args.strict_steps > 0 and fused and not split and not sp and net.backend == "hip":
         # the same trees, the same loop, the strict engine: weights shared with the benchmarked net
-        net_s = PolicyValueNet(args.blocks, dev, torch.float16, backend="hip", ctx=ctx, split=True, module=net.module)
-        if tdt != torch.float16:   # the planes buffer is written in the benchmarked engine's type: the strict leg needs fp16 planes
+        net_s = PolicyValueNet(args.blocks, dev, torch.float16, backend="hip", ctx=ctx, split="strict", module=net.module)
+        if tdt != torch.float16:   # the planes buffer is written in the benchmarked engine's type: a bf16 run gets bf16 halves
             net_s = PolicyValueNet(args.blocks, dev, tdt, backend="hip", ctx=ctx, split=True, module=net.module)
         net_s.fuse_policy_fc = net.fuse_policy_fc
         cur.update(net=net_s, conv_ev=[], ev=[])
@@ -560,17 +673,28 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed
     # rocprofv3 --pmc measurement of the same launch shape is attached when the configuration matches.
-    tower_kernel = "k_trunk_split_c128" if split else "k_tower8_c128"
-    traffic, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_strict.json" if split else "pmc_traffic.json")))
-        want = {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype}
-        if ({k: tj["config"].get(k) for k in want} == want and bool(tj["config"].get("compact", False)) == bool(compact)
-                and args.backend in ("auto", "hip") and tj["kernel"] == tower_kernel):
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_src = "profiles/pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; algorithmic bytes %d)" % ("_strict" if split else "", tj["algorithmic_bytes_per_launch"])
-    except Exception:
-        pass
+    tower_kernel = TRUNK_KERNEL.get(args.dtype, "k_tower8_c128")
+
+    def pmc_traffic(kernel, dtype_name):
+        """-> (bytes per launch or None, where from / why not): profiles/pmc_traffic*.json holds the rocprofv3 --pmc measurement
+        of one engine at one configuration (tools/summarize_profile.py writes kernel name prefixes: "k_tower8", "k_trunk_split")"""
+        f = TRAFFIC_FILE.get(kernel)
+        if not f or args.backend not in ("auto", "hip"):
+            return None, "no committed PMC measurement for this engine"
+        path = os.path.join(ROOT, "profiles", f)
+        try:
+            tj = json.load(open(path))
+        except (OSError, ValueError) as e:
+            return None, "profiles/%s unreadable: %r" % (f, e)
+        want = {"B": G, "res_block_nums": args.blocks, "dtype": dtype_name}
+        have = {k: tj.get("config", {}).get(k) for k in want}
+        if have != want or bool(tj["config"].get("compact", False)) != bool(compact):
+            return None, "profiles/%s was measured at %s, this run is %s" % (f, have, want)
+        if not kernel.startswith(str(tj.get("kernel"))):
+            return None, "profiles/%s describes kernel %r, not %s" % (f, tj.get("kernel"), kernel)
+        return tj["traffic_bytes_per_launch"], ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
+                                                "correction; algorithmic bytes %d)" % (f, tj["algorithmic_bytes_per_launch"]))
+    traffic, traffic_src = pmc_traffic(tower_kernel, args.dtype)
     st, nodes, sims, depth = eng.status()
     bad = int((st & ~8).ne(0).sum().item())
     st_bits = {name: int(((st & bit) != 0).sum().item()) for name, bit in
@@ -589,6 +713,16 @@ def main():
         tot = PL.sum_over_ranks([sims_, rows_], cdev)
         return tot[0], tot[1], PL.per_rank(float(sims_) / mine_dt, cdev)
     total_sims, total_rows, per_rank = totals((dt, my_dt, my_sims, my_rows, rows_per_launch))
+    # how evenly the ranks ran (N > 1): each rank's simulations over ITS OWN busy time of the headline leg (before the closing
+    # barrier), the spread of those rates, and the whole-job value against N copies of the slowest / the fastest rank
+    head_leg = 1 if (steady is not None and len(busy_log) > 1) else 0
+    head_sims = steady[2] if head_leg else my_sims
+    own_rate = PL.per_rank(float(head_sims) / busy_log[head_leg], cdev) if dist_on else [float(head_sims) / busy_log[head_leg]]
+    own_busy = PL.per_rank(busy_log[head_leg], cdev) if dist_on else [busy_log[head_leg]]
+    rank_cpus = None
+    if dist_on and cpus:
+        lo, hi, n_ = PL.per_rank(min(cpus), cdev), PL.per_rank(max(cpus), cdev), PL.per_rank(len(cpus), cdev)
+        rank_cpus = [[int(a), int(b), int(c)] for a, b, c in zip(lo, hi, n_)]     # [first cpu, last cpu, count] per rank
     steady_out = None
     if steady is not None:
         s_sims, s_rows, s_pr = totals(steady)
@@ -621,8 +755,10 @@ def main():
     # file-0, file-9 and rank-8 tiles), 1 of 18 in k_trunk_split_c128 (its rank-0 tile), times the products per operand pair
     ISSUE_FAST = (96.0 / 90.0) * (93.0 / 108.0)
     ISSUE_SPLIT = 3.0 * (96.0 / 90.0) * (17.0 / 18.0)
+    ISSUE_MX = 1.5 * (96.0 / 90.0) * (17.0 / 18.0)      # two fp16 MFMAs + one 8-pass fp6 MFMA per 32 input channels, in fp16-MFMA passes
+    issue_of = lambda kernel: {"k_trunk_split_c128": ISSUE_SPLIT, "k_trunk_mx_c128": ISSUE_MX}.get(kernel, ISSUE_FAST)
 
-    def trunk_roofline(conv_ms_, n_launches, issued_factor, kernel_name, clock_, telemetry_):
+    def trunk_roofline(conv_ms_, n_launches, issued_factor, kernel_name, clock_, telemetry_, traffic=traffic, traffic_src=traffic_src):
         nl_ = 2 * args.blocks
         conv_flops_ = float(trunk_flops_per_pos) * rows_per_launch
         ach = conv_flops_ / (conv_ms_ * 1e-3) / 1e12
@@ -654,7 +790,7 @@ def main():
         conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
         if net.backend == "hip":
             kname = (tower_kernel + " (first conv + whole residual tower + head 1x1 convs in one launch: %d conv layers, LDS-resident activations, %s MFMA, fp32 acc)" % (2 * args.blocks + 3, args.dtype))
-            roof = trunk_roofline(conv_ms, len(conv_ev), ISSUE_SPLIT if split else ISSUE_FAST, kname, clock, telemetry)
+            roof = trunk_roofline(conv_ms, len(conv_ev), issue_of(tower_kernel), kname, clock, telemetry)
             roof["net_forward_ms_per_step"] = net_ms
             roof["net_forward_tflops"] = flops / (net_ms * 1e-3) / 1e12
             roof["mfma_peak_measured"] = mfma_peak_measured
@@ -713,7 +849,9 @@ def main():
            "net_rows_per_step": rows_per_launch, "compact_batches": bool(compact), "hip_graph": graph[0] is not None, "record_gather": gather_ok, "res_block_nums": args.blocks, "search_threads": K,
            "positions": "seeded random playouts from the start position, ply~U[0,80]",
            "nodes_per_tree": cap, "node_pool_GB": G * cap * 30 / 1e9,
-           "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "rank0_cpus": cpus, "per_rank_sims_per_s": per_rank,
+           "dist_backend": (dist.get_backend() if dist_on else None), "world_size": world, "rank0_cpus": cpus, "rank_cpus": rank_cpus,
+           "per_rank_sims_per_s": per_rank, "per_rank_own_busy_sims_per_s": own_rate, "per_rank_busy_seconds": own_busy,
+           "per_rank_spread": (max(own_rate) - min(own_rate)) / (sum(own_rate) / len(own_rate)),
            "simulations_counted": total_sims, "net_rows": total_rows,
            "simulations_per_net_row": total_sims / max(1.0, total_rows), "terminal_extra": TE, "advance_every": args.advance_every,
            "net_rows_per_s": total_rows / dt,
@@ -728,34 +866,42 @@ def main():
                            "draws": s["draws"], "records": s["plies"], "stalled_games": s["stalled"], "dropped_records": s["dropped"],
                            "game_generations": s["games"] / float(G), "timed_gather": bool(args.timed_gather and dist_on),
                            "gathers": gather_stats["gathers"], "gathered_records": gather_stats["records"],
-                           "gather_seconds_rank0": gather_stats["seconds"]}
+                           "gather_seconds_rank0": gather_stats["seconds"], "pending_after_flush": gather_stats.get("pending_after_flush")}
     strict_out = None
     if strict_leg is not None:
         leg, s_ev, net_s = strict_leg
         s_sims, s_rows, s_pr = totals(leg)
-        strict_out = {"engine": "k_trunk_split_c128: every weight and stored activation as fp16 hi + lo halves, three MFMAs per product (bench.py --dtype strict times it on its own)" if net_s.dtype == torch.float16 else "k_trunk_split_c128, bf16 halves",
+        s_kernel = "k_trunk_mx_c128" if net_s.mx else "k_trunk_split_c128"
+        s_dtype = "mx6" if net_s.mx else ("fp16x2" if net_s.dtype == torch.float16 else "bf16x2")
+        strict_out = {"engine": {"mx6": "k_trunk_mx_c128: fp16 hi halves on fp16 MFMAs + both cross terms of the hi + lo split on one block-scaled fp6 MFMA, 1.5 MFMA-equivalents per product (bench.py --dtype strict times it on its own)",
+                                 "fp16x2": "k_trunk_split_c128: every weight and stored activation as fp16 hi + lo halves, three MFMAs per product (bench.py --dtype strict times it on its own)",
+                                 "bf16x2": "k_trunk_split_c128, bf16 halves"}[s_dtype], "dtype": s_dtype, "kernel": s_kernel,
                       "steps": args.strict_steps, "seconds": leg[0], "value": s_sims / leg[0], "unit": "sims/s",
                       "ms_per_step": leg[0] / args.strict_steps * 1e3, "net_rows_per_s": s_rows / leg[0], "per_rank_sims_per_s": s_pr,
                       "meets_target_1e6_sims_per_s_per_gpu": bool(s_sims / leg[0] / world >= 1e6),
                       "note": "third barrier-bracketed timed region: the same trees and loop with the strict engine swapped in (same weights)"}
         if s_ev:
             s_ms = float(np.mean([a.elapsed_time(b) for a, b in s_ev]))
-            strict_out["roofline"] = trunk_roofline(s_ms, len(s_ev), ISSUE_SPLIT, "k_trunk_split_c128", None, None)
+            s_tr, s_src = pmc_traffic(s_kernel, s_dtype)
+            strict_out["roofline"] = trunk_roofline(s_ms, len(s_ev), issue_of(s_kernel), s_kernel, None, None, s_tr, s_src)
     # headline: the LONG leg (steady_state) when it ran — the K contract steps (the driver's K = 20 is 47 ms) read a percent
     # or two off it and are kept as contract_steps
     contract = {"steps": args.steps, "seconds": dt, "value": total_sims / dt, "ms_per_step": dt / args.steps * 1e3,
                 "note": "the EXACTLY-K-steps region of the bench contract (barrier + synchronize on both sides, max over ranks)"}
     head_val, head_ms, head_src = total_sims / dt, dt / args.steps * 1e3, "contract_steps"
     if steady_out is not None:
-        head_val, head_ms, head_src = steady_out["value"], steady_out["ms_per_step"], "steady_state"
+        head_val, head_ms, head_src = steady_out["value"], steady_out["ms_per_step"], "steady_state (value and ms_per_step are the %d-step leg timed right after the K = %d contract steps, which are kept under contract_steps)" % (args.steady_steps, args.steps)
     out = {
         "metric": "MCTS simulations/sec (whole node), playout=%d, %d-block net" % (playout, args.blocks),
         "value": head_val, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head_ms, "value_source": head_src, "contract_steps": contract,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic", "steady_state": steady_out, "strict_engine": strict_out, "net_error": None, "config": cfg,
+        "dtype": args.dtype, "data": "synthetic", "engine": "%s (%s)" % (tower_kernel if fused else "torch/MIOpen", {"fp16": "one fp16 per operand: the fast engine; the 1e-3 contract engine of this depth is the strict_engine leg", "bf16": "one bf16 per operand", "mx6": "strict: fp16 hi halves + fp6 block-scaled cross terms", "fp16x2": "strict: fp16 hi + lo halves, three MFMAs per product", "bf16x2": "bf16 hi + lo halves"}.get(args.dtype, args.dtype)),
+        "steady_state": steady_out, "strict_engine": strict_out, "net_error": None, "config": cfg,
         "roofline": roof, "roofline_tree": tree_roof, "roofline_rules": None,
     }
+    cfg["efficiency_vs_min_rank"] = head_val / (world * min(own_rate))
+    cfg["efficiency_vs_max_rank"] = head_val / (world * max(own_rate))
     if rank == 0:
         # precision of the benchmarked engine, measured here: the net exactly as timed (same weights) and a peaked,
         # trained-like weight set, against fp32 on the same inputs (256 of the run's own synthetic positions)
@@ -766,14 +912,14 @@ def main():
                   "as_benchmarked_glorot": net_error(net, xs)}
             ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] = bool(ne["as_benchmarked_glorot"]["dlogit"] <= 1e-3 and ne["as_benchmarked_glorot"]["dvalue"] <= 1e-3)
             out["net_error"] = ne
-            net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split=split)
+            net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split="mx" if mx else split)
             trained_like_(net_t, xs[:96])
             ne["trained_like"] = net_error(net_t, xs)
             ne["meets_1e-3_abs_logit_and_value_trained_like"] = bool(ne["trained_like"]["dlogit"] <= 1e-3 and ne["trained_like"]["dvalue"] <= 1e-3)
             if strict_leg is not None:
                 net_s = strict_leg[2]
                 se = {"as_benchmarked_glorot": net_error(net_s, xs)}
-                net_ts = PolicyValueNet(args.blocks, dev, net_s.dtype, backend="hip", ctx=ctx, split=True, module=net_t.module)
+                net_ts = PolicyValueNet(args.blocks, dev, net_s.dtype, backend="hip", ctx=ctx, split="mx" if net_s.mx else True, module=net_t.module)
                 se["trained_like"] = net_error(net_ts, xs)
                 se["meets_1e-3_abs_logit_and_value"] = bool(max(se[k][q] for k in ("as_benchmarked_glorot", "trained_like") for q in ("dlogit", "dvalue")) <= 1e-3)
                 out["strict_engine"]["net_error"] = se
@@ -794,7 +940,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.blocks, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 5.0))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        line = compact_line(out)
+        line["detail_file"] = write_detail(out, "%s_n%d" % (args.dtype, world))
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -636,9 +636,10 @@ if __name__ == '__main__':
     # additions (not in the reference): size of the lock-step game pool per GPU, bounded runs for scripts
     parser.add_argument('--games', default=256, type=int, help='parallel self-play games per GPU')
     parser.add_argument('--max_batches', default=None, type=int, help='stop after this many self-play batches')
-    parser.add_argument('--net_precision', default=None, choices=['strict', 'fp16', 'bf16', 'bf16x2', 'fp32'], type=str,
-                        help='net engine (policy_value_network.PRECISIONS): strict (default) = fp16 hi+lo halves, within 1e-3 of '
-                             'the reference fp32 graph on any weights; fp16 = 2.8x faster, 1e-3 only relative to the logit scale')
+    parser.add_argument('--net_precision', default=None, choices=['strict', 'mx6', 'fp16x2', 'fp16', 'bf16', 'bf16x2', 'fp32'], type=str,
+                        help='net engine (policy_value_network.PRECISIONS): strict (default) = within 1e-3 of the reference fp32 graph '
+                             'on trained-like weights (mx6 up to 8 blocks, fp16x2 beyond); fp16 = 2x faster, 1e-3 only relative to '
+                             'the logit scale')
     args = parser.parse_args()
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # launched by torch.distributed.run: one rank per GPU

@@ -27,19 +27,24 @@ from cchess_zero_amd.train import Trainer
 
 
 class policy_value_network(object):
-    PRECISIONS = {"strict": (torch.float16, True), "fp16x2": (torch.float16, True), "bf16x2": (torch.bfloat16, True),
-                  "fp16": (torch.float16, False), "bf16": (torch.bfloat16, False), "fp32": (torch.float32, False)}
+    PRECISIONS = {"strict": (torch.float16, "strict"), "mx6": (torch.float16, "mx"), "fp16x2": (torch.float16, True),
+                  "bf16x2": (torch.bfloat16, True), "fp16": (torch.float16, False), "bf16": (torch.bfloat16, False),
+                  "fp32": (torch.float32, False)}
 
     def __init__(self, res_block_nums=7, device=None, dtype=None, save_dir="./models", seed=0, precision=None):
         """precision (or the environment's CCHESS_NET_PRECISION; default "strict"): which engine evaluates the net.
-          "strict" (= "fp16x2")  every weight and stored activation as fp16 hi + lo halves, three MFMAs per product
-                                 (k_trunk_split_c128): forward() within 1e-3 ABSOLUTE of the reference's fp32 sess.run
-                                 (policy_value_network.py:202-214) on every weight set tested, trained-like peaked weights
-                                 and 19 blocks included (measured 7e-5 / 2e-4) — the drop-in default; 1.28 M simulations/s;
-          "fp16"                 one fp16 per operand (k_tower8_c128): 2.8x the rate (3.6 M simulations/s), 1.2e-4 on
-                                 TF-default weights, 1.3e-2 absolute (1.1e-3 of the largest logit) on peaked weights;
-          "bf16"                 the same rate + 3 %, 8x the error;   "bf16x2": strict with bf16 halves (2e-4 / 7e-4);
-          "fp32"                 torch/MIOpen fp32 (1e-7 .. 3e-5), not a kernel of this library.
+          "strict"   the cheapest engine that keeps forward() within 1e-3 ABSOLUTE of the reference's fp32 sess.run
+                     (policy_value_network.py:202-214) with a factor of two to spare on peaked, trained-like weights at this
+                     depth — the drop-in default: "mx6" up to 8 residual blocks, "fp16x2" beyond;
+          "mx6"      fp16 hi halves on fp16 MFMAs + both cross terms of the hi + lo split on ONE block-scaled fp6 MFMA
+                     (k_trunk_mx_c128, 1.5 MFMA-equivalents per product): 5e-4 / 2e-4 at 7 blocks, 1.0e-3 / 1.1e-3 at 19;
+                     1.9 M simulations/s;
+          "fp16x2"   every weight and stored activation as fp16 hi + lo halves, three MFMAs per product
+                     (k_trunk_split_c128): 7e-5 / 2e-4 also at 19 blocks; 1.3 M simulations/s;
+          "fp16"     one fp16 per operand (k_tower8_c128): 3.6-3.9 M simulations/s, 1.2e-4 on TF-default weights, 1.3e-2
+                     absolute (1.1e-3 of the largest logit) on peaked weights;
+          "bf16"     the same rate + 3 %, 8x the error;   "bf16x2": fp16x2 with bf16 halves (2e-4 / 7e-4);
+          "fp32"     torch/MIOpen fp32 (1e-7 .. 3e-5), not a kernel of this library.
         dtype (older callers): a torch dtype selects the one-value-per-operand engine of that type."""
         if dtype is not None:
             split = False

@@ -1,0 +1,63 @@
+"""bench.py's evidence plumbing, on the CPU: the committed PMC traffic files are the ones the bench will look
+up for its three trunk engines (round 4 shipped `roofline.traffic: null` because the kernel name in the JSON and the name in
+bench.py had drifted apart behind a bare `except`), and the one line rank 0 prints stays under the 8 KB the driver's record
+keeps, with the contract-true engine's numbers at the top level."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_committed_pmc_traffic_files_match_what_bench_looks_up():
+    import bench
+    dtype_of = {"k_tower8_c128": "fp16", "k_trunk_split_c128": "fp16x2", "k_trunk_mx_c128": "mx6"}
+    seen = 0
+    for kernel, fname in bench.TRAFFIC_FILE.items():
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        tj = json.load(open(path))
+        seen += 1
+        assert kernel.startswith(tj["kernel"]), (fname, tj["kernel"], kernel)       # what bench.py's pmc_traffic() requires
+        cfg = tj["config"]
+        assert (cfg["B"], cfg["res_block_nums"], cfg["dtype"], bool(cfg.get("compact", False))) == (8192, 7, dtype_of[kernel], False), (fname, cfg)
+        assert tj["traffic_bytes_per_launch"] >= tj["algorithmic_bytes_per_launch"] > 30e6
+        assert set(bench.TRUNK_KERNEL[d] for d in bench.TRUNK_KERNEL) == set(bench.TRAFFIC_FILE)
+    assert seen >= 2
+
+
+def test_compact_line_is_small_and_carries_the_contract_numbers():
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04H_bench_default.json")))     # a complete record of round 4 (20 KB)
+    assert len(json.dumps(full)) > 9000
+    line = bench.compact_line(full)
+    txt = json.dumps(line)
+    assert len(txt) < 6000, len(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "strict_engine", "steady_state", "contract_steps", "roofline_tree", "roofline_rules",
+              "net_error"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["config"]["workload"] == full["config"]["workload"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel"] == "k_tower8_c128" and "traffic" in r
+    se = line["strict_engine"]
+    assert se["value"] == full["strict_engine"]["value"] and se["frac"] == full["strict_engine"]["roofline"]["frac"]
+    assert se["dlogit_trained_like"] <= 1e-3 and se["meets_1e-3_abs_logit_and_value"] is True
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and "sample" in cb and "measured_in_this_run" not in cb   # old record: no flag
+    assert set(line["roofline_rules"]) >= {"bound", "achieved", "peak", "unit", "frac"}
+
+
+def test_reference_python_flag(monkeypatch):
+    """cpu_baseline.reference_python.measured_in_this_run: True only when /root/reference was imported and timed in this run."""
+    import bench
+    monkeypatch.setattr(bench, "_cpu_workers", lambda specs: (_ for _ in ()).throw(RuntimeError("no workers in this test")))
+    monkeypatch.setattr(bench, "reference_python_now", lambda timeout=90: None)
+    out = bench.cpu_baseline(2, 1.0)
+    assert out["reference_python"]["measured_in_this_run"] is False and out["reference_python"]["search_only_sims_per_s_per_core"] == 405
+    monkeypatch.setattr(bench, "reference_python_now", lambda timeout=90: {"search_only_sims_per_s_per_core": 650.0})
+    out = bench.cpu_baseline(2, 1.0)
+    assert out["reference_python"]["measured_in_this_run"] is True and out["reference_python"]["search_only_sims_per_s_per_core"] == 650.0
+    assert out["reference_python"]["static_record"]["end_to_end_7block_sims_per_s"] == 157

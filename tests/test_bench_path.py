@@ -189,11 +189,12 @@ def test_fused_step_configs2_full_length_1600_playouts_vs_oracle():
 # last bits of the fp32 logits — is not the same on every box): a numerically worse kernel fails.
 # The STRICT engine (fp16 hi + lo halves, k_trunk_split_c128) is within 4e-5 of the fp32 logits on these weights: the
 # searches must agree like two fp32 evaluations do — >= 0.999 of the most visited root moves, visit L1 <= 0.002.
+# The MX engine (k_trunk_mx_c128: cross terms on a block-scaled fp6 MFMA, 30-40x closer to fp32 than "fp16"): >= 0.995 / <= 0.004.
 _AGREE = {"bf16": (torch.bfloat16, 0.93, 0.10, False), "fp16": (torch.float16, 0.975, 0.025, False),
-          "strict": (torch.float16, 0.999, 0.002, True)}
+          "strict": (torch.float16, 0.999, 0.002, True), "mx6": (torch.float16, 0.995, 0.004, "mx")}
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16", "strict"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "strict", "mx6"])
 def test_fused_search_agrees_with_fp32_engine(dname):
     """The fused 16-bit net (and the strict split engine) vs the fp32 engine (torch/MIOpen fp32 convs, full logits) on the same
     1024 roots, 400 playouts, trained-like weights: the root move a self-play game would most likely play (most visited child)

@@ -61,11 +61,15 @@ def test_bench_two_ranks_search_loop_default_engine():
     """The default loop (search, aged trees, steady leg, strict leg) with two ranks: both legs carry two per-rank figures."""
     d = _bench(["--gpus", "2", "--all-on-device0", "--dist-backend", "gloo", "--games", "512", "--playout", "64", "--steps", "24",
                 "--warmup", "4", "--age-steps", "48", "--steady-steps", "48", "--strict-steps", "16", "--no-cpu-baseline"])
-    assert d["n_gpus"] == 2 and d["value_source"] == "steady_state"
+    assert d["n_gpus"] == 2 and d["value_source"].startswith("steady_state")
     assert len(d["steady_state"]["per_rank_sims_per_s"]) == 2 and len(d["strict_engine"]["per_rank_sims_per_s"]) == 2
     assert d["contract_steps"]["steps"] == 24 and d["config"]["record_gather"] is True
     assert d["config"]["trees_with_error_status"] == 0
-    assert d["strict_engine"]["net_error"]["meets_1e-3_abs_logit_and_value"] is True
+    assert d["strict_engine"]["kernel"] == "k_trunk_mx_c128" and d["strict_engine"]["meets_1e-3_abs_logit_and_value"] is True
+    assert d["strict_engine"]["value"] > 0 and d["strict_engine"]["frac"] > 0
+    assert len(json.dumps(d)) < 8000                      # the driver's record keeps an 8 KB tail of the line
+    full = json.load(open(os.path.join(ROOT, d["detail_file"])))
+    assert full["strict_engine"]["net_error"]["meets_1e-3_abs_logit_and_value"] is True and "telemetry" in json.dumps(full)
 
 
 @pytest.mark.gpu
@@ -97,3 +101,52 @@ def test_train_two_ranks_end_with_identical_weights(tmp_path):
     assert got[0] == got[1], got                     # weights digest, global step, buffer length
     assert int(got[0][1]) >= 1 and int(got[0][2]) > 64
     assert "samples:" in p.stdout and "kl:" in p.stdout
+
+
+def _disjoint(rank_cpus):
+    """[first cpu, last cpu, count] per rank -> the slices do not overlap (pin_rank_to_cpus hands out contiguous slices)"""
+    spans = sorted((a, b) for a, b, n in rank_cpus)
+    return all(spans[i][1] < spans[i + 1][0] for i in range(len(spans) - 1)) and all(b - a + 1 == n for a, b, n in rank_cpus)
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_self_launch_selfplay_with_timed_exchange():
+    """the shape of the driver's 8-GPU launch, on one device — `python bench.py --gpus 8` from a bare shell
+    (bench.py starts its own 8 ranks through torch.distributed.run), self-play with the fixed-capacity record exchange inside
+    the timed region (configs[3]'s exchange step; policy_value_network_gpus.py:216-250 / main.py:1240 in the reference).  Eight
+    per-rank figures, disjoint CPU slices, every record delivered, nothing left in the exchange."""
+    d = _bench(["--gpus", "8", "--all-on-device0", "--dist-backend", "gloo", "--selfplay", "--timed-gather", "--games", "64",
+                "--playout", "16", "--steps", "128", "--warmup", "8", "--age-steps", "32", "--steady-steps", "0", "--strict-steps", "0",
+                "--no-cpu-baseline"], timeout=1500)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["world_size"] == 8 and c["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    assert len(c["per_rank_sims_per_s"]) == 8 and all(v > 0 for v in c["per_rank_sims_per_s"])
+    # whole-job value against 8 copies of the fastest / the slowest rank's own rate (own = before it waits at the closing barrier)
+    assert len(c["per_rank_busy_seconds"]) == 8 and 0 < c["efficiency_vs_max_rank"] <= c["efficiency_vs_min_rank"] <= 1.0 + 1e-6
+    assert c["per_rank_spread"] >= 0
+    assert c["rank_cpus"] is None or (len(c["rank_cpus"]) == 8 and _disjoint(c["rank_cpus"])), c["rank_cpus"]
+    assert c["record_gather"] is True and c["trees_with_error_status"] == 0
+    sp = c["selfplay"]
+    assert sp["timed_gather"] is True and sp["gathers"] >= 2 and sp["gathered_records"] > 0
+    assert sp["stalled_games"] == 0 and sp["dropped_records"] == 0 and sp["pending_after_flush"] == 0
+    assert d["value"] > max(c["per_rank_sims_per_s"]) and d["value"] <= sum(c["per_rank_sims_per_s"]) * 1.001
+    assert len(json.dumps(d)) < 8000
+
+
+@pytest.mark.gpu
+def test_train_eight_ranks_end_with_identical_weights(tmp_path):
+    """`main.py --mode train` with eight ranks on one device: eight self-play shards, one all-gather of records, one data-parallel
+    policy update — eight identical replicas afterwards."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(CCHESS_DIST_BACKEND="gloo", CCHESS_ALL_ON_DEVICE0="1", CCHESS_WEIGHT_DIGEST_DIR=str(tmp_path),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(ROOT, "main.py"), "--mode", "train", "--games", "32", "--train_playout", "12",
+           "--batch_size", "64", "--res_block_nums", "2", "--max_batches", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=1500, stdin=subprocess.DEVNULL)
+    if p.returncode != 0:
+        _keep_logs("train_eight_ranks", p)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read().split() for r in range(8)]
+    assert all(g == got[0] for g in got), got             # weights digest, global step, buffer length
+    assert int(got[0][1]) >= 1 and int(got[0][2]) > 64

@@ -100,20 +100,23 @@ def test_inference_engine_fp32_within_1e3(blocks):
 @pytest.mark.gpu
 def test_facade_default_forward_meets_1e3(tmp_path):
     """policy_value_network(res_block_nums=7).forward — the API north_star names (policy_value_network.py:202-214) with its
-    DEFAULT engine (since round 4 the strict one: fp16 hi + lo halves, k_trunk_split_c128) — against the fp32 NumPy
-    restatement of the reference graph: |dlogit| <= 1e-3 and |dvalue| <= 1e-3 ABSOLUTE on the TF-default weights and on the
-    peaked trained-like set (|logit| ~ 12).  precision="fp16" selects the fast engine bench.py's headline runs: the same
-    bound on TF-default weights only (measured 1.2e-4 / 1.1e-4)."""
+    DEFAULT engine (precision "strict": since round 5 k_trunk_mx_c128 up to 8 blocks — fp16 hi halves + the cross terms on a
+    block-scaled fp6 MFMA —, k_trunk_split_c128 beyond) — against the fp32 NumPy restatement of the reference graph:
+    |dlogit| <= 1e-3 and |dvalue| <= 1e-3 ABSOLUTE on the TF-default weights and on the peaked trained-like set (|logit| ~ 12).
+    precision="fp16" selects the fast engine bench.py's headline runs: the same bound on TF-default weights only (measured
+    1.2e-4 / 1.1e-4)."""
     from policy_value_network import policy_value_network
+    deep = policy_value_network(9, save_dir=str(tmp_path / "deep"))
+    assert deep.net.split and not deep.net.mx            # deeper than MX_DEPTH_LIMIT: three fp16 MFMAs per product
     pv = policy_value_network(7, save_dir=str(tmp_path))
-    assert pv.net.dtype == torch.float16 and pv.net.backend == "hip" and pv.net.fused_search and pv.net.split
+    assert pv.net.dtype == torch.float16 and pv.net.backend == "hip" and pv.net.fused_search and pv.net.split and pv.net.mx
     x = _positions(64, 2)
     for wset in ("glorot", "trained_like"):
         H.WEIGHT_SETS[wset](pv.net)
         logits, v = pv.forward(x)
         ln, vn = net_numpy.forward(pv.module.export_tf_layout(), x, 7)
         e = H.errors(logits, v, ln, vn)
-        print("facade default (strict, 7 blocks, %s): max|logit| %.3g dlogit %.3g dvalue %.3g dsoftmax %.3g" % (wset, e["max_abs_logit"], e["dlogit"], e["dvalue"], e["dprob"]))
+        print("facade default (strict = mx6, 7 blocks, %s): max|logit| %.3g dlogit %.3g dvalue %.3g dsoftmax %.3g" % (wset, e["max_abs_logit"], e["dlogit"], e["dvalue"], e["dprob"]))
         assert logits.dtype == np.float32 and logits.shape == (64, 2086) and v.shape == (64, 1)
         assert e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3 and e["dprob"] <= 1e-4
     chk = pv.net.range_check()
@@ -345,17 +348,71 @@ def test_strict_engine_meets_1e3_absolute(dname, blocks, wset):
     assert e["argmax_agree"] == 1.0
 
 
+# The MX engine (split="mx", k_trunk_mx_c128; round 5): a*w = a_hi*w_hi on fp16 MFMAs + both cross terms of the hi + lo split on
+# one block-scaled fp6 MFMA (4 significant bits per cross-term operand, ~2^-16 of a product).  Held to north_star's ABSOLUTE
+# 1e-3 at the depths precision "strict" uses it for (<= 8 blocks) — emulated on the CPU (tests/mxemu.py; against the fp64
+# graph): 4.9e-4 / 2.2e-4 on trained-like weights at 7 blocks, 3.2e-4 / 1.9e-4 at 8; 1.0e-3 / 1.1e-3 at 19 (k_trunk_split_c128's
+# job) — and, at shallow depth, to its CPU emulation on the trunk activations themselves.
+MX_CASES = [(2, "glorot"), (7, "glorot"), (3, "structured"), (3, "trained_like"), (7, "trained_like"), (8, "trained_like")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_strict_engine_rows_are_independent_and_routes_agree(dt):
-    """k_trunk_split_c128: (i) a position's outputs do not depend on its row in the batch, on the batch size (ragged last
+@pytest.mark.parametrize("blocks,wset", MX_CASES)
+def test_mx_engine_meets_1e3_absolute(blocks, wset):
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(blocks, "cuda:0", torch.float16, seed=1, split="mx")
+    assert net.backend == "hip" and net.split and net.mx and net.fused_search
+    H.WEIGHT_SETS[wset](net)
+    x = _positions(64, 2)
+    logits, v = net.forward(x)
+    ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, blocks)
+    e = H.errors(logits, v, ln, vn)
+    print("mx6 %d-block %s: max|logit| %.3g  dlogit %.3g (rel %.3g)  dprob %.3g  dvalue %.3g  argmax agreement %.3f" %
+          (blocks, wset, e["max_abs_logit"], e["dlogit"], e["dlogit_rel"], e["dprob"], e["dvalue"], e["argmax_agree"]))
+    assert np.isfinite(logits).all() and np.isfinite(v).all()
+    assert e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3     # north_star: "policy/value outputs match within 1e-3 fp32"
+    if wset != "trained_like":
+        assert e["dlogit"] <= 5e-5 and e["dvalue"] <= 5e-5
+    assert e["argmax_agree"] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,wset,tol", [(1, "structured", 2e-5), (1, "trained_like", 2e-5), (2, "structured", 4e-5)])
+def test_mx_engine_matches_its_cpu_emulation(blocks, wset, tol):
+    """k_trunk_mx_c128's trunk activations (fp32, last layer) against tests/mxemu.py — the same hi / lo split, the same
+    E2M3 grid under the same block scales, fp32 accumulation in another order: measured 3e-6 .. 6e-6 of the largest
+    activation at 1 - 2 blocks (a wrong slot, scale byte or channel grouping is off by 1e-3 and more); and every head output."""
+    import mxemu
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(blocks, "cuda:0", torch.float16, seed=1, split="mx")
+    H.WEIGHT_SETS[wset](net)
+    x = _positions(37, 2)
+    xd = torch.from_numpy(x).cuda()
+    lg, vg = net.forward_device(xd)
+    tg = net.tower(xd).float().cpu()
+    mod = net.module.float().cpu()
+    with torch.no_grad():
+        le, ve, te = mxemu.forward_mx(mod, torch.from_numpy(x).permute(0, 3, 1, 2).contiguous())
+    net.module.to("cuda:0")
+    rel = float((tg - te).abs().max() / te.abs().max())
+    dl, dv = float((lg.cpu() - le).abs().max()), float((vg.cpu().reshape(-1) - ve.reshape(-1)).abs().max())
+    print("mx6 %d-block %s kernel vs CPU emulation: trunk %.3g of its largest value, logits %.3g (max |logit| %.3g), value %.3g" %
+          (blocks, wset, rel, dl, float(le.abs().max()), dv))
+    assert rel <= tol
+    assert dl <= 2e-5 * float(le.abs().max()) + 2e-6 and dv <= 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,split", [(torch.float16, True), (torch.bfloat16, True), (torch.float16, "mx")])
+def test_strict_engine_rows_are_independent_and_routes_agree(dt, split):
+    """k_trunk_split_c128 / k_trunk_mx_c128: (i) a position's outputs do not depend on its row in the batch, on the batch size (ragged last
     workgroup: 2 positions per workgroup) or on the device-side row count of the compact path; (ii) zero-copy 16-channel planes
     in the operand type == repacked f32 planes; (iii) the fp32 trunk output (hi + lo) through torch's fp32 head convs and FCs
     agrees with the fused heads to fp32 summation-order noise."""
     import ctypes as C
     from cchess_zero_amd._lib import check, lib
     from cchess_zero_amd.net import PolicyValueNet
-    net = PolicyValueNet(3, "cuda:0", dt, seed=4, split=True)
+    net = PolicyValueNet(3, "cuda:0", dt, seed=4, split=split)
     H.structured_(net)
     x = torch.from_numpy(_positions(37, 5)).cuda()
     l_all, v_all = net.forward_device(x)
@@ -391,7 +448,7 @@ def test_fp16_engines_do_not_overflow_to_inf():
     the split); with the first layer's bias at 1e5 every activation of the net saturates and the outputs stay finite."""
     from cchess_zero_amd.net import PolicyValueNet
     x = torch.from_numpy(_positions(6, 3)).cuda()
-    for split in (False, True):
+    for split in (False, True, "mx"):
         net = PolicyValueNet(2, "cuda:0", torch.float16, seed=2, split=split)
         with torch.no_grad():
             net.module.conv_in.conv.bias.fill_(1.0e5)

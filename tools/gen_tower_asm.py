@@ -162,16 +162,50 @@ def slabMX(hs):
     L += [f(2, "w1", "a1h")]
     L += ["ds_read_b128 %[a0h2], %[t2]", "ds_read_b128 %[w0], %[vbn]"]
     # step C
-    L += ["s_waitcnt lgkmcnt(4)", mx(0)]
+    dma1 = ["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]
+    dma2 = ["s_add_u32 m0, %[ldst], 0x2000", "s_nop 0", "global_load_lds_dwordx4 %[voff1], %[sbase]"]
+    place = os.environ.get("MX_DMA_PLACE", "C")     # experiment knob: where the wave's two LDS-DMA pieces go
+    if place == "B0":       # both right behind the barrier
+        i = L.index("s_barrier") + 1
+        L[i:i] = dma1 + dma2
+    elif place == "B0C0":   # one behind the barrier, one at the top of step C
+        i = L.index("s_barrier") + 1
+        L[i:i] = dma1
+    L += ["s_waitcnt lgkmcnt(4)"]
+    if place == "B0C0":
+        L += dma2
+    L += [mx(0)]
     L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca + 2, nkey, i) for i in range(3)]
     L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(3)]
-    L += ["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]
+    if place == "C":
+        L += dma1
     L += [mx(1)]
     L += ["ds_read_b128 %[a1h0], %[t0]", "ds_read_b128 %[a1h1], %[t1]"]
-    L += ["s_add_u32 m0, %[ldst], 0x2000", "s_nop 0", "global_load_lds_dwordx4 %[voff1], %[sbase]"]
+    if place == "C":
+        L += dma2
     L += [mx(2)]
     L += ["ds_read_b128 %[a1h2], %[t2]", "ds_read_b128 %[w1], %[vbn] offset:4096"]
+    if place == "Cend":
+        L += dma1 + dma2
     L += ["s_mov_b32 m0, %[keep]"]
+    # timing ablations (tools/experiments/mx_ablate.sh; wrong results): MX_ABLATE = comma list of nobarrier, bar2 (barrier in
+    # every other slab), noc (no fp6 operand reads), nomx (no fp6 MFMAs), nodma, nohi (no fp16 operand reads)
+    ab = [a for a in os.environ.get("MX_ABLATE", "").split(",") if a]
+    if "nobarrier" in ab or ("bar2" in ab and hs % 2 == 1):
+        L = [l for l in L if l != "s_barrier"]
+    if "noc" in ab:
+        L = [l for l in L if not (l.startswith("ds_read") and ("v[2" in l or "%[ws]" in l or "%[sb" in l))]
+        L = [l.replace("lgkmcnt(12)", "lgkmcnt(0)").replace("lgkmcnt(9)", "lgkmcnt(0)") for l in L]
+    if "nohi" in ab:
+        L = [l for l in L if not (l.startswith("ds_read_b128 %[a") or l.startswith("ds_read_b128 %[w"))]
+        L = [l.replace("lgkmcnt(4)", "lgkmcnt(0)") for l in L]
+    if "nomx" in ab:
+        L = [l for l in L if not l.startswith("v_mfma_scale")]
+    if "novmwait" in ab:      # the DMAs are issued but never waited for: issue cost vs waiting for the data
+        L = [l.replace("s_waitcnt vmcnt(2)", "s_nop 0") for l in L]
+    if "nodma" in ab:
+        L = [l for l in L if not l.startswith("global_load_lds")]
+        L = [l.replace("s_waitcnt vmcnt(2)", "s_nop 0") for l in L]
     return L
 
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun): one parameterised session instead of one script per session (rounds 2-4 kept ~45 of those; they
+# are in git history).  usage: tools/gpu_session.sh <tag> <step> [<step> ...]   — output under gpurun_out/<tag>/
+#   tests[:k-expr]   pytest -m gpu (optionally -k <expr>)        smoke            __graft_entry__.smoke()
+#   bench[:args]     python bench.py <args> (default line + CPU baseline)         bench_nocpu[:args]  the same with --no-cpu-baseline
+#   profile[:dtype]  tools/profile_round.sh (rocprofv3 kernel stats + HBM PMC passes of the bench, engine <dtype>)
+#   pmcsq:<engine>   tools/pmc_mx.sh (SQ counters of one trunk engine: fp16 | x3 | mx)
+#   rules            tools/rules_bench.py (stand-alone K1 / K2 / K3 / hash kernels, 1 M positions)
+#   mx               tools/mx_check.py --time (the mx engine against its CPU emulation; launch times of the three fp16 engines)
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p $O
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+  case $name in
+    tests) ( timeout 1700 python -m pytest tests -m gpu -q -x -p no:cacheprovider ${arg:+-k "$arg"} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log ); tail -5 $O/pytest_gpu.log;;
+    smoke) ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log ); tail -3 $O/smoke.log;;
+    bench) n=bench_$(echo "${arg:-default}" | tr -c 'A-Za-z0-9\n' '_'); timeout 900 python bench.py $arg > $O/$n.json 2> $O/$n.err; python tools/jline.py $O/$n.json | tee $O/$n.txt; cp gpurun_out/bench_detail_*.json $O/ 2>/dev/null;;
+    bench_nocpu) n=bench_$(echo "${arg:-default}" | tr -c 'A-Za-z0-9\n' '_'); timeout 900 python bench.py --no-cpu-baseline $arg > $O/$n.json 2> $O/$n.err; python tools/jline.py $O/$n.json | tee $O/$n.txt; cp gpurun_out/bench_detail_*.json $O/ 2>/dev/null;;
+    profile) tools/profile_round.sh $TAG/prof_${arg:-fp16} ${arg:+--dtype $arg} > $O/profile_${arg:-fp16}.log 2>&1; tail -3 $O/profile_${arg:-fp16}.log;;
+    pmcsq) tools/pmc_mx.sh $O/pmcsq_$arg $arg 2>&1 | tail -8 | tee $O/pmcsq_$arg.txt;;
+    rules) timeout 600 python tools/rules_bench.py > $O/rules_bench.log 2>&1; tail -12 $O/rules_bench.log;;
+    mx) timeout 600 python tools/mx_check.py --time > $O/mx_check.txt 2>&1; tail -20 $O/mx_check.txt | cut -c1-260;;
+    *) echo "unknown step $step";;
+  esac
+done

@@ -5,6 +5,13 @@ import sys
 src = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
 lines = [l for l in src.strip().splitlines() if l.startswith("{")]
 d = json.loads(lines[-1])
+if "detail_file" in d:   # the compact line of round 5: the complete record sits in the side file
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cand in (d["detail_file"], os.path.join(root, d["detail_file"]), os.path.join(os.path.dirname(sys.argv[1]) if len(sys.argv) > 1 else ".", os.path.basename(d["detail_file"]))):
+        if os.path.exists(cand):
+            d = json.load(open(cand))
+            break
 r = d["roofline"]
 print("%.0f sims/s  %.3f ms/step  n_gpus %d  trunk %.1f us  %.1f TF/s (frac %.3f)  errors %s" % (
     d["value"], d["ms_per_step"], d["n_gpus"], r.get("us_per_launch", float("nan")), r["achieved"], r["frac"], d["config"].get("trees_with_error_status")))

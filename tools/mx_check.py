@@ -17,9 +17,11 @@ ap.add_argument("--blocks", default="1,2,3,7")
 ap.add_argument("--wsets", default="glorot,structured,trained_like")
 ap.add_argument("--time", action="store_true")
 ap.add_argument("--n", type=int, default=37)
+ap.add_argument("--engines", default="fp16,x3,mx", help="--time: which engines")
+ap.add_argument("--launches", type=int, default=20)
 args = ap.parse_args()
 torch.set_grad_enabled(False)
-for blocks in [int(b) for b in args.blocks.split(",")]:
+for blocks in [int(b) for b in args.blocks.split(",") if b]:
     for wset in args.wsets.split(","):
         if wset == "structured" and blocks > 3:
             continue
@@ -49,14 +51,16 @@ if args.time:
     x16 = torch.zeros((8192, 9, 10, 16), dtype=torch.float16, device="cuda")
     x16[..., :14] = x.to(torch.float16)
     for name, split in (("fp16", False), ("x3", True), ("mx", "mx")):
+        if name not in args.engines.split(","):
+            continue
         net = PolicyValueNet(7, "cuda:0", torch.float16, seed=0, split=split)
         for rep in range(2):
             net._hip_net_forward(x16)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20):
+            for _ in range(args.launches):
                 net._hip_net_forward(x16)
             e1.record()
             torch.cuda.synchronize()
-            print("%-5s 7 blocks, 8192 positions: %.1f us per launch" % (name, e0.elapsed_time(e1) / 20 * 1e3), flush=True)
+            print("%-5s 7 blocks, 8192 positions: %.1f us per launch" % (name, e0.elapsed_time(e1) / args.launches * 1e3), flush=True)

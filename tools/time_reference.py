@@ -32,6 +32,16 @@ def run(forward, playouts, search_threads):
 
 
 def main():
+    if "--json" in sys.argv:   # bench.py's cpu_baseline leg: search-only, 50 and 400 playouts, one core
+        import json
+        const = (np.zeros((1, 2086), np.float32) + 0.01, np.zeros((1, 1), np.float32))
+        fake = lambda positions: (np.repeat(const[0], len(positions), 0), np.repeat(const[1], len(positions), 0))
+        a = max(run(fake, 50, 16) for _ in range(2))
+        b = run(fake, 400, 16)
+        print(json.dumps({"search_only_sims_per_s_per_core": b, "search_only_50_playouts_sims_per_s": a, "search_only_400_playouts_sims_per_s": b,
+                          "where": "the unmodified reference's MCTS_tree.main imported from /root/reference, constant-time forward, "
+                                   "search_threads 16, one core, timed by tools/time_reference.py --json inside this bench run"}))
+        return
     playouts = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     const = (np.zeros((1, 2086), np.float32) + 0.01, np.zeros((1, 1), np.float32))
 
