@@ -226,6 +226,15 @@ CZM_FN CzmSets czm_sets(const uint32_t (&w)[23], int side) {
     S.enemy = CzmSet{S.occ.lo & ~S.own.lo, S.occ.hi & ~S.own.hi};
     return S;
 }
+// The generators below take a kind's squares as the LOWEST and HIGHEST bit of its set (pawns: five iterations): a board with a third
+// rook / cannon / knight / advisor / bishop, a sixth pawn or a second king of the side to move is not a Xiangqi position, and the
+// in-search generator (czd_wave_movegen: any board) would list moves this one silently drops — so such a board is an ERROR
+// (count 0xFFFF, like a board with more than 16 own pieces), never a shorter list.
+CZM_FN int czm_popcnt(const CzmSet &s) { return __builtin_popcountll(s.lo) + __builtin_popcount(s.hi); }
+CZM_FN bool czm_not_xiangqi(const CzmSets &S) {
+    return (czm_popcnt(S.own) > 16) | (czm_popcnt(S.R) > 2) | (czm_popcnt(S.C) > 2) | (czm_popcnt(S.N) > 2) | (czm_popcnt(S.A) > 2) |
+           (czm_popcnt(S.B) > 2) | (czm_popcnt(S.P) > 5) | (czm_popcnt(S.K) > 1);
+}
 // rook / cannon on square q (main.py:757-833, 947-1062): the 17-bit field of its destinations
 template <bool cannon>
 CZM_FN uint32_t czm_slider_field(const CzmSets &S, int q) {
@@ -301,13 +310,14 @@ CZM_FN uint32_t czm_diag_good(const CzmSets &S, int side, int q) {
 }
 
 // ---- the SET: czm_position.  Returns the number of legal moves, or -1 when the position is not a Xiangqi position the
-// vocabulary can express (more than 16 pieces of a colour; an advisor / bishop move without a label).  Branch-free apart from
+// vocabulary can express (more than 16 pieces of the side to move, or more of a kind than a Xiangqi set holds — czm_not_xiangqi;
+// an advisor / bishop move without a label).  Branch-free apart from
 // the loops: every lane runs every kind's code; a missing piece (square -1) computes on square 0 and its field is zeroed before
 // it is handed out.
 template <typename Emit>
 CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, Emit emit) {
     const CzmSets S = czm_sets(w, side);
-    bool err = __builtin_popcountll(S.own.lo) + __builtin_popcount(S.own.hi) > 16;
+    bool err = czm_not_xiangqi(S);
     int count = 0;
     auto put = [&](int bit, uint32_t f, bool ok) {
         f = ok ? f : 0u;
@@ -406,7 +416,7 @@ CZM_FN int czm_rank_below(const CzmSet &own, int q) {   // own pieces on squares
 template <typename Put, typename Scr, typename Mid, typename Emit>
 CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put put, Scr scr, Mid mid, Emit emit) {
     const CzmSets S = czm_sets(w, side);
-    bool err = __builtin_popcountll(S.own.lo) + __builtin_popcount(S.own.hi) > 16;
+    bool err = czm_not_xiangqi(S);
     // slots in kind order: 0, 1 rooks; 2, 3 cannons; 4, 5 knights; 6 king; 7 .. 11 pawns; 12, 13 advisors; 14, 15 bishops
     int q[16];
     uint32_t pay[16];

@@ -49,35 +49,39 @@ extern "C" int cz_probe_mfma_peak(cz_ctx *c, int dtype, int data, int iters, dou
     CZ_HIP(hipSetDevice(c->device));
     uint4 *src = nullptr;
     float *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     const int grid = 256 * 4, threads = 512;
-    CZ_HIP(hipMalloc(&src, 1024 * 16));
-    CZ_HIP(hipMalloc(&dst, (size_t)grid * threads * 4));
-    unsigned short h[8192];
-    unsigned s = 12345u;
-    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
-    for (int i = 0; i < 8192; ++i) {
-        const unsigned r0 = rnd(), r1 = rnd(), r2 = rnd();
-        h[i] = (data == 1 || (data == 2 && (r0 & 1))) ? 0 : (unsigned short)(0x3c00 + (r1 & 0x3ff) + ((r2 & 1) << 15));
-    }
-    CZ_HIP(hipMemcpy(src, h, sizeof h, hipMemcpyHostToDevice));
-    hipEvent_t e0, e1;
-    CZ_HIP(hipEventCreate(&e0));
-    CZ_HIP(hipEventCreate(&e1));
     float best = 0.f;
-    for (int rep = 0; rep < 2; ++rep) {   // the first launch loads the code object and lets the clocks settle
-        CZ_HIP(hipEventRecord(e0, c->stream));
-        if (dtype == CZ_F16) hipLaunchKernelGGL((k_mfma_peak<true>), dim3(grid), dim3(threads), 0, c->stream, src, dst, iters);
-        else hipLaunchKernelGGL((k_mfma_peak<false>), dim3(grid), dim3(threads), 0, c->stream, src, dst, iters);
-        CZ_HIP(hipEventRecord(e1, c->stream));
-        CZ_HIP(hipEventSynchronize(e1));
-        CZ_HIP(hipEventElapsedTime(&best, e0, e1));
+    // every HIP call through `step`: the first failure is remembered and the buffers / events are released on every path
+    hipError_t bad = hipSuccess;
+    auto step = [&](hipError_t e) { if (bad == hipSuccess && e != hipSuccess) bad = e; return bad == hipSuccess; };
+    if (step(hipMalloc(&src, 1024 * 16)) && step(hipMalloc(&dst, (size_t)grid * threads * 4))) {
+        unsigned short h[8192];
+        unsigned s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+        for (int i = 0; i < 8192; ++i) {
+            const unsigned r0 = rnd(), r1 = rnd(), r2 = rnd();
+            h[i] = (data == 1 || (data == 2 && (r0 & 1))) ? 0 : (unsigned short)(0x3c00 + (r1 & 0x3ff) + ((r2 & 1) << 15));
+        }
+        step(hipMemcpy(src, h, sizeof h, hipMemcpyHostToDevice));
+        step(hipEventCreate(&e0));
+        step(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2 && bad == hipSuccess; ++rep) {   // the first launch loads the code object and lets the clocks settle
+            step(hipEventRecord(e0, c->stream));
+            if (dtype == CZ_F16) hipLaunchKernelGGL((k_mfma_peak<true>), dim3(grid), dim3(threads), 0, c->stream, src, dst, iters);
+            else hipLaunchKernelGGL((k_mfma_peak<false>), dim3(grid), dim3(threads), 0, c->stream, src, dst, iters);
+            step(hipEventRecord(e1, c->stream));
+            step(hipEventSynchronize(e1));
+            step(hipEventElapsedTime(&best, e0, e1));
+        }
+        step(hipGetLastError());
     }
-    CZ_HIP(hipGetLastError());
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (bad != hipSuccess) { cz_set_error(hipGetErrorString(bad)); return CZ_EHIP; }
     *ms = best;
     *tflops = (double)grid * (threads / 64) * iters * 48.0 * 32 * 32 * 16 * 2 / (best * 1e-3) / 1e12;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(src);
-    (void)hipFree(dst);
     return CZ_OK;
 }

@@ -641,12 +641,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
                 if (__ballot(xk == key) == 0ull && xm) {
                     // the first empty slot at or behind a key-dependent position: trees filing different positions into one
                     // bucket in the same launch do not all go for slot 0 (the loser of a swap does not retry: write-once table)
+                    // (a tree that loses the swap to ANOTHER position tries the next empty slot, up to three times — a lost
+                    // swap no longer drops the entry while the bucket has room; losing it to the SAME position means it is filed)
                     const int rot = (int)((key >> 40) & 63);
-                    const unsigned long long xr = rot ? (xm >> rot) | (xm << (64 - rot)) : xm;
-                    const int slot = (__ffsll((long long)xr) - 1 + rot) & 63;
-                    int won = 0;
-                    if (lane == 0) won = atomicCAS(&czx_key(t)[xb0 + slot], 0ull, key) == 0ull ? 1 : 0;
-                    won = __shfl(won, 0, 64);
+                    unsigned long long xr = rot ? (xm >> rot) | (xm << (64 - rot)) : xm;
+                    int slot = 0, won = 0;
+                    for (int attempt = 0; attempt < 3 && xr && !won; ++attempt) {
+                        slot = (__ffsll((long long)xr) - 1 + rot) & 63;
+                        xr &= xr - 1ull;
+                        unsigned long long seen = 0ull;
+                        if (lane == 0) seen = atomicCAS(&czx_key(t)[xb0 + slot], 0ull, key);
+                        seen = __shfl(seen, 0, 64);
+                        won = seen == 0ull ? 1 : 0;
+                        if (seen == key) break;
+                    }
                     if (won) {
                         const size_t e = xb0 + slot;
                         const int n2 = t.pend_nmoves[g];

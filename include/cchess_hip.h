@@ -114,7 +114,13 @@ int cz_download(cz_ctx *, void *dst_host, const void *src_device, size_t bytes);
 /* ---- rules kernels (stand-alone, G positions per launch) -----------------------------------
  * K1  replaces GameBoard.get_legal_moves, main.py:743-1109.
  *     moves [G][128] labels in the reference's generation order (0xFFFF padding), count [G];
- *     mask [G][66] 2086-bit legality mask (bit i of word i/32).  moves or mask may be NULL. */
+ *     mask [G][66] 2086-bit legality mask (bit i of word i/32).  moves or mask may be NULL.
+ *     Alignment: `moves` must be 16-byte aligned (the list rows leave as 16-byte stores; CZ_EINVAL otherwise); boards, side,
+ *     count and mask may sit at any byte / element address (unaligned inputs take a slower staging path).
+ *     A board this library cannot be asked about answers count 0xFFFF (its list / mask row is undefined): more than 16 pieces of
+ *     the side to move, more of a kind than a Xiangqi set holds (3 rooks / cannons / knights / advisors / bishops, 6 pawns, 2
+ *     kings of the side to move — the one-lane-per-position generators take a kind's squares as the lowest and highest of its
+ *     set), or an advisor / bishop step the 2086-label vocabulary has no label for. */
 int cz_movegen(cz_ctx *, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves,
                uint16_t *count, uint32_t *mask);
 /* K2  replaces GameBoard.sim_do_action (main.py:647-702), is_kill_move (:226) and the king test

@@ -18,8 +18,8 @@ def _u16(t):
 
 
 def test_movegen_golden(rules, rules_golden):
-    """Ordered move lists, counts and 2086-bit masks of 4 381 reference positions (k_movegen: four positions per wave); and the
-    same masks and counts from the mask-only kernel (k_movegen_mask: one position per lane, no list)."""
+    """Ordered move lists, counts and 2086-bit masks of 4 381 reference positions (k_movegen_list<MASK>: one position per lane,
+    czm_list); and the same masks and counts from the mask-only kernel (k_movegen_mask: one position per lane, no list)."""
     g = rules_golden
     moves, count, mask = rules.movegen(g["boards"], g["side"])
     moves, count, mask = _u16(moves), _u16(count), mask.cpu().numpy().view(np.uint32)
@@ -126,7 +126,7 @@ def test_mask_kernel_persistent_waves_walk_many_groups(rules, rules_golden):
     _, mcount, mmask = rules.movegen(boards, side, want_moves=False)
     ref_c = torch.empty(G, dtype=mcount.dtype, device="cuda")
     ref_m = torch.empty_like(mmask)
-    for a in range(0, G, 65536):   # the list kernel in slices it handles with one group of four positions per wave
+    for a in range(0, G, 65536):   # the list kernel (k_movegen_list<MASK>) in slices of 1 024 groups of 64 positions
         _, c, m = rules.movegen(boards[a:a + 65536], side[a:a + 65536])
         ref_c[a:a + 65536] = c
         ref_m[a:a + 65536] = m
@@ -232,3 +232,27 @@ def test_movegen_mask_kernel_flags_unexpressible_positions(rules):
     assert cl[0] == 44 and cm[0] == 44
     assert cl[1] == 0xFFFF and cm[1] == 0xFFFF
     assert cl[2] == 0xFFFF and cm[2] == 0xFFFF
+
+
+def test_non_xiangqi_boards_answer_0xffff(rules):
+    """include/cchess_hip.h (cz_movegen): a board with more of a kind than a Xiangqi set holds for the side to move answers count
+    0xFFFF from both stand-alone kernels (the one-lane-per-position generators would otherwise drop that piece's moves
+    silently); with the other side to move the same board is generated normally, and list and set agree."""
+    from oracle import oracle as O
+    start = O.fen_to_board(O.START_FEN)
+    boards, sides, bad = [], [], []
+    for code in (3, 7, 5, 2, 4, 6, 1):
+        b = start.copy()
+        b[4 * 9 + 4] = code
+        for s in (0, 1):
+            boards.append(b.copy()); sides.append(s); bad.append(s == 0)
+    bt, st = torch.from_numpy(np.stack(boards)).cuda(), torch.tensor(sides, dtype=torch.uint8).cuda()
+    mv, c, m = rules.movegen(bt, st)
+    _, c2, m2 = rules.movegen(bt, st, want_moves=False)
+    c, c2 = _u16(c), _u16(c2)
+    for i, is_bad in enumerate(bad):
+        assert (c[i] == 0xFFFF) == is_bad and (c2[i] == 0xFFFF) == is_bad, (i, c[i], c2[i])
+        if not is_bad:
+            want = O.legal_moves(boards[i], sides[i])
+            assert c[i] == len(want) == c2[i] and np.array_equal(_u16(mv)[i, :c[i]], np.asarray(want, np.uint16))
+            assert torch.equal(m[i], m2[i])

@@ -116,3 +116,27 @@ def test_listgen_matches_oracle_on_random_playouts(host):
         assert np.array_equal(mv[i, :c[i]], np.asarray(want[i], np.uint16)), (i, mv[i, :c[i]], want[i])
         assert (mv[i, c[i]:] == 0xFFFF).all()
         assert np.array_equal(host.lists.last_mask[i], _mask_of(want[i])), i
+
+
+def test_boards_with_more_of_a_kind_than_a_set_holds_are_errors(host):
+    """the one-lane-per-position generators take a kind's squares as the lowest and highest of its set (pawns: five
+    iterations) — a third rook / cannon / knight / advisor / bishop, a sixth pawn or a second king of the side to move would
+    silently lose its moves.  Such a board answers -1 (count 0xFFFF through the C-ABI) from both forms; the same extra piece of
+    the side NOT to move is none of the generator's business."""
+    from oracle import oracle as O
+    start = O.fen_to_board(O.START_FEN)
+    own = {"R": 3, "C": 7, "N": 5, "A": 2, "B": 4, "P": 6, "K": 1}          # red's codes ("KARBNPCkarbnpc", code = index + 1)
+    boards, sides, bad = [], [], []
+    for kind, code in own.items():
+        for colour in (0, 1):
+            b = start.copy()
+            b[4 * 9 + 4] = code + (7 if colour else 0)                      # an extra piece of that kind in the middle of the board
+            for s in (0, 1):
+                boards.append(b.copy()); sides.append(s); bad.append(s == colour)
+    m, c = host(np.stack(boards), np.array(sides, np.uint8))
+    mv, c2 = host.lists(np.stack(boards), np.array(sides, np.uint8))
+    for i, is_bad in enumerate(bad):
+        assert (c[i] == -1) == is_bad and (c2[i] == -1) == is_bad, (i, c[i], c2[i], is_bad)
+        if not is_bad:
+            want = O.legal_moves(boards[i], sides[i])
+            assert c[i] == len(want) and np.array_equal(mv[i, :c2[i]], np.asarray(want, np.uint16))
