@@ -386,7 +386,9 @@ def main():
     from cchess_zero_amd.rules import Rules
     # one process per GPU: every rank keeps to its own CPUs (the launcher thread of a rank must not be migrated over, or
     # throttled together with, the other ranks' under the box's CPU quota)
-    cpus = PL.pin_rank_to_cpus(local_rank, world) if world > 1 else None
+    # (the rank's own LOCAL_RANK, not the device index: with --all-on-device0 every rank computes on cuda:0 but still gets its own
+    # CPU slice — the 8-rank test of round 5 found all eight ranks pinned to CPUs 0-7)
+    cpus = PL.pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     if world > 1:
         torch.set_num_threads(max(1, min(4, len(cpus) if cpus else 2)))
 

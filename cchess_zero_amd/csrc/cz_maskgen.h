@@ -232,8 +232,9 @@ CZM_FN CzmSets czm_sets(const uint32_t (&w)[23], int side) {
 // (count 0xFFFF, like a board with more than 16 own pieces), never a shorter list.
 CZM_FN int czm_popcnt(const CzmSet &s) { return __builtin_popcountll(s.lo) + __builtin_popcount(s.hi); }
 CZM_FN bool czm_not_xiangqi(const CzmSets &S) {
-    return (czm_popcnt(S.own) > 16) | (czm_popcnt(S.R) > 2) | (czm_popcnt(S.C) > 2) | (czm_popcnt(S.N) > 2) | (czm_popcnt(S.A) > 2) |
-           (czm_popcnt(S.B) > 2) | (czm_popcnt(S.P) > 5) | (czm_popcnt(S.K) > 1);
+    const int over = (int)(czm_popcnt(S.own) > 16) | (int)(czm_popcnt(S.R) > 2) | (int)(czm_popcnt(S.C) > 2) | (int)(czm_popcnt(S.N) > 2) |
+                     (int)(czm_popcnt(S.A) > 2) | (int)(czm_popcnt(S.B) > 2) | (int)(czm_popcnt(S.P) > 5) | (int)(czm_popcnt(S.K) > 1);
+    return over != 0;
 }
 // rook / cannon on square q (main.py:757-833, 947-1062): the 17-bit field of its destinations
 template <bool cannon>
@@ -285,6 +286,42 @@ CZM_FN uint32_t czm_pawn_field(const CzmSets &S, int side, int q) {
     const uint32_t fwd = (uint32_t)fin & (side ? czm_wbit(fr, 0) : czm_wbit(fr, 18));
     const int gp = side ? (y > 0 ? y - 1 : 0) : y;
     return ((lr << x) >> 1) | (fwd << (gp + 8));
+}
+// All pawns at once (round 5): which pawns may step left / right / forward as three SETS — the pawn set
+// shifted against the own-piece set — so that a pawn's three move bits are three bit tests instead of a 64-square window, its
+// bounds and river tests and the extraction per pawn (czm_pawn_field above: ~90 instructions per pawn, five pawns per position).
+struct CzmPawnSets { CzmSet l, r, f; };
+CZM_FN CzmSet czm_shl(const CzmSet &s, int n) {   // 0 < n < 32: square q -> q + n
+    return CzmSet{s.lo << n, ((s.hi << n) | (uint32_t)(s.lo >> (64 - n))) & 0x03FFFFFFu};
+}
+CZM_FN CzmSet czm_shr(const CzmSet &s, int n) {   // 0 < n < 32: square q -> q - n
+    return CzmSet{(s.lo >> n) | ((uint64_t)s.hi << (64 - n)), s.hi >> n};
+}
+CZM_FN CzmPawnSets czm_pawn_sets(const CzmSets &S, int side) {
+    // files 0 / 8 as sets: bit 9 r + x
+    const CzmSet f0 = {0x8040201008040201ull, 0x00020100u}, f8 = {0x4020100804020100ull, 0x02010080u};   // squares 0, 9, .. 81 / 8, 17, .. 89
+    const CzmSet river = side ? CzmSet{(1ull << 45) - 1ull, 0u} : CzmSet{~((1ull << 45) - 1ull), 0x03FFFFFFu};   // black: y < 5, red: y > 4
+    const CzmSet pr = czm_and(S.P, river);
+    CzmPawnSets o;
+    // left: q - 1 free of own pieces, x >= 1;  right: q + 1, x <= 7
+    o.l = CzmSet{pr.lo & ~f0.lo & ~(S.own.lo << 1), pr.hi & ~f0.hi & ~((S.own.hi << 1) | (uint32_t)(S.own.lo >> 63))};
+    o.r = CzmSet{pr.lo & ~f8.lo & ~((S.own.lo >> 1) | ((uint64_t)S.own.hi << 63)), pr.hi & ~f8.hi & ~(S.own.hi >> 1)};
+    // forward: red to q + 9 (exists for y <= 8), black to q - 9 (y >= 1)
+    const CzmSet up = czm_shr(S.own, 9), dn = czm_shl(S.own, 9);       // own piece on q + 9 / on q - 9, as a property of q
+    const CzmSet fr = side ? CzmSet{S.P.lo & ~dn.lo & ~0x1FFull, S.P.hi & ~dn.hi} : CzmSet{S.P.lo & ~up.lo, S.P.hi & ~up.hi & 0x0001FFFFu};
+    o.f = fr;
+    return o;
+}
+// the pawn on q: its field from the three sets (same layout as czm_pawn_field)
+CZM_FN uint32_t czm_pawn_field2(const CzmPawnSets &PS, int side, int q) {
+    const int y = q / 9, x = q - y * 9;
+    const bool low = q < 64;
+    const int sh = q & (low ? 63 : 31);
+    const uint32_t l = (uint32_t)((low ? PS.l.lo >> sh : (uint64_t)(PS.l.hi >> sh)) & 1ull);
+    const uint32_t r = (uint32_t)((low ? PS.r.lo >> sh : (uint64_t)(PS.r.hi >> sh)) & 1ull);
+    const uint32_t f = (uint32_t)((low ? PS.f.lo >> sh : (uint64_t)(PS.f.hi >> sh)) & 1ull);
+    const int gp = side ? (y > 0 ? y - 1 : 0) : y;
+    return (((l | (r << 1)) << x) >> 1) | (f << (gp + 8));
 }
 // advisor (kind 0; main.py:889-918: one diagonal step inside the palace) / bishop (kind 1; main.py:857-888: two diagonal steps,
 // the eye empty, own half of the board) on q: bit d = direction d ((dy,dx) = (-s,-s) (-s,+s) (+s,+s) (+s,-s)) is legal.  The
@@ -351,7 +388,8 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, E
         const uint32_t f = czm_king_field(S, side, q, eq, &fg);
         put(T.base[q], f | fg, ok);
     }
-    {   // pawns: at most five
+    {   // pawns: at most five; their move bits come from three sets computed once (czm_pawn_sets)
+        const CzmPawnSets PS = czm_pawn_sets(S, side);
         CzmSet P = S.P;
 #pragma unroll 1
         for (int it = 0; it < 5; ++it) {
@@ -359,7 +397,7 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, E
             P = czm_without(P, sq);
             const bool ok = sq >= 0;
             const int q = ok ? sq : 0;
-            put(T.base[q], czm_pawn_field(S, side, q), ok);
+            put(T.base[q], czm_pawn_field2(PS, side, q), ok);
         }
     }
     uint64_t lits = 0ull;   // the 48 advisor / bishop literals of the position (labels 2038 + l)
@@ -439,12 +477,13 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
         fg = kq >= 0 ? fg : 0u;
     }
     {
+        const CzmPawnSets PS = czm_pawn_sets(S, side);
         CzmSet P = S.P;
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int sq = czm_lowest(P);
             P = czm_without(P, sq);
-            slot(7 + it, sq, sq >= 0, czm_pawn_field(S, side, sq >= 0 ? sq : 0));
+            slot(7 + it, sq, sq >= 0, czm_pawn_field2(PS, side, sq >= 0 ? sq : 0));
         }
     }
     {

@@ -46,6 +46,7 @@ def test_bench_two_ranks_selfplay_with_timed_record_exchange():
     c = d["config"]
     assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["dist_backend"] == "gloo" and d["scaling"] == "weak"
     assert len(c["per_rank_sims_per_s"]) == 2 and all(v > 0 for v in c["per_rank_sims_per_s"])
+    assert c["rank_cpus"] is None or (len(c["rank_cpus"]) == 2 and _disjoint(c["rank_cpus"])), c["rank_cpus"]   # also with --all-on-device0
     assert c["record_gather"] is True
     sp = c["selfplay"]
     assert sp["timed_gather"] is True and sp["gathers"] >= 1 and sp["gathered_records"] > 0
@@ -121,8 +122,9 @@ def test_bench_eight_ranks_self_launch_selfplay_with_timed_exchange():
     c = d["config"]
     assert d["n_gpus"] == 8 and c["world_size"] == 8 and c["dist_backend"] == "gloo" and d["scaling"] == "weak"
     assert len(c["per_rank_sims_per_s"]) == 8 and all(v > 0 for v in c["per_rank_sims_per_s"])
-    # whole-job value against 8 copies of the fastest / the slowest rank's own rate (own = before it waits at the closing barrier)
-    assert len(c["per_rank_busy_seconds"]) == 8 and 0 < c["efficiency_vs_max_rank"] <= c["efficiency_vs_min_rank"] <= 1.0 + 1e-6
+    # whole-job value against 8 copies of the fastest / the slowest rank's own rate (own = its simulations over its time before it
+    # waits at the closing barrier; the ranks complete slightly different numbers of simulations, so "min" may pass 1 by a percent)
+    assert len(c["per_rank_busy_seconds"]) == 8 and 0 < c["efficiency_vs_max_rank"] <= 1.0 + 1e-6 and c["efficiency_vs_max_rank"] <= c["efficiency_vs_min_rank"] < 1.2
     assert c["per_rank_spread"] >= 0
     assert c["rank_cpus"] is None or (len(c["rank_cpus"]) == 8 and _disjoint(c["rank_cpus"])), c["rank_cpus"]
     assert c["record_gather"] is True and c["trees_with_error_status"] == 0
