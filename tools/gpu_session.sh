@@ -5,7 +5,7 @@
 #   bench[:args]     python bench.py <args> (default line + CPU baseline)         bench_nocpu[:args]  the same with --no-cpu-baseline
 #   profile[:dtype]  tools/profile_round.sh (rocprofv3 kernel stats + HBM PMC passes of the bench, engine <dtype>)
 #   pmcsq:<engine>   tools/pmc_mx.sh (SQ counters of one trunk engine: fp16 | x3 | mx)
-#   rules            tools/rules_bench.py (stand-alone K1 / K2 / K3 / hash kernels, 1 M positions)
+#   rules            tools/rules_bench.py (stand-alone K1 / K2 / K3 / hash kernels, 1 M positions) + its rocprofv3 kernel stats
 #   mx               tools/mx_check.py --time (the mx engine against its CPU emulation; launch times of the three fp16 engines)
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
@@ -18,7 +18,7 @@ for step in "$@"; do
     bench_nocpu) n=bench_$(echo "${arg:-default}" | tr -c 'A-Za-z0-9\n' '_'); timeout 900 python bench.py --no-cpu-baseline $arg > $O/$n.json 2> $O/$n.err; python tools/jline.py $O/$n.json | tee $O/$n.txt; cp gpurun_out/bench_detail_*.json $O/ 2>/dev/null;;
     profile) tools/profile_round.sh $TAG/prof_${arg:-fp16} ${arg:+--dtype $arg} > $O/profile_${arg:-fp16}.log 2>&1; tail -3 $O/profile_${arg:-fp16}.log;;
     pmcsq) tools/pmc_mx.sh $O/pmcsq_$arg $arg 2>&1 | tail -8 | tee $O/pmcsq_$arg.txt;;
-    rules) timeout 600 python tools/rules_bench.py > $O/rules_bench.log 2>&1; tail -12 $O/rules_bench.log;;
+    rules) timeout 600 python tools/rules_bench.py > $O/rules_bench.log 2>&1; tail -12 $O/rules_bench.log; tools/rules_profile.sh $O/rules_prof;;
     mx) timeout 600 python tools/mx_check.py --time > $O/mx_check.txt 2>&1; tail -20 $O/mx_check.txt | cut -c1-260;;
     *) echo "unknown step $step";;
   esac

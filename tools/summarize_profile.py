@@ -86,8 +86,11 @@ def main():
     # algorithmic bytes of one launch: planes in (bf16 [G][90][16]) + all folded weights once
     # (first conv 9*16*128, 2*blocks layers of 9*128*128, bf16) + biases (f32) + head conv output (f32 [G][90][3])
     rows_ = cfg.get("net_rows_per_step", G)   # compact batches: fewer rows than trees
-    halves = 2 if bline["dtype"].endswith("x2") else 1   # the strict engine streams every weight as hi + lo
-    alg = int(rows_ * 90 * 16 * 2 + (9 * 16 * 128 + 2 * blocks * 9 * 128 * 128) * 2 * halves + (2 * blocks + 1) * 128 * 4 + rows_ * 90 * 3 * 4)
+    halves = 2 if bline["dtype"].endswith("x2") else 1   # the x3 strict engine streams every weight as hi + lo
+    wbytes = (9 * 16 * 128 + 2 * blocks * 9 * 128 * 128) * 2 * halves
+    if bline["dtype"] == "mx6":   # first layer hi + lo fp16; tower: 36 slabs per layer of fp16 hi (8 KB) + fp6 blocks (6 KB) + scale dwords (1 KB)
+        wbytes = 9 * 16 * 128 * 2 * 2 + 2 * blocks * 36 * 15360
+    alg = int(rows_ * 90 * 16 * 2 + wbytes + (2 * blocks + 1) * 128 * 4 + rows_ * 90 * 3 * 4)
     tj = {"kernel": ksub, "config": {"B": G, "res_block_nums": blocks, "dtype": bline["dtype"], "compact": bool(cfg.get("compact_batches", False)),
                                      "net_rows_per_step": rows_},
           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
