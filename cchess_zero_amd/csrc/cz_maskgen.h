@@ -230,10 +230,16 @@ CZM_FN CzmSets czm_sets(const uint32_t (&w)[23], int side) {
 // rook / cannon / knight / advisor / bishop, a sixth pawn or a second king of the side to move is not a Xiangqi position, and the
 // in-search generator (czd_wave_movegen: any board) would list moves this one silently drops — so such a board is an ERROR
 // (count 0xFFFF, like a board with more than 16 own pieces), never a shorter list.
+// All eight tests in one place, right behind czm_sets, with the result pinned by an opaque barrier: left to its own scheduling
+// hipcc spread the popcounts over the function and took k_movegen_mask from 163 to 172 VGPRs (3 -> 2 waves per SIMD: -26 %) and
+// k_movegen_list<false> from 156 to 178.
 CZM_FN int czm_popcnt(const CzmSet &s) { return __builtin_popcountll(s.lo) + __builtin_popcount(s.hi); }
-CZM_FN bool czm_not_xiangqi(const CzmSets &S) {
-    const int over = (int)(czm_popcnt(S.own) > 16) | (int)(czm_popcnt(S.R) > 2) | (int)(czm_popcnt(S.C) > 2) | (int)(czm_popcnt(S.N) > 2) |
-                     (int)(czm_popcnt(S.A) > 2) | (int)(czm_popcnt(S.B) > 2) | (int)(czm_popcnt(S.P) > 5) | (int)(czm_popcnt(S.K) > 1);
+CZM_FN bool czm_not_a_set(const CzmSets &S) {   // all eight tests at once, the result pinned where it is computed
+    int over = (int)(czm_popcnt(S.own) > 16) | (int)(czm_popcnt(S.R) > 2) | (int)(czm_popcnt(S.C) > 2) | (int)(czm_popcnt(S.N) > 2) |
+               (int)(czm_popcnt(S.A) > 2) | (int)(czm_popcnt(S.B) > 2) | (int)(czm_popcnt(S.P) > 5) | (int)(czm_popcnt(S.K) > 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(over));
+#endif
     return over != 0;
 }
 // rook / cannon on square q (main.py:757-833, 947-1062): the 17-bit field of its destinations
@@ -347,14 +353,14 @@ CZM_FN uint32_t czm_diag_good(const CzmSets &S, int side, int q) {
 }
 
 // ---- the SET: czm_position.  Returns the number of legal moves, or -1 when the position is not a Xiangqi position the
-// vocabulary can express (more than 16 pieces of the side to move, or more of a kind than a Xiangqi set holds — czm_not_xiangqi;
+// vocabulary can express (more than 16 pieces of the side to move, or more of a kind than a Xiangqi set holds — czm_not_a_set;
 // an advisor / bishop move without a label).  Branch-free apart from
 // the loops: every lane runs every kind's code; a missing piece (square -1) computes on square 0 and its field is zeroed before
 // it is handed out.
 template <typename Emit>
 CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, Emit emit) {
     const CzmSets S = czm_sets(w, side);
-    bool err = czm_not_xiangqi(S);
+    bool err = czm_not_a_set(S);
     int count = 0;
     auto put = [&](int bit, uint32_t f, bool ok) {
         f = ok ? f : 0u;
@@ -454,7 +460,7 @@ CZM_FN int czm_rank_below(const CzmSet &own, int q) {   // own pieces on squares
 template <typename Put, typename Scr, typename Mid, typename Emit>
 CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put put, Scr scr, Mid mid, Emit emit) {
     const CzmSets S = czm_sets(w, side);
-    bool err = czm_not_xiangqi(S);
+    bool err = czm_not_a_set(S);
     // slots in kind order: 0, 1 rooks; 2, 3 cannons; 4, 5 knights; 6 king; 7 .. 11 pawns; 12, 13 advisors; 14, 15 bishops
     int q[16];
     uint32_t pay[16];
@@ -477,13 +483,12 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
         fg = kq >= 0 ? fg : 0u;
     }
     {
-        const CzmPawnSets PS = czm_pawn_sets(S, side);
         CzmSet P = S.P;
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int sq = czm_lowest(P);
             P = czm_without(P, sq);
-            slot(7 + it, sq, sq >= 0, czm_pawn_field2(PS, side, sq >= 0 ? sq : 0));
+            slot(7 + it, sq, sq >= 0, czm_pawn_field(S, side, sq >= 0 ? sq : 0));
         }
     }
     {

@@ -82,6 +82,17 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             if any(n in m.group(1) for n in names):   # k_select also matches k_select_k, k_expand_backup the _k variant
                 assert int(m.group(2)) == 0, "%s uses %s bytes of scratch" % (m.group(1), m.group(2))
                 checked += 1
+    # register budgets that decide occupancy (MI355X_MICROARCH.md: <= 168 VGPRs for 3 waves per SIMD, <= 64 for 8): round 5 lost 26 %
+    # of k_movegen_mask to nine registers (163 -> 172) without any test noticing
+    budgets = {"k_movegen_mask": 168, "k_movegen_listILb0": 168, "k_movegen_listILb1": 256, "k_trunk_mx_c128": 256, "k_trunk_split_c128": 256, "k_tower8_c128": 256}
+    seen = set()
+    for src in ("cz_rules.hip", "cz_conv.hip"):
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", texts[src]):
+            for name, lim in budgets.items():
+                if name in m.group(1):
+                    assert int(m.group(2)) <= lim, "%s uses %s VGPRs (budget %d)" % (m.group(1), m.group(2), lim)
+                    seen.add(name)
+    assert seen == set(budgets), seen
     # 2 + 2 + 1 trunk instantiations; 4 select + 2 select_k + 3 expand + 2 expand_k + advance + root_stats; 2 heads; 3 rules; 3 self-play
     assert checked >= 5 + 13 + 2 + 3 + 3, checked   # (k_movegen also matches k_movegen_mask)
 

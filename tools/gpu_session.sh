@@ -16,9 +16,13 @@ for step in "$@"; do
     smoke) ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log ); tail -3 $O/smoke.log;;
     bench) n=bench_$(echo "${arg:-default}" | tr -c 'A-Za-z0-9\n' '_'); timeout 900 python bench.py $arg > $O/$n.json 2> $O/$n.err; python tools/jline.py $O/$n.json | tee $O/$n.txt; cp gpurun_out/bench_detail_*.json $O/ 2>/dev/null;;
     bench_nocpu) n=bench_$(echo "${arg:-default}" | tr -c 'A-Za-z0-9\n' '_'); timeout 900 python bench.py --no-cpu-baseline $arg > $O/$n.json 2> $O/$n.err; python tools/jline.py $O/$n.json | tee $O/$n.txt; cp gpurun_out/bench_detail_*.json $O/ 2>/dev/null;;
-    profile) tools/profile_round.sh $TAG/prof_${arg:-fp16} ${arg:+--dtype $arg} > $O/profile_${arg:-fp16}.log 2>&1; tail -3 $O/profile_${arg:-fp16}.log;;
+    profile) d=${arg:-fp16}; tools/profile_round.sh $TAG/prof_$d ${arg:+--dtype $arg} > $O/profile_$d.log 2>&1
+             # summarised HERE (the raw traces are tens of MB and gpurun merges at most 64 MiB back): profiles_out/ holds what goes to profiles/
+             case $d in mx6) k=k_trunk_mx; sfx=_mx;; fp16x2) k=k_trunk_split; sfx=_strict;; *) k=k_tower8; sfx="";; esac
+             PROFILES_OUT=$O/profiles_out python tools/summarize_profile.py gpurun_out/$TAG/prof_$d r05_$d $k $sfx > $O/summary_$d.log 2>&1; tail -4 $O/summary_$d.log
+             rm -rf gpurun_out/$TAG/prof_$d/stats gpurun_out/$TAG/prof_$d/pmc_f gpurun_out/$TAG/prof_$d/pmc_w;;
     pmcsq) tools/pmc_mx.sh $O/pmcsq_$arg $arg 2>&1 | tail -8 | tee $O/pmcsq_$arg.txt;;
-    rules) timeout 600 python tools/rules_bench.py > $O/rules_bench.log 2>&1; tail -12 $O/rules_bench.log; tools/rules_profile.sh $O/rules_prof;;
+    rules) timeout 600 python tools/rules_bench.py > $O/rules_bench.log 2>&1; tail -12 $O/rules_bench.log; tools/rules_profile.sh $O/rules_prof; rm -rf $O/rules_prof/stats;;
     mx) timeout 600 python tools/mx_check.py --time > $O/mx_check.txt 2>&1; tail -20 $O/mx_check.txt | cut -c1-260;;
     *) echo "unknown step $step";;
   esac

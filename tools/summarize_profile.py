@@ -36,7 +36,8 @@ def main():
     src, rnd = sys.argv[1], sys.argv[2]
     ksub = sys.argv[3] if len(sys.argv) > 3 else "k_tower8_c128"
     sfx = sys.argv[4] if len(sys.argv) > 4 else ""
-    prof = os.path.join(ROOT, "profiles")
+    prof = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")   # PROFILES_OUT: summarise on the GPU box into gpurun_out/
+    os.makedirs(prof, exist_ok=True)
     stats = find(os.path.join(src, "stats"), "*kernel_stats.csv")
     shutil.copy(stats, os.path.join(prof, rnd + "_kernel_stats.csv"))
     bline = None
