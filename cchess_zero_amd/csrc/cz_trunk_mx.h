@@ -167,7 +167,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
         const int delta = (tap / 3 - 1) * 20 + (tap - (tap / 3) * 3 - 1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int kk = (rowk[i] < 0 ? 0 : rowk[i]) + delta;
+            // a padding lane (rowk < 0, every tap masked) keeps its OWN virtual row: with row 0 for all twelve of them their zero-row
+            // slot / alias entry collided with the real row lane 12 reads (8.5 % of the LDS cycles in bank conflicts, round 5)
+            const int kk = rowk[i] + delta;
             const bool on = (tapmask[i] >> tap) & 1;
             const int rb = Geo::HI_OFF + kk * CV_ROWB;
             ab[i] = on ? rb : Geo::ZERO_OFF;

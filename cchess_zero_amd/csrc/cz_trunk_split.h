@@ -178,7 +178,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_split_c128(const uint16_t *__r
         const int k = 32 * (wr * 3 + i) + l31 - 12;       // LDS row; k < 0: one of the 12 padding rows
         const int kk = k < 0 ? 0 : k;
         const int h = kk / 20, rem = kk - h * 20, pp = rem / 10, w = rem - pp * 10;
-        rowb[i] = kk * CV_ROWB;
+        rowb[i] = k * CV_ROWB;   // a padding lane (k < 0, every tap masked) keeps its own virtual row for the zero row's slot: with row 0 for all
+                                 // twelve their slot collided with the real row lane 12 reads (10.6 % of the LDS cycles in bank conflicts)
         natb[i] = (pp * 90 + h * 10 + w) * 32;           // the cell's 32 bytes of input planes (natural order)
         int m = 0;
         for (int t = 0; t < 9; ++t) {

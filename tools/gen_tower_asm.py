@@ -188,7 +188,7 @@ def slabMX(hs):
     if place == "Cend":
         L += dma1 + dma2
     L += ["s_mov_b32 m0, %[keep]"]
-    # timing ablations (tools/experiments/mx_ablate.sh; wrong results): MX_ABLATE = comma list of nobarrier, bar2 (barrier in
+    # timing ablations (tools/experiments/mx_ablate.sh; wrong results): MX_ABLATE = comma list of nolgkmwait, novmwait, nobarrier, bar2 (barrier in
     # every other slab), noc (no fp6 operand reads), nomx (no fp6 MFMAs), nodma, nohi (no fp16 operand reads)
     ab = [a for a in os.environ.get("MX_ABLATE", "").split(",") if a]
     if "nobarrier" in ab or ("bar2" in ab and hs % 2 == 1):
@@ -201,6 +201,8 @@ def slabMX(hs):
         L = [l.replace("lgkmcnt(4)", "lgkmcnt(0)") for l in L]
     if "nomx" in ab:
         L = [l for l in L if not l.startswith("v_mfma_scale")]
+    if "nolgkmwait" in ab:    # operands are never waited for: what perfect latency hiding of the LDS reads would buy (same LDS traffic)
+        L = [l for l in L if not l.startswith("s_waitcnt lgkmcnt")]
     if "novmwait" in ab:      # the DMAs are issued but never waited for: issue cost vs waiting for the data
         L = [l.replace("s_waitcnt vmcnt(2)", "s_nop 0") for l in L]
     if "nodma" in ab:
