@@ -512,9 +512,12 @@ class cchess_main(object):
                           # the evaluation cache pays from a few hundred playouts per move on (in-tree repeat rate 1 % at 100
                           # playouts, 4 % at 400, 12 % at 1600; the lookup costs the select launch 10-25 us)
                           eval_cache=self.playout_counts >= 400,
-                          # ... and its cross-tree level: every game starts from the same position, the openings are shared
-                          # (2**18 entries = 285 MB)
-                          xcache_log2=18 if self.playout_counts >= 400 else 0,
+                          # ... and its cross-tree level: every game starts from the same position, the openings are shared.  Sized
+                          # for the 288 GB of the MI355X: ~2 048 entries of 1 088 bytes per game slot (256 games: 2**19 = 0.6 GB,
+                          # 8192 games: 2**24 = 18 GB) — measured at 8192 games x 1600 playouts over 48 000 lock-steps
+                          # (profiles/r05j_*, r05o_*): no cache 3.61 M simulations/s, per-tree level 3.96 M, 2**22 entries
+                          # 4.16 M, 2**24 entries 4.38 M (+21.6 %); the write-once table is full either way
+                          xcache_log2=min(24, max(18, (G * 2048 - 1).bit_length())) if self.playout_counts >= 400 else 0,
                           # a drain interval can end every game of every slot in the worst case: room for ~160 plies per slot
                           ring_records=max(65536, 160 * G))
             b0 = np.tile(state_to_board(START_STATE), (G, 1))
