@@ -203,13 +203,23 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
     alg = 312.0 * n
     abi = (90 + 1 + 264 + 2) * float(n)
     abi_list = (90 + 1 + 256 + 264 + 2) * float(n)
+    # counter traffic of the same launch shapes (tools/pmc_rules.sh -> profiles/pmc_rules_traffic.json), attached when the size matches
+    tr_mask, tr_list, tr_src = None, None, "no committed PMC measurement at %d positions" % n
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_rules_traffic.json")))
+        if int(tj.get("positions", -1)) == n:
+            tr_mask = tj["kernels"]["k_movegen_mask"]["traffic_bytes_per_launch"]
+            tr_list = tj["kernels"]["k_movegen_list<true>"]["traffic_bytes_per_launch"]
+            tr_src = "profiles/pmc_rules_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+    except (OSError, ValueError, KeyError) as e:
+        tr_src = "profiles/pmc_rules_traffic.json unusable: %r" % (e,)
     return {"bound": "hbm", "kernel": "k_movegen_mask (stand-alone K1, the legal-move SET: 2086-bit mask + count, one position per lane, register bit sets; inside the search the ordered generator runs in k_select)",
-            "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": tr_mask, "traffic_source": tr_src,
             "positions": n, "positions_per_s": n / sec, "us_per_launch": sec * 1e6, "algorithmic_bytes_per_position": 312,
             "abi_bytes_per_position": abi / n, "abi_GBps": abi / sec / 1e9,
             "ordered_list_kernel": {"kernel": "k_movegen_list<MASK> (ordered move list in the reference's generation order and the mask from one launch: one position per lane)",
                                     "positions_per_s": n / sec_list, "us_per_launch": sec_list * 1e6, "achieved": alg / sec_list / 1e9,
-                                    "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "abi_bytes_per_position": abi_list / n, "abi_GBps": abi_list / sec_list / 1e9,
+                                    "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "traffic": tr_list, "abi_bytes_per_position": abi_list / n, "abi_GBps": abi_list / sec_list / 1e9,
                                     "note": "issue-bound (VALU: the per-kind generation, the ordering by square, one LDS write per move), not bandwidth-bound: see DESIGN.md 4.6b"}}
 
 
@@ -264,7 +274,7 @@ def compact_line(full):
         o = dict(_pick(rr, ["bound", "achieved", "peak", "unit", "frac", "traffic", "positions", "positions_per_s", "us_per_launch"]), kernel="k_movegen_mask")
         ol = rr.get("ordered_list_kernel")
         if ol:
-            o["ordered_list_kernel"] = dict(_pick(ol, ["positions_per_s", "frac", "us_per_launch"]), kernel="k_movegen_list<MASK>")
+            o["ordered_list_kernel"] = dict(_pick(ol, ["positions_per_s", "frac", "us_per_launch", "traffic"]), kernel="k_movegen_list<MASK>")
         out["roofline_rules"] = o
     else:
         out["roofline_rules"] = rr

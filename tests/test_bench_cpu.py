@@ -25,7 +25,14 @@ def test_committed_pmc_traffic_files_match_what_bench_looks_up():
         assert (cfg["B"], cfg["res_block_nums"], cfg["dtype"], bool(cfg.get("compact", False))) == (8192, 7, dtype_of[kernel], False), (fname, cfg)
         assert tj["traffic_bytes_per_launch"] >= tj["algorithmic_bytes_per_launch"] > 30e6
         assert set(bench.TRUNK_KERNEL[d] for d in bench.TRUNK_KERNEL) == set(bench.TRAFFIC_FILE)
-    assert seen >= 2
+    assert seen >= 3
+    # the rules kernels' counter traffic: measured at the size bench.py's rules_roofline uses, and equal to the ABI bytes (the
+    # set form reads 91 B and writes 266 B per position: nothing is re-read)
+    rj = json.load(open(os.path.join(ROOT, "profiles", "pmc_rules_traffic.json")))
+    assert rj["positions"] == 1 << 20
+    m = rj["kernels"]["k_movegen_mask"]["traffic_bytes_per_launch"] / float(1 << 20)
+    assert 350 < m < 365, m
+    assert 600 < rj["kernels"]["k_movegen_list<true>"]["traffic_bytes_per_launch"] / float(1 << 20) < 630
 
 
 def test_compact_line_is_small_and_carries_the_contract_numbers():
