@@ -280,10 +280,12 @@ class PolicyValueNet:
         dtype: fp16 is the default — the same MFMA rate as bf16 on gfx950 with 11 instead of 8 mantissa bits per stored
         activation: 7 blocks stay within north_star's 1e-3 of the fp32 graph on TF-default weights (|dlogit| 1.2e-4) and
         within 1.1e-3 of the largest logit on peaked, trained-like weights (bf16: 9e-3; tests/test_net.py).
-        split: the STRICT engine (k_trunk_split_c128): every weight and every stored activation is carried as hi + lo, two
-        values of `dtype` (22 significant bits for fp16, 16 for bf16), three MFMAs per product — north_star's 1e-3 against
-        the fp32 graph also on peaked, trained-like weights and at 19 blocks (measured 2e-5 / 1e-4), at a third of the
-        16-bit engine's rate.  hip backend only."""
+        split: the STRICT engines (hip backend only).  True / "x3" = k_trunk_split_c128: every weight and every stored
+        activation is carried as hi + lo, two values of `dtype` (22 significant bits for fp16, 16 for bf16), three MFMAs per
+        product — north_star's 1e-3 against the fp32 graph also on peaked, trained-like weights and at 19 blocks (measured
+        2e-5 / 1e-4), at a third of the 16-bit engine's rate.  "mx" = k_trunk_mx_c128 (fp16 only): the hi halves on fp16 MFMAs,
+        both cross terms of the split on one block-scaled fp6 MFMA: 1.5 MFMA-equivalents per product, half the 16-bit engine's
+        rate, 5e-4 / 2e-4 at 7 blocks (1.0e-3 / 1.1e-3 at 19).  "strict" = "mx" up to MX_DEPTH_LIMIT blocks, "x3" beyond."""
         self.device = torch.device(device)
         self.dtype = dtype
         # split: False | True (= "x3": k_trunk_split_c128, three MFMAs per product) | "mx" (k_trunk_mx_c128: fp16 hi halves +
