@@ -57,6 +57,24 @@ def test_compact_line_is_small_and_carries_the_contract_numbers():
     assert set(line["roofline_rules"]) >= {"bound", "achieved", "peak", "unit", "frac"}
 
 
+def test_round5_record_compacts_to_the_committed_line():
+    """profiles/r05_bench_default_detail.json (the complete record of a default run at HEAD) -> compact_line == the line that run
+    printed (profiles/r05_bench_default_line.json), under 8 KB, with the strict engine's kernel, rate, roofline fraction and
+    measured errors at the top level."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_detail.json")))
+    line = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05_bench_default_line.json")) if l.startswith("{")][-1])
+    got = bench.compact_line(full)
+    got["detail_file"] = line["detail_file"]
+    assert json.loads(json.dumps(got)) == line
+    assert len(json.dumps(line)) < 8000
+    se = line["strict_engine"]
+    assert se["kernel"] == "k_trunk_mx_c128" and se["dtype"] == "mx6" and se["value"] > 1.7e6 and 0.25 < se["frac"] < 0.35
+    assert se["dlogit_trained_like"] <= 1e-3 and se["dvalue_trained_like"] <= 1e-3 and se["meets_1e-3_abs_logit_and_value"] is True
+    assert line["roofline"]["traffic"] and line["roofline"]["kernel"] == "k_tower8_c128" and line["engine"].startswith("k_tower8_c128")
+    assert line["cpu_baseline"]["reference_python"]["measured_in_this_run"] is False      # the GPU box has no /root/reference
+
+
 def test_reference_python_flag(monkeypatch):
     """cpu_baseline.reference_python.measured_in_this_run: True only when /root/reference was imported and timed in this run."""
     import bench
