@@ -38,14 +38,15 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
+from cchess_zero_amd.net import MX_DEPTH_LIMIT   # precision "strict": mx6 up to this depth (before the self-check), fp16x2 beyond
+from cchess_zero_amd.rules import START_BOARD
+
+START = START_BOARD
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp16x2": 2500.0, "bf16x2": 2500.0, "mx6": 2500.0}  # dense peaks, same guide (x2 / mx6: the strict engines; algorithmic flops of the fp32 graph against the 16-bit MFMA peak)
-MX_DEPTH_LIMIT = 8           # cchess_zero_amd.net.MX_DEPTH_LIMIT: precision "strict" = mx6 up to this depth, fp16x2 beyond
 TRUNK_KERNEL = {"fp16": "k_tower8_c128", "bf16": "k_tower8_c128", "fp16x2": "k_trunk_split_c128", "bf16x2": "k_trunk_split_c128", "mx6": "k_trunk_mx_c128"}
 TRAFFIC_FILE = {"k_tower8_c128": "pmc_traffic.json", "k_trunk_split_c128": "pmc_traffic_strict.json", "k_trunk_mx_c128": "pmc_traffic_mx.json"}
-
-START = np.array([3, 5, 4, 2, 1, 2, 4, 5, 3] + [0] * 9 + [0, 7, 0, 0, 0, 0, 0, 7, 0] + [6, 0, 6, 0, 6, 0, 6, 0, 6] + [0] * 18 +
-                 [13, 0, 13, 0, 13, 0, 13, 0, 13] + [0, 14, 0, 0, 0, 0, 0, 14, 0] + [0] * 9 + [10, 12, 11, 9, 8, 9, 11, 12, 10], np.uint8)
 
 # The unmodified reference (pure Python) timed in the build container — it cannot run on the GPU box, where
 # /root/reference does not exist; recorded in BASELINE.md and attached to the line as static, labelled fields.
@@ -66,31 +67,9 @@ def default_nodes_per_tree(playout):
 
 
 def synth_positions(rules, G, seed, max_ply=80):
-    """Seeded uniform-random playouts from the start position, ply ~ U[0, max_ply] per game, all on the GPU
-    (K1 movegen -> random pick -> K2 apply).  Games whose king would be captured stop early."""
-    dev = rules.dev
-    gen = torch.Generator(device=dev).manual_seed(seed)
-    boards = torch.from_numpy(np.tile(START, (G, 1))).to(dev)
-    side = torch.zeros(G, dtype=torch.uint8, device=dev)
-    rr = torch.zeros(G, dtype=torch.int32, device=dev)
-    target = torch.randint(0, max_ply + 1, (G,), generator=gen, device=dev)
-    alive = torch.ones(G, dtype=torch.bool, device=dev)
-    for ply in range(max_ply):
-        moves, count, _ = rules.movegen(boards, side, want_mask=False)
-        cnt = count.to(torch.int64) & 0xFFFF
-        go = alive & (target > ply) & (cnt > 0)
-        r = (torch.rand(G, generator=gen, device=dev) * cnt.clamp(min=1)).to(torch.int64).clamp(max=127)
-        pick = moves.gather(1, r.unsqueeze(1)).squeeze(1)
-        # do not play a king capture: keep both kings on the board for the search roots
-        nb, ns = boards.clone(), side.clone()
-        lab = torch.where(go, pick, torch.full_like(pick, -1))
-        cap, term = rules.apply_move(nb, ns, lab)
-        ok = go & (term == 0)
-        boards = torch.where(ok.unsqueeze(1), nb, boards)
-        side = torch.where(ok, ns, side)
-        rr = torch.where(ok, torch.where(cap != 0, torch.zeros_like(rr), rr + 1), rr)
-        alive = alive & (ok | ~go)
-    return boards.contiguous(), side.contiguous(), rr.contiguous()
+    """SURVEY 8(d)'s synthetic positions: cchess_zero_amd.rules.random_positions (seeded random playouts on the GPU)."""
+    from cchess_zero_amd.rules import random_positions
+    return random_positions(rules, G, seed, max_ply)
 
 
 # ---- CPU baseline: the C oracle's search + a torch-CPU (oneDNN) fp32 net on this host's cores -----------------------------
@@ -233,24 +212,26 @@ def compact_line(full):
     per-kernel explanations — goes to the side file named in `detail_file` (tools/jline.py reads either)."""
     out = _pick(full, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                        "dtype", "data", "engine", "value_source"])
-    st = full.get("strict_engine")
-    if st:
-        se = _pick(st, ["dtype", "kernel", "value", "unit", "ms_per_step", "steps", "meets_target_1e6_sims_per_s_per_gpu"])
-        r = st.get("roofline") or {}
-        se.update({"frac": r.get("frac"), "achieved_TFLOPs": r.get("achieved"), "us_per_launch": r.get("us_per_launch"), "traffic": r.get("traffic")})
-        ne = st.get("net_error") or {}
-        for k in ("as_benchmarked_glorot", "trained_like"):
-            if k in ne:
-                se["dlogit_" + k] = ne[k].get("dlogit")
-                se["dvalue_" + k] = ne[k].get("dvalue")
-        se["meets_1e-3_abs_logit_and_value"] = ne.get("meets_1e-3_abs_logit_and_value")
-        out["strict_engine"] = se
-    else:
-        out["strict_engine"] = None
+    out["strict_check"] = full.get("strict_check")
+    for leg_key in ("strict_engine", "fast_engine"):   # the OTHER engine's leg (strict_engine in a fast run, fast_engine in a strict run)
+        st = full.get(leg_key)
+        if st:
+            se = _pick(st, ["dtype", "kernel", "value", "unit", "ms_per_step", "steps", "meets_target_1e6_sims_per_s_per_gpu"])
+            r = st.get("roofline") or {}
+            se.update({"frac": r.get("frac"), "achieved_TFLOPs": r.get("achieved"), "us_per_launch": r.get("us_per_launch"), "traffic": r.get("traffic")})
+            ne = st.get("net_error") or {}
+            for k in ("as_benchmarked_glorot", "trained_like"):
+                if k in ne:
+                    se["dlogit_" + k] = ne[k].get("dlogit")
+                    se["dvalue_" + k] = ne[k].get("dvalue")
+            se["meets_1e-3_abs_logit_and_value"] = ne.get("meets_1e-3_abs_logit_and_value")
+            if full.get("n_gpus", 1) > 1:
+                se["per_rank_sims_per_s"] = st.get("per_rank_sims_per_s")
+            out[leg_key] = se
+        else:
+            out[leg_key] = None
     for k in ("steady_state", "contract_steps"):
         out[k] = _pick(full.get(k) or {}, ["steps", "seconds", "value", "ms_per_step", "simulations_per_net_row", "per_rank_sims_per_s"]) or None
-    if st and full.get("n_gpus", 1) > 1:
-        out["strict_engine"]["per_rank_sims_per_s"] = st.get("per_rank_sims_per_s")
     c = full.get("config") or {}
     out["config"] = _pick(c, ["workload", "games_per_gpu", "playout", "res_block_nums", "world_size", "dist_backend", "per_rank_sims_per_s",
                               "efficiency_vs_min_rank", "efficiency_vs_max_rank", "per_rank_spread", "per_rank_busy_seconds", "rank_cpus", "search_threads", "simulations_per_net_row", "net_rows_per_step",
@@ -281,7 +262,9 @@ def compact_line(full):
     ne = full.get("net_error")
     if ne and "as_benchmarked_glorot" in ne:
         out["net_error"] = {k: _pick(ne[k], ["dlogit", "dvalue", "max_abs_logit", "argmax_agree"]) for k in ("as_benchmarked_glorot", "trained_like") if k in ne}
-        out["net_error"].update(_pick(ne, ["meets_1e-3_abs_logit_and_value_as_benchmarked", "meets_1e-3_abs_logit_and_value_trained_like"]))
+        out["net_error"].update(_pick(ne, ["meets_1e-3_abs_logit_and_value_as_benchmarked", "meets_1e-3_abs_logit_and_value_trained_like", "probe_informative"]))
+        if "strict_on_trained_like" in ne:
+            out["net_error"]["strict_on_trained_like"] = _pick(ne["strict_on_trained_like"], ["engine", "dlogit", "dvalue", "fell_over_from"])
     else:
         out["net_error"] = ne
     cb = full.get("cpu_baseline")
@@ -331,11 +314,11 @@ def main():
     ap.add_argument("--games", type=int, default=8192, help="game trees per GPU")
     ap.add_argument("--playout", type=int, default=1600)
     ap.add_argument("--blocks", type=int, default=7)
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp16x2", "bf16x2", "mx6", "strict"],
-                    help="engine of the tower (fp32 accumulate).  fp16 (default): one fp16 per operand (k_tower8_c128), the same MFMA rate as bf16 on gfx950 and 8x closer to the fp32 graph (see net_error in the output).  The STRICT engines keep north_star's 1e-3 against fp32 on trained-like weights: mx6 = fp16 hi halves + both cross terms of the hi + lo split on one block-scaled fp6 MFMA (k_trunk_mx_c128, 1.5 MFMA-equivalents per product; holds 1e-3 with a factor of two to spare up to 8 blocks); fp16x2 / bf16x2 = hi + lo halves of that type, three MFMAs per product (k_trunk_split_c128; also 19 blocks); strict = mx6 up to 8 blocks, fp16x2 beyond (the default of policy_value_network() and main.py)")
+    ap.add_argument("--dtype", default="strict", choices=["bf16", "fp16", "fp32", "fp16x2", "bf16x2", "mx6", "strict"],
+                    help="engine of the tower (fp32 accumulate).  strict (default since round 6: the engine policy_value_network() and main.py run, so `value` and `roofline` are the product's): the net measures itself against fp32 on its weights and runs the cheapest engine of mx6 -> fp16x2 -> fp32 inside 5e-4 (mx6 up to 8 blocks on the bench's weights, fp16x2 beyond); the fast fp16 engine is then timed as the fast_engine leg.  mx6 = fp16 hi halves + both cross terms of the hi + lo split on one block-scaled fp6 MFMA (k_trunk_mx_c128, 1.5 MFMA-equivalents per product); fp16x2 / bf16x2 = hi + lo halves of that type, three MFMAs per product (k_trunk_split_c128; also 19 blocks); fp16: one fp16 per operand (k_tower8_c128), twice the rate, 1e-3 only relative to the logit scale (see net_error in the output); with fp16 / bf16 the strict engine is the extra leg")
     ap.add_argument("--age-steps", type=int, default=800, help="untimed lock-steps BEFORE --warmup that bring every tree to a representative phase of its search: each tree's first search is cut at its own threshold (uniform in [8, age-steps] simulations), so when the timed region starts the trees are spread over the phases of a playout-long search on subtrees kept from a previous ply — the state of a long run — instead of all standing 25 simulations into a fresh search")
     ap.add_argument("--steady-steps", type=int, default=2000, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
-    ap.add_argument("--strict-steps", type=int, default=240, help="lock-steps of a third timed region in which the SAME trees are searched with the strict engine of this depth (k_trunk_mx_c128 up to 8 blocks, k_trunk_split_c128 beyond: 1e-3 of fp32 on trained-like weights) — the strict_engine block of the output; 0 = off; ignored when --dtype already names a strict engine")
+    ap.add_argument("--alt-steps", "--strict-steps", dest="alt_steps", type=int, default=240, help="lock-steps of a third timed region in which the SAME trees are searched with the OTHER engine: the fast fp16 engine (k_tower8_c128; the fast_engine block of the output) when the run's engine is a strict one, the strict engine of this depth (the strict_engine block) when --dtype is fp16 / bf16; 0 = off")
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="conv backend of the net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only for single-GPU smoke tests of the N>1 path")
@@ -356,10 +339,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="testing only: initialise the process group and run every collective even with a world of 1 (RCCL API check on one GPU)")
     ap.add_argument("--start-position", action="store_true", help="--selfplay: every game starts from the start position (default: the synthetic positions)")
     args = ap.parse_args()
-    if args.dtype == "strict":
+    asked_strict = args.dtype == "strict"
+    if asked_strict:   # where the ladder starts; the net's own measurement (strict_check, below) has the last word
         args.dtype = "mx6" if args.blocks <= MX_DEPTH_LIMIT else "fp16x2"
-    mx = args.dtype == "mx6"
-    split = args.dtype.endswith("x2") or mx
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -407,21 +389,34 @@ def main():
     cap = args.nodes_per_tree or default_nodes_per_tree(playout)
     ctx = Context(G, cap, local_rank)
     rules = Rules(ctx)
-    # planes are written by k_select directly in the fused net kernel's input format (bf16, 16 channels)
-    fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16", "fp16x2", "bf16x2", "mx6")
     K = max(1, args.search_threads)
     if args.selfplay and K != 1:
         ap.error("--selfplay runs one simulation in flight per tree")
+    SPLIT_OF = {"mx6": "mx", "fp16x2": True, "bf16x2": True}
+    strict_report = None
+    if asked_strict:
+        # the product's default engine, chosen the product's way: the ladder mx6 -> fp16x2 -> fp32 measured on these weights
+        net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend="hip", ctx=ctx, split="strict")
+        strict_report = net.strict_check()
+        args.dtype = net.engine_name
+        if args.dtype == "fp32":
+            tdt = torch.float32
+    else:
+        net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split=SPLIT_OF.get(args.dtype, False))
+    mx = args.dtype == "mx6"
+    split = args.dtype.endswith("x2") or mx
+    # planes are written by k_select directly in the fused net kernel's input format (its 16-bit type, 16 channels)
+    fused = (args.backend in ("auto", "hip")) and args.dtype in ("bf16", "fp16", "fp16x2", "bf16x2", "mx6")
     eng = SearchEngine(G, cap, local_rank, plane_dtype=tdt if fused else torch.float32, channels=16 if fused else 14, ctx=ctx, width=K)
-    net = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split="mx" if mx else split)
     if args.full_policy_fc:
         net.fuse_policy_fc = False
     fused_fc = net.fused_search and K == 1
     compact = fused_fc and args.compact   # leaves that need no net evaluation are not in the net's batch
     eng.compact = compact
     boards, side, rr = synth_positions(rules, G, seed=1000 + rank)
+    probe_boards, probe_side = boards[:256].clone(), side[:256].clone()   # the net-error block measures on these whatever the roots are
     if args.selfplay and args.start_position:
-        boards = torch.from_numpy(np.tile(START, (G, 1))).to(dev)
+        boards = torch.from_numpy(np.tile(START_BOARD, (G, 1))).to(dev)
         side, rr = torch.zeros_like(side), torch.zeros_like(rr)
 
     ev = []        # per sampled step: (before select, after select, after net, after expand) HIP events
@@ -448,7 +443,7 @@ def main():
     gather_ok = None   # N > 1: result of the (untimed) record all-gather
     banked = torch.zeros(1, dtype=torch.int64, device=dev)   # simulations of the searches closed by an advance
     reloaded = torch.zeros(1, dtype=torch.int64, device=dev)  # games that ended and started afresh
-    start_boards = torch.from_numpy(np.tile(START, (G, 1))).to(dev)
+    start_boards = torch.from_numpy(np.tile(START_BOARD, (G, 1))).to(dev)
     start_side, start_rr = torch.zeros(G, dtype=torch.uint8, device=dev), torch.zeros(G, dtype=torch.int32, device=dev)
     TE = max(0, args.terminal_extra) if K == 1 else 0
 
@@ -650,18 +645,22 @@ def main():
                 clock = probe.mean()
         except Exception as e:
             print("bench: telemetry read-out failed (%r)" % (e,), file=sys.stderr)
-    strict_leg = None
-    if args.strict_steps > 0 and fused and not split and not sp and net.backend == "hip":
-        # the same trees, the same loop, the strict engine: weights shared with the benchmarked net
-        net_s = PolicyValueNet(args.blocks, dev, torch.float16, backend="hip", ctx=ctx, split="strict", module=net.module)
-        if tdt != torch.float16:   # the planes buffer is written in the benchmarked engine's type: a bf16 run gets bf16 halves
-            net_s = PolicyValueNet(args.blocks, dev, tdt, backend="hip", ctx=ctx, split=True, module=net.module)
-        net_s.fuse_policy_fc = net.fuse_policy_fc
-        cur.update(net=net_s, conv_ev=[], ev=[])
-        run(8, False)
-        leg = timed_region(args.strict_steps)
-        strict_leg = (leg, cur["conv_ev"], net_s)
-        cur.update(net=net, conv_ev=conv_ev, ev=ev)
+    strict_leg = None     # the OTHER engine on the same trees and loop (weights shared): (leg, events, net, "strict_engine" | "fast_engine")
+    if args.alt_steps > 0 and fused and not sp and net.backend == "hip":
+        if split:   # the run's engine is a strict one: the fast engine of the same 16-bit type (the planes buffer is in that type)
+            net_s, alt_key = PolicyValueNet(args.blocks, dev, tdt, backend="hip", ctx=ctx, split=False, module=net.module), "fast_engine"
+        elif tdt == torch.float16:
+            net_s, alt_key = PolicyValueNet(args.blocks, dev, tdt, backend="hip", ctx=ctx, split="strict", module=net.module), "strict_engine"
+            net_s.strict_check()
+        else:       # a bf16 run gets bf16 halves
+            net_s, alt_key = PolicyValueNet(args.blocks, dev, tdt, backend="hip", ctx=ctx, split=True, module=net.module), "strict_engine"
+        if net_s.backend == "hip":
+            net_s.fuse_policy_fc = net.fuse_policy_fc
+            cur.update(net=net_s, conv_ev=[], ev=[])
+            run(8, False)
+            leg = timed_region(args.alt_steps)
+            strict_leg = (leg, cur["conv_ev"], net_s, alt_key)
+            cur.update(net=net, conv_ev=conv_ev, ev=ev)
     if dist_on:
         # outside the timed regions: the record exchange of the self-play loop (all-gather of packed (s, pi, z) records,
         # device-resident end to end; both the sized and the fixed-capacity form) on a ragged token batch, so every N>1 run
@@ -879,19 +878,22 @@ def main():
                            "game_generations": s["games"] / float(G), "timed_gather": bool(args.timed_gather and dist_on),
                            "gathers": gather_stats["gathers"], "gathered_records": gather_stats["records"],
                            "gather_seconds_rank0": gather_stats["seconds"], "pending_after_flush": gather_stats.get("pending_after_flush")}
-    strict_out = None
+    strict_out, alt_key = None, None
     if strict_leg is not None:
-        leg, s_ev, net_s = strict_leg
+        leg, s_ev, net_s, alt_key = strict_leg
         s_sims, s_rows, s_pr = totals(leg)
-        s_kernel = "k_trunk_mx_c128" if net_s.mx else "k_trunk_split_c128"
-        s_dtype = "mx6" if net_s.mx else ("fp16x2" if net_s.dtype == torch.float16 else "bf16x2")
-        strict_out = {"engine": {"mx6": "k_trunk_mx_c128: fp16 hi halves on fp16 MFMAs + both cross terms of the hi + lo split on one block-scaled fp6 MFMA, 1.5 MFMA-equivalents per product (bench.py --dtype strict times it on its own)",
-                                 "fp16x2": "k_trunk_split_c128: every weight and stored activation as fp16 hi + lo halves, three MFMAs per product (bench.py --dtype strict times it on its own)",
-                                 "bf16x2": "k_trunk_split_c128, bf16 halves"}[s_dtype], "dtype": s_dtype, "kernel": s_kernel,
-                      "steps": args.strict_steps, "seconds": leg[0], "value": s_sims / leg[0], "unit": "sims/s",
-                      "ms_per_step": leg[0] / args.strict_steps * 1e3, "net_rows_per_s": s_rows / leg[0], "per_rank_sims_per_s": s_pr,
+        s_dtype = net_s.engine_name
+        s_kernel = TRUNK_KERNEL[s_dtype]
+        strict_out = {"engine": {"mx6": "k_trunk_mx_c128: fp16 hi halves on fp16 MFMAs + both cross terms of the hi + lo split on one block-scaled fp6 MFMA, 1.5 MFMA-equivalents per product",
+                                 "fp16x2": "k_trunk_split_c128: every weight and stored activation as fp16 hi + lo halves, three MFMAs per product",
+                                 "bf16x2": "k_trunk_split_c128, bf16 halves",
+                                 "fp16": "k_tower8_c128: one fp16 per operand — twice the strict engine's rate, 1e-3 only relative to the logit scale (see its net_error)",
+                                 "bf16": "k_tower8_c128: one bf16 per operand"}[s_dtype], "dtype": s_dtype, "kernel": s_kernel,
+                      "steps": args.alt_steps, "seconds": leg[0], "value": s_sims / leg[0], "unit": "sims/s",
+                      "ms_per_step": leg[0] / args.alt_steps * 1e3, "net_rows_per_s": s_rows / leg[0], "per_rank_sims_per_s": s_pr,
                       "meets_target_1e6_sims_per_s_per_gpu": bool(s_sims / leg[0] / world >= 1e6),
-                      "note": "third barrier-bracketed timed region: the same trees and loop with the strict engine swapped in (same weights)"}
+                      "strict_check": net_s.strict_report,
+                      "note": "third barrier-bracketed timed region: the same trees and loop with this engine swapped in (same weights)"}
         if s_ev:
             s_ms = float(np.mean([a.elapsed_time(b) for a, b in s_ev]))
             s_tr, s_src = pmc_traffic(s_kernel, s_dtype)
@@ -908,8 +910,11 @@ def main():
         "value": head_val, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head_ms, "value_source": head_src, "contract_steps": contract,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic", "engine": "%s (%s)" % (tower_kernel if fused else "torch/MIOpen", {"fp16": "one fp16 per operand: the fast engine; the 1e-3 contract engine of this depth is the strict_engine leg", "bf16": "one bf16 per operand", "mx6": "strict: fp16 hi halves + fp6 block-scaled cross terms", "fp16x2": "strict: fp16 hi + lo halves, three MFMAs per product", "bf16x2": "bf16 hi + lo halves"}.get(args.dtype, args.dtype)),
-        "steady_state": steady_out, "strict_engine": strict_out, "net_error": None, "config": cfg,
+        "dtype": args.dtype, "data": "synthetic", "engine": "%s (%s)%s" % (tower_kernel if fused else "torch/MIOpen", {"fp16": "one fp16 per operand: the fast engine; the 1e-3 contract engine of this depth is the strict_engine leg", "bf16": "one bf16 per operand", "mx6": "strict: fp16 hi halves + fp6 block-scaled cross terms", "fp16x2": "strict: fp16 hi + lo halves, three MFMAs per product", "bf16x2": "bf16 hi + lo halves"}.get(args.dtype, args.dtype),
+                                                                           "; precision 'strict' = the default of policy_value_network() / main.py, selected by the net's own measurement against fp32 on these weights" if asked_strict else ""),
+        "strict_check": strict_report,
+        "steady_state": steady_out, "strict_engine": strict_out if alt_key == "strict_engine" else None,
+        "fast_engine": strict_out if alt_key == "fast_engine" else None, "net_error": None, "config": cfg,
         "roofline": roof, "roofline_tree": tree_roof, "roofline_rules": None,
     }
     cfg["efficiency_vs_min_rank"] = head_val / (world * min(own_rate))
@@ -919,22 +924,27 @@ def main():
         # trained-like weight set, against fp32 on the same inputs (256 of the run's own synthetic positions)
         try:
             from cchess_zero_amd.net import net_error, trained_like_
-            xs = rules.encode_planes(boards[:256], side[:256]).float()
+            xs = rules.encode_planes(probe_boards, probe_side).float()    # the run's synthetic positions, also under --start-position
             ne = {"reference": "fp32 torch module on the device, same weights and inputs (that engine: <= 3e-5 of the NumPy restatement of the reference graph, tests/test_net.py)",
                   "as_benchmarked_glorot": net_error(net, xs)}
             ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] = bool(ne["as_benchmarked_glorot"]["dlogit"] <= 1e-3 and ne["as_benchmarked_glorot"]["dvalue"] <= 1e-3)
             out["net_error"] = ne
-            net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split="mx" if mx else split)
+            net_t = PolicyValueNet(args.blocks, dev, tdt, seed=0, backend=args.backend, ctx=ctx, split=SPLIT_OF.get(args.dtype, False))
             trained_like_(net_t, xs[:96])
             ne["trained_like"] = net_error(net_t, xs)
             ne["meets_1e-3_abs_logit_and_value_trained_like"] = bool(ne["trained_like"]["dlogit"] <= 1e-3 and ne["trained_like"]["dvalue"] <= 1e-3)
+            # the probe must say something: a dead value head (dvalue exactly 0) or a blown-up calibration would not
+            ne["probe_informative"] = bool(0.0 < ne["trained_like"]["dvalue"] < 0.5 and ne["trained_like"]["dlogit"] > 0.0)
+            if asked_strict:   # what precision "strict" itself would run on the trained-like set (it may fall over where mx6 is marginal)
+                net_a = PolicyValueNet(args.blocks, dev, torch.float16, backend="hip", ctx=ctx, split="strict", module=net_t.module)
+                ne["strict_on_trained_like"] = dict(net_a.strict_check(), probe=net_error(net_a, xs))
             if strict_leg is not None:
                 net_s = strict_leg[2]
                 se = {"as_benchmarked_glorot": net_error(net_s, xs)}
-                net_ts = PolicyValueNet(args.blocks, dev, net_s.dtype, backend="hip", ctx=ctx, split="mx" if net_s.mx else True, module=net_t.module)
+                net_ts = PolicyValueNet(args.blocks, dev, net_s.dtype, backend="hip", ctx=ctx, split=SPLIT_OF.get(net_s.engine_name, False), module=net_t.module)
                 se["trained_like"] = net_error(net_ts, xs)
                 se["meets_1e-3_abs_logit_and_value"] = bool(max(se[k][q] for k in ("as_benchmarked_glorot", "trained_like") for q in ("dlogit", "dvalue")) <= 1e-3)
-                out["strict_engine"]["net_error"] = se
+                out[alt_key]["net_error"] = se
         except Exception as e:
             out["net_error"] = {"error": repr(e)}
         try:

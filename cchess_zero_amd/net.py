@@ -221,48 +221,65 @@ def _e2m3_codes(x):
 
 
 def _pack_fp6(codes):
-    """[..., 32] six-bit codes -> [..., 24] uint8, slot i at bits 6 i .. 6 i + 5"""
-    c = codes.to(torch.int64)
-    words = torch.zeros(c.shape[:-1] + (3,), dtype=torch.int64, device=c.device)   # three 64-bit words hold 10 + 2/3 slots each
-    out = torch.zeros(c.shape[:-1] + (24,), dtype=torch.int64, device=c.device)
-    for i in range(32):
-        bit = 6 * i
-        byte, sh = bit // 8, bit % 8
-        v = c[..., i] << sh
-        out[..., byte] |= v & 255
-        if sh > 2:
-            out[..., byte + 1] |= (v >> 8) & 255
-    del words
-    return out.to(torch.uint8)
+    """[..., 32] six-bit codes -> [..., 24] uint8, slot i at bits 6 i .. 6 i + 5 (four slots = one 24-bit word = three bytes)"""
+    c = codes.to(torch.int64).reshape(codes.shape[:-1] + (8, 4))
+    w = c[..., 0] | (c[..., 1] << 6) | (c[..., 2] << 12) | (c[..., 3] << 18)
+    return torch.stack([w & 255, (w >> 8) & 255, (w >> 16) & 255], dim=-1).reshape(codes.shape[:-1] + (24,)).to(torch.uint8)
+
+
+def mx_pack_layers(w):
+    """Folded fp32 conv weights [L][128 co][128 ci][3][3] -> the 36 slabs per layer of k_trunk_mx_c128 (include/cchess_hip.h:
+    cz_net_trunk_mx), uint8 [L][36][16384], all layers in one pass (a refresh() is ~60 torch ops whatever the depth).  Per
+    32-input-channel quarter of a tap: fp16 w_hi in the strict engine's hi layout, then per (co, half h) the fp6 block of the 16
+    channels c_j = 32 quarter + 8 (j / 4) + 4 h + j % 4: slot 2j = q6(2^11 w_lo), slot 2j+1 = q6(w_hi) under the block scale
+    2^(exponent(amax) - 2); the E8M0 byte handed to the MFMA has the 2^-11 folded in."""
+    dev, L = w.device, w.shape[0]
+    t = w.permute(0, 3, 4, 2, 1).reshape(L, 9, 4, 4, 8, FILTERS).permute(0, 1, 2, 3, 5, 4).contiguous()    # [L][tap][quarter][ci8][co][ci%8]
+    hi_bytes = t.to(torch.float16).contiguous().view(torch.uint8).reshape(L, 9, 4, 8192)
+    wq = w.permute(0, 3, 4, 1, 2).reshape(L, 9, FILTERS, 4, 4, 2, 4)           # [L][tap][co][quarter][q][h][i], ci = 32 Q + 8 q + 4 h + i
+    whi = wq.to(torch.float16).float()
+    wlo = (wq - whi).to(torch.float16).float() * 2048.0
+    whi = whi.permute(0, 1, 3, 5, 2, 4, 6).reshape(L, 9, 4, 2, FILTERS, 16)    # [L][tap][quarter][h][co][j = 4 q + i]
+    wlo = wlo.permute(0, 1, 3, 5, 2, 4, 6).reshape(L, 9, 4, 2, FILTERS, 16)
+    amax = torch.maximum(whi.abs().amax(-1), wlo.abs().amax(-1))
+    _, e = torch.frexp(amax.clamp(min=1e-30))
+    byte = (e + 124).clamp(min=12, max=254)                                    # biased exponent(amax) - 2
+    sc = torch.exp2((byte - 127).float()).unsqueeze(-1)
+    slots = torch.stack([_e2m3_codes(wlo / sc), _e2m3_codes(whi / sc)], dim=-1).reshape(L, 9, 4, 2, FILTERS, 32)
+    blk = _pack_fp6(slots)                                                     # [L][9][4][2][128][24]
+    xb = blk[..., :16].reshape(L, 9, 4, 4096)
+    yb = blk[..., 16:].reshape(L, 9, 4, 2048)
+    sdw = torch.zeros((L, 9, 4, 2, FILTERS, 4), dtype=torch.uint8, device=dev)
+    sdw[..., 0] = (byte - 11).to(torch.uint8)
+    pad = torch.zeros((L, 9, 4, 1024), dtype=torch.uint8, device=dev)
+    return torch.cat([hi_bytes, xb, yb, sdw.reshape(L, 9, 4, 1024), pad], dim=-1).reshape(L, 36, 16384).contiguous()
 
 
 def mx_pack_layer(w):
-    """Folded fp32 conv weights [128 co][128 ci][3][3] -> the 36 slabs of k_trunk_mx_c128 (include/cchess_hip.h:
-    cz_net_trunk_mx), uint8 [36][16384].  Per 32-input-channel quarter of a tap: fp16 w_hi in the strict engine's hi layout,
-    then per (co, half h) the fp6 block of the 16 channels c_j = 32 quarter + 8 (j / 4) + 4 h + j % 4: slot 2j = q6(2^11 w_lo),
-    slot 2j+1 = q6(w_hi) under the block scale 2^(exponent(amax) - 2); the E8M0 byte handed to the MFMA has the 2^-11 folded
-    in."""
-    dev = w.device
-    t = w.permute(2, 3, 1, 0).reshape(9, 4, 4, 8, FILTERS).permute(0, 1, 2, 4, 3).contiguous()    # [tap][quarter][ci8][co][ci%8]
-    hi16 = t.to(torch.float16)
-    hi_bytes = hi16.contiguous().view(torch.uint8).reshape(9, 4, 8192)
-    wq = w.permute(2, 3, 0, 1).reshape(9, FILTERS, 4, 4, 2, 4)              # [tap][co][quarter][q][h][i], ci = 32 Q + 8 q + 4 h + i
-    whi = wq.to(torch.float16).float()
-    wlo = (wq - whi).to(torch.float16).float() * 2048.0
-    whi = whi.permute(0, 2, 4, 1, 3, 5).reshape(9, 4, 2, FILTERS, 16)        # [tap][quarter][h][co][j = 4 q + i]
-    wlo = wlo.permute(0, 2, 4, 1, 3, 5).reshape(9, 4, 2, FILTERS, 16)
-    amax = torch.maximum(whi.abs().amax(-1), wlo.abs().amax(-1))
-    _, e = torch.frexp(amax.clamp(min=1e-30))
-    byte = (e + 124).clamp(min=12, max=254)                                  # biased exponent(amax) - 2
-    sc = torch.exp2((byte - 127).float()).unsqueeze(-1)
-    slots = torch.stack([_e2m3_codes(wlo / sc), _e2m3_codes(whi / sc)], dim=-1).reshape(9, 4, 2, FILTERS, 32)
-    blk = _pack_fp6(slots)                                                   # [9][4][2][128][24]
-    xb = blk[..., :16].reshape(9, 4, 4096)
-    yb = blk[..., 16:].reshape(9, 4, 2048)
-    sdw = torch.zeros((9, 4, 2, FILTERS, 4), dtype=torch.uint8, device=dev)
-    sdw[..., 0] = (byte - 11).to(torch.uint8)
-    pad = torch.zeros((9, 4, 1024), dtype=torch.uint8, device=dev)
-    return torch.cat([hi_bytes, xb, yb, sdw.reshape(9, 4, 1024), pad], dim=-1).reshape(36, 16384).contiguous()
+    """One layer [128 co][128 ci][3][3] -> uint8 [36][16384] (mx_pack_layers)."""
+    return mx_pack_layers(w.unsqueeze(0))[0]
+
+
+STRICT_CHECK_TOL = 5e-4        # precision "strict": the engine's MEASURED |dlogit| / |dvalue| against fp32 on the live weights must
+STRICT_CHECK_POSITIONS = 64    # stay below this on this many distinct positions (half of north_star's 1e-3), else the next engine
+_STRICT_LADDER = ("mx6", "fp16x2", "fp32")
+_probe_planes = {}
+
+
+def strict_probe_planes(ctx):
+    """The positions precision "strict" measures itself on: STRICT_CHECK_POSITIONS distinct seeded random-playout positions
+    (rules.random_positions: K1 / K2 on the device, plies 0 .. 80, both sides to move) as [n,9,10,14] float32 encoder planes on
+    the context's device; made once per device."""
+    key = ctx.device.index or 0
+    if key not in _probe_planes:
+        from .rules import Rules, random_positions
+        r = Rules(ctx)
+        boards, side, _ = random_positions(r, 4 * STRICT_CHECK_POSITIONS, seed=20260930, max_ply=80)
+        rows = torch.unique(torch.cat([boards, side.unsqueeze(1)], dim=1), dim=0)      # sorted: deterministic
+        rows = rows[torch.linspace(0, rows.shape[0] - 1, STRICT_CHECK_POSITIONS, device=rows.device).long()]
+        assert torch.unique(rows, dim=0).shape[0] == STRICT_CHECK_POSITIONS
+        _probe_planes[key] = r.encode_planes(rows[:, :90].contiguous(), rows[:, 90].contiguous()).float()
+    return _probe_planes[key]
 
 
 class PolicyValueNet:
@@ -291,6 +308,14 @@ class PolicyValueNet:
         # split: False | True (= "x3": k_trunk_split_c128, three MFMAs per product) | "mx" (k_trunk_mx_c128: fp16 hi halves +
         # both cross terms on one block-scaled fp6 MFMA, 1.5 MFMA-equivalents per product, fp16 only) | "strict" (the cheaper
         # of the two that holds 1e-3 with a factor of two to spare at this depth: mx up to MX_DEPTH_LIMIT blocks)
+        # "strict" is a GUARANTEE, not a depth constant (round 6): the depth rule picks where to start, then every refresh() —
+        # construction, restore(), each train_step — is followed (lazily, at the next evaluation) by strict_check(): the engine
+        # is measured against the fp32 module on the live weights and the net falls over mx6 -> fp16x2 -> fp32 above
+        # STRICT_CHECK_TOL.  strict_report holds the last measurement.
+        self.strict_auto = split == "strict"
+        self.strict_report = None
+        self._check_pending = False
+        self._fp32_fallback = False
         if split == "strict":
             split = "mx" if (module.res_block_nums if module is not None else res_block_nums) <= MX_DEPTH_LIMIT and dtype == torch.float16 else True
         if split == "x3":
@@ -320,8 +345,66 @@ class PolicyValueNet:
 
     @torch.no_grad()
     def refresh(self):
-        """Re-fold BN and re-cast after a weight change."""
-        m, dt = self.module, self.dtype
+        """Re-fold BN and re-cast after a weight change.  Precision "strict": the engine ladder starts over and the new
+        weights are measured at the next evaluation (strict_check)."""
+        if self.strict_auto:
+            self._strict_select(0 if (self.res_block_nums <= MX_DEPTH_LIMIT and self.dtype == torch.float16) else 1)
+            self._check_pending = self.device.type == "cuda"
+        self._pack()
+
+    def _strict_select(self, rung):
+        """engine of rung `rung` of the strict ladder: mx6 (k_trunk_mx_c128), fp16x2 (k_trunk_split_c128), fp32 (torch/MIOpen)"""
+        self._rung = rung
+        self.mx, self.split, self._fp32_fallback = rung == 0, rung in (0, 1), rung == 2
+        self.backend = "torch" if rung == 2 else "hip"
+
+    @property
+    def engine_name(self):
+        """Which arithmetic evaluates the tower right now: mx6 | fp16x2 | bf16x2 | fp16 | bf16 | fp32."""
+        if self._fp32_fallback or self.dtype == torch.float32:
+            return "fp32"
+        half = "fp16" if self.dtype == torch.float16 else "bf16"
+        return "mx6" if self.mx else (half + "x2" if self.split else half)
+
+    @torch.no_grad()
+    def strict_check(self, planes_nhwc=None, tol=None):
+        """Precision "strict" measured on the LIVE weights (policy_value_network.py:202-214 is an fp32 sess.run; north_star
+        allows 1e-3): the selected engine and the fp32 torch module evaluate the same >= 64 distinct positions; above `tol`
+        (default STRICT_CHECK_TOL = 5e-4: a factor of two inside the contract, the probe is 64 positions and not every
+        position) the net falls over to the next engine of the ladder mx6 -> fp16x2 -> fp32 and measures again.
+        -> strict_report = {"engine", "dlogit", "dvalue", "max_abs_logit", "tol", "positions", "fell_over_from": [...]}."""
+        import warnings
+        tol = STRICT_CHECK_TOL if tol is None else float(tol)
+        self._check_pending = False
+        x = strict_probe_planes(self._hip_ctx()) if planes_nhwc is None else torch.as_tensor(np.asarray(planes_nhwc.cpu() if torch.is_tensor(planes_nhwc) else planes_nhwc, dtype=np.float32)).to(self.device)
+        lr, vr = self.module.float()(x.permute(0, 3, 1, 2).contiguous())
+        lr, vr = lr.double(), vr.double().reshape(-1)
+        failed = []
+        while True:
+            l, v = self.forward_device(x)
+            dl = float((l.double() - lr).abs().max())
+            dv = float((v.double().reshape(-1) - vr).abs().max())
+            ok = dl <= tol and dv <= tol      # NaN compares false: a non-finite engine fails
+            rep = {"engine": self.engine_name, "dlogit": dl, "dvalue": dv, "max_abs_logit": float(lr.abs().max()), "tol": tol,
+                   "positions": int(x.shape[0]), "fell_over_from": list(failed)}
+            if ok or not self.strict_auto or self._rung >= 2:
+                break
+            failed.append(dict(engine=self.engine_name, dlogit=dl, dvalue=dv))
+            warnings.warn("precision 'strict': %s measures |dlogit| %.3g / |dvalue| %.3g against fp32 on these weights (> %.1g, |logit| <= %.3g): "
+                          "falling over to %s" % (self.engine_name, dl, dv, tol, rep["max_abs_logit"], _STRICT_LADDER[self._rung + 1]))
+            self._strict_select(self._rung + 1)
+            self._pack()
+        self.strict_report = rep
+        return rep
+
+    def _ensure_checked(self):
+        if self._check_pending:
+            self.strict_check()
+
+    @torch.no_grad()
+    def _pack(self):
+        """the operand images of the selected engine"""
+        m, dt = self.module, (torch.float32 if self._fp32_fallback else self.dtype)
         cl = torch.channels_last
 
         def conv_pack(cb):
@@ -348,8 +431,8 @@ class PolicyValueNet:
             self.hip_tower_w = torch.stack([w for w, _ in layers]).contiguous() if layers else torch.zeros((0,), dtype=hdt, device=self.device)
             self.hip_tower_b = torch.stack([b for _, b in layers]).contiguous() if layers else torch.zeros((0,), dtype=torch.float32, device=self.device)
             if self.mx:
-                sl = [mx_pack_layer(cb.folded()[0]) for blk in m.blocks for cb in blk]
-                self.hip_mx_w = torch.stack(sl).contiguous() if sl else torch.zeros((0,), dtype=torch.uint8, device=self.device)
+                sl = [cb.folded()[0] for blk in m.blocks for cb in blk]
+                self.hip_mx_w = mx_pack_layers(torch.stack(sl)) if sl else torch.zeros((0,), dtype=torch.uint8, device=self.device)
             if self.split:
                 # strict engine: w = hi + lo, two values of hdt.  Tower layer: [tap][32-channel quarter of the tap = one 16 KB
                 # slab][hi, lo][ci/8 within the quarter][co][ci%8]; first layer: [tap][hi, lo][ci/8][co][ci%8]
@@ -533,7 +616,7 @@ class PolicyValueNet:
     def first_conv(self, planes):
         """planes [B,9,10,C>=14] (NHWC, any float dtype) -> conv3x3(14->128)+BN+ReLU, [B,128,9,10] channels_last."""
         x = planes[..., :14] if planes.shape[-1] != 14 else planes
-        x = x.to(self.dtype).permute(0, 3, 1, 2)  # NHWC memory == NCHW channels_last view
+        x = x.to(self.w_in[0].dtype).permute(0, 3, 1, 2)  # NHWC memory == NCHW channels_last view (fp32 on the strict ladder's last rung)
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         return F.relu_(F.conv2d(x, self.w_in[0], self.w_in[1], padding=1))
@@ -541,6 +624,7 @@ class PolicyValueNet:
     @torch.no_grad()
     def tower(self, planes):
         """planes [B,9,10,C>=14] (NHWC, any float dtype) -> trunk activations [B,128,9,10] channels_last."""
+        self._ensure_checked()
         if self.backend == "hip" and (self.dtype == torch.float16 or self.split) and self.res_block_nums >= 1:
             t = self._hip_net_forward(planes, trunk=True)   # fp16 / strict: the fused kernel is the only hip route
             return t.reshape(t.shape[0], 9, 10, FILTERS).permute(0, 3, 1, 2)
@@ -619,6 +703,7 @@ class PolicyValueNet:
     @property
     def fused_search(self):
         """True when the search loop may skip the full policy FC (SearchEngine.step -> expand_backup_fc)."""
+        self._ensure_checked()   # precision "strict": new weights are measured before the loop decides how to call the net
         return self.backend == "hip" and self.res_block_nums >= 1 and self.fuse_policy_fc
 
     @torch.no_grad()
@@ -628,6 +713,7 @@ class PolicyValueNet:
         (SearchEngine.select_compact) — only the first *n_rows rows are computed, the rest of z / value is undefined."""
         import ctypes as C
         from ._lib import check, lib
+        self._ensure_checked()
         h = self._hip_ctx().h
         if n_rows is not None:
             check(lib().cz_set_batch_count(h, n_rows), "cz_set_batch_count")
@@ -646,6 +732,7 @@ class PolicyValueNet:
     @torch.no_grad()
     def forward_device(self, planes):
         """Device planes [B,9,10,C] -> (logits [B,2086] f32, value [B,1] f32), all on the device."""
+        self._ensure_checked()
         if self.backend == "hip" and self.res_block_nums >= 1:
             return self._hip_fc_heads(self._hip_net_forward(planes))
         return self.heads(self.tower(planes))
@@ -681,15 +768,28 @@ def trained_like_(net, planes_nhwc, seed=5):
         # both heads are calibrated on the given positions, whatever the depth of the tower: the policy FC is scaled so
         # that the largest logit of a position averages 10; the last value layer so that tanh's argument has mean 0 and
         # std 0.6 (a Glorot-initialised head answers ~-0.65 +- 0.03 for every position: no value signal for a search)
-        feats = []
-        hook = m.value_fc2.register_forward_hook(lambda mod, inp, out: feats.append(inp[0].detach()))
         x = torch.as_tensor(np.asarray(planes_nhwc.cpu() if torch.is_tensor(planes_nhwc) else planes_nhwc, dtype=np.float32)).to(w.device).permute(0, 3, 1, 2)
+        feats, vconv = [], []
+        hook = m.value_fc2.register_forward_hook(lambda mod, inp, out: feats.append(inp[0].detach()))
+        hook2 = m.value_conv.register_forward_hook(lambda mod, inp, out: vconv.append(out.detach()))
         logits, _ = m(x)
-        hook.remove()
         w.mul_(10.0 / float(logits.max(dim=1).values.mean()))
+        # a value head whose 1x1 conv is negative on (nearly) every cell of every position is DEAD behind its ReLU — it happens
+        # at 19 blocks, where the trunk's activations have drifted — and would answer one constant: dvalue = 0 says nothing
+        # about an engine.  Its bias is shifted to the median of the pre-activations (half of the cells fire), then the two
+        # FC layers see a signal to calibrate on.
+        if float((vconv[0] > 0).float().mean()) < 0.1:
+            m.value_conv.conv.bias.sub_(vconv[0].median() * torch.sqrt(m.value_conv.moving_var + BN_EPS))
+            del feats[:], vconv[:]
+            m(x)
+        hook.remove()
+        hook2.remove()
         pre = feats[0] @ m.value_fc2.weight.t()
-        sd = float(pre.std())
-        k = 0.6 / sd if sd > 0 else 1.0   # a dead value head (every ReLU of the head conv off) has nothing to calibrate
+        sd = float(pre.std()) if pre.shape[0] > 1 else 0.0
+        if not sd > 1e-5 * max(1.0, float(pre.abs().mean())):     # identical rows differ by rounding noise at most
+            raise ValueError("trained_like_: the value head answers one constant on the %d calibration positions (identical positions?): "
+                             "calibrate on distinct positions" % pre.shape[0])
+        k = 0.6 / sd
         m.value_fc2.weight.mul_(k)
         m.value_fc2.bias.fill_(-float(pre.mean()) * k)
     net.refresh()

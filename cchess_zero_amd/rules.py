@@ -8,6 +8,39 @@ from ._lib import BF16, F16, F32, MASK_WORDS, MAXMOVES, NLABELS, NSQ, check, lib
 from .engine import Context, _ptr
 
 
+# the start position (main.py:585: RNBAKABNR/9/1C5C1/P1P1P1P1P/9/9/p1p1p1p1p/1c5c1/9/rnbakabnr) as piece codes, sq = 9 y + x
+START_BOARD = np.array([3, 5, 4, 2, 1, 2, 4, 5, 3] + [0] * 9 + [0, 7, 0, 0, 0, 0, 0, 7, 0] + [6, 0, 6, 0, 6, 0, 6, 0, 6] + [0] * 18 +
+                       [13, 0, 13, 0, 13, 0, 13, 0, 13] + [0, 14, 0, 0, 0, 0, 0, 14, 0] + [0] * 9 + [10, 12, 11, 9, 8, 9, 11, 12, 10], np.uint8)
+
+
+def random_positions(rules, G, seed, max_ply=80):
+    """Seeded uniform-random playouts from the start position, ply ~ U[0, max_ply] per game, all on the GPU (K1 movegen ->
+    random pick -> K2 apply); a move that would capture a king is not played (both kings stay on the board).  The synthetic
+    positions of SURVEY 8(d) -> (boards [G,90] u8, side [G] u8, restrict_round [G] i32), device tensors."""
+    dev = rules.dev
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    boards = torch.from_numpy(np.tile(START_BOARD, (G, 1))).to(dev)
+    side = torch.zeros(G, dtype=torch.uint8, device=dev)
+    rr = torch.zeros(G, dtype=torch.int32, device=dev)
+    target = torch.randint(0, max_ply + 1, (G,), generator=gen, device=dev)
+    alive = torch.ones(G, dtype=torch.bool, device=dev)
+    for ply in range(max_ply):
+        moves, count, _ = rules.movegen(boards, side, want_mask=False)
+        cnt = count.to(torch.int64) & 0xFFFF
+        go = alive & (target > ply) & (cnt > 0)
+        r = (torch.rand(G, generator=gen, device=dev) * cnt.clamp(min=1)).to(torch.int64).clamp(max=127)
+        pick = moves.gather(1, r.unsqueeze(1)).squeeze(1)
+        nb, ns = boards.clone(), side.clone()
+        lab = torch.where(go, pick, torch.full_like(pick, -1))
+        cap, term = rules.apply_move(nb, ns, lab)
+        ok = go & (term == 0)
+        boards = torch.where(ok.unsqueeze(1), nb, boards)
+        side = torch.where(ok, ns, side)
+        rr = torch.where(ok, torch.where(cap != 0, torch.zeros_like(rr), rr + 1), rr)
+        alive = alive & (ok | ~go)
+    return boards.contiguous(), side.contiguous(), rr.contiguous()
+
+
 class Rules:
     def __init__(self, ctx=None, device=0):
         self.ctx = ctx or Context(1, 2, device)

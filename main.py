@@ -501,7 +501,7 @@ class cchess_main(object):
         sp = getattr(self, "_sp", None)
         if sp is None or sp.eng.G != G or sp.eng.ctx.cap < cap or sp.playouts != self.playout_counts or sp.net is not net:
             # planes are written by the select kernel straight in the fused net's input format (16 channels of its 16-bit type)
-            fused = net.backend == "hip" and net.dtype in (torch.float16, torch.bfloat16)
+            fused = (net.backend == "hip" or net.strict_auto) and net.dtype in (torch.float16, torch.bfloat16)
             eng = SearchEngine(G, cap, torch.cuda.current_device(), plane_dtype=net.dtype if fused else torch.float32,
                                channels=16 if fused else 14)
             # every rank seeds its games differently but reproducibly from the shared Python RNG state
@@ -640,9 +640,9 @@ if __name__ == '__main__':
     parser.add_argument('--games', default=256, type=int, help='parallel self-play games per GPU')
     parser.add_argument('--max_batches', default=None, type=int, help='stop after this many self-play batches')
     parser.add_argument('--net_precision', default=None, choices=['strict', 'mx6', 'fp16x2', 'fp16', 'bf16', 'bf16x2', 'fp32'], type=str,
-                        help='net engine (policy_value_network.PRECISIONS): strict (default) = within 1e-3 of the reference fp32 graph '
-                             'on trained-like weights (mx6 up to 8 blocks, fp16x2 beyond); fp16 = 2x faster, 1e-3 only relative to '
-                             'the logit scale')
+                        help='net engine (policy_value_network.PRECISIONS): strict (default) = measured within 5e-4 absolute of the '
+                             'fp32 graph on 64 positions with the LIVE weights after every weight change, falling over mx6 -> fp16x2 -> '
+                             'fp32 otherwise (mx6: ~4e-5 of the largest logit; fp16x2: ~6e-6); fp16 = 2x faster, ~1e-3 of the largest logit')
     args = parser.parse_args()
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:   # launched by torch.distributed.run: one rank per GPU

@@ -33,9 +33,11 @@ class policy_value_network(object):
 
     def __init__(self, res_block_nums=7, device=None, dtype=None, save_dir="./models", seed=0, precision=None):
         """precision (or the environment's CCHESS_NET_PRECISION; default "strict"): which engine evaluates the net.
-          "strict"   the cheapest engine that keeps forward() within 1e-3 ABSOLUTE of the reference's fp32 sess.run
-                     (policy_value_network.py:202-214) with a factor of two to spare on peaked, trained-like weights at this
-                     depth — the drop-in default: "mx6" up to 8 residual blocks, "fp16x2" beyond;
+          "strict"   the drop-in default: forward() within 1e-3 ABSOLUTE of the reference's fp32 sess.run
+                     (policy_value_network.py:202-214), MEASURED, not assumed: it starts with "mx6" up to 8 residual blocks and
+                     "fp16x2" beyond, and after every weight change (construction, restore(), each train_step) the engine and
+                     the fp32 module evaluate 64 distinct positions; above 5e-4 in a logit or the value the net falls over
+                     mx6 -> fp16x2 -> fp32 and says so (net.strict_report / strict_report() hold the last measurement);
           "mx6"      fp16 hi halves on fp16 MFMAs + both cross terms of the hi + lo split on ONE block-scaled fp6 MFMA
                      (k_trunk_mx_c128, 1.5 MFMA-equivalents per product): 5e-4 / 2e-4 at 7 blocks, 1.0e-3 / 1.1e-3 at 19;
                      1.9 M simulations/s;
@@ -79,6 +81,13 @@ class policy_value_network(object):
 
     def refresh(self):
         self.net.refresh()
+
+    def strict_report(self):
+        """precision "strict": the last self-measurement of the engine against fp32 on the live weights ({"engine", "dlogit",
+        "dvalue", "max_abs_logit", "tol", "positions", "fell_over_from"}; measured now if a weight change is pending)."""
+        if self.net.strict_auto:
+            self.net._ensure_checked()
+        return self.net.strict_report
 
     # ---- inference --------------------------------------------------------------------------
     def forward(self, positions):

@@ -66,7 +66,9 @@ def test_round5_record_compacts_to_the_committed_line():
     line = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05_bench_default_line.json")) if l.startswith("{")][-1])
     got = bench.compact_line(full)
     got["detail_file"] = line["detail_file"]
-    assert json.loads(json.dumps(got)) == line
+    got = json.loads(json.dumps(got))
+    assert {k: got[k] for k in line} == line      # round 6 added keys (strict_check, fast_engine): None for a round-5 record
+    assert got["fast_engine"] is None and got["strict_check"] is None
     assert len(json.dumps(line)) < 8000
     se = line["strict_engine"]
     assert se["kernel"] == "k_trunk_mx_c128" and se["dtype"] == "mx6" and se["value"] > 1.7e6 and 0.25 < se["frac"] < 0.35
@@ -86,3 +88,30 @@ def test_reference_python_flag(monkeypatch):
     out = bench.cpu_baseline(2, 1.0)
     assert out["reference_python"]["measured_in_this_run"] is True and out["reference_python"]["search_only_sims_per_s_per_core"] == 650.0
     assert out["reference_python"]["static_record"]["end_to_end_7block_sims_per_s"] == 157
+
+
+def test_trained_like_probe_is_informative_cpu():
+    """bench.py's trained-like net-error probe.  (a) A value head whose 1x1 conv is off behind its ReLU on every
+    cell (what 19 blocks produced: dvalue = 0.0 on the committed lines) is revived before the heads are calibrated: the value
+    output varies across positions.  (b) Calibrating on identical positions (96 copies of the start position, --start-position
+    in round 5: tanh argument scaled by 1 / 0) raises instead of producing a blown-up head.  fp32 torch engine on the CPU."""
+    import numpy as np
+    import torch
+    from cchess_zero_amd.net import PolicyValueNet, trained_like_
+    rng = np.random.default_rng(0)
+    x = np.zeros((48, 9, 10, 14), np.float32)
+    for i in range(48):                                   # distinct sparse one-hot planes: encoder-like inputs
+        idx = rng.choice(90, 20, replace=False)
+        x[i].reshape(90, 14)[idx, rng.integers(0, 14, 20)] = 1.0
+    net = PolicyValueNet(2, "cpu", torch.float32, seed=4, backend="torch")
+    with torch.no_grad():
+        net.module.value_conv.conv.bias.fill_(-50.0)      # dead: every pre-activation far below zero
+    _, v0 = net.module(torch.from_numpy(x).permute(0, 3, 1, 2))
+    assert float(v0.std()) == 0.0
+    trained_like_(net, x)
+    lg, v = net.module(torch.from_numpy(x).permute(0, 3, 1, 2))
+    assert float(v.std()) > 0.05 and float(v.abs().max()) < 1.0 and 5.0 < float(lg.max(dim=1).values.mean()) < 15.0
+    import pytest
+    net2 = PolicyValueNet(2, "cpu", torch.float32, seed=4, backend="torch")
+    with pytest.raises(ValueError, match="distinct positions"):
+        trained_like_(net2, np.repeat(x[:1], 96, axis=0))

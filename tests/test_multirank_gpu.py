@@ -59,18 +59,31 @@ def test_bench_two_ranks_selfplay_with_timed_record_exchange():
 
 @pytest.mark.gpu
 def test_bench_two_ranks_search_loop_default_engine():
-    """The default loop (search, aged trees, steady leg, strict leg) with two ranks: both legs carry two per-rank figures."""
+    """The default loop (search, aged trees, steady leg, the other engine's leg) with two ranks: both legs carry two per-rank
+    figures.  Since round 6 the default engine is precision "strict" (what policy_value_network() runs), selected by the net's own
+    measurement; the fast fp16 engine is the extra leg."""
     d = _bench(["--gpus", "2", "--all-on-device0", "--dist-backend", "gloo", "--games", "512", "--playout", "64", "--steps", "24",
-                "--warmup", "4", "--age-steps", "48", "--steady-steps", "48", "--strict-steps", "16", "--no-cpu-baseline"])
+                "--warmup", "4", "--age-steps", "48", "--steady-steps", "48", "--alt-steps", "16", "--no-cpu-baseline"])
     assert d["n_gpus"] == 2 and d["value_source"].startswith("steady_state")
-    assert len(d["steady_state"]["per_rank_sims_per_s"]) == 2 and len(d["strict_engine"]["per_rank_sims_per_s"]) == 2
+    assert len(d["steady_state"]["per_rank_sims_per_s"]) == 2 and len(d["fast_engine"]["per_rank_sims_per_s"]) == 2
     assert d["contract_steps"]["steps"] == 24 and d["config"]["record_gather"] is True
     assert d["config"]["trees_with_error_status"] == 0
-    assert d["strict_engine"]["kernel"] == "k_trunk_mx_c128" and d["strict_engine"]["meets_1e-3_abs_logit_and_value"] is True
-    assert d["strict_engine"]["value"] > 0 and d["strict_engine"]["frac"] > 0
+    assert d["dtype"] == "mx6" and d["roofline"]["kernel"] == "k_trunk_mx_c128" and d["engine"].startswith("k_trunk_mx_c128")
+    assert d["strict_check"]["engine"] == "mx6" and d["strict_check"]["positions"] >= 64 and not d["strict_check"]["fell_over_from"]
+    assert max(d["strict_check"]["dlogit"], d["strict_check"]["dvalue"]) <= 5e-4
+    ne = d["net_error"]
+    assert ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] is True and ne["meets_1e-3_abs_logit_and_value_trained_like"] is True
+    assert ne["probe_informative"] is True and ne["trained_like"]["dvalue"] > 0
+    assert d["strict_engine"] is None and d["fast_engine"]["kernel"] == "k_tower8_c128" and d["fast_engine"]["dtype"] == "fp16"
+    assert d["fast_engine"]["value"] > d["value"] > 0 and d["fast_engine"]["frac"] > d["roofline"]["frac"] > 0
     assert len(json.dumps(d)) < 8000                      # the driver's record keeps an 8 KB tail of the line
     full = json.load(open(os.path.join(ROOT, d["detail_file"])))
-    assert full["strict_engine"]["net_error"]["meets_1e-3_abs_logit_and_value"] is True and "telemetry" in json.dumps(full)
+    assert full["net_error"]["strict_on_trained_like"]["engine"] in ("mx6", "fp16x2") and "telemetry" in json.dumps(full)
+    # the fast engine by explicit choice: the strict engine is then the extra leg (round 5's layout)
+    d = _bench(["--dtype", "fp16", "--games", "512", "--playout", "64", "--steps", "24", "--warmup", "4", "--age-steps", "48", "--steady-steps", "0",
+                "--strict-steps", "16", "--no-cpu-baseline"])
+    assert d["dtype"] == "fp16" and d["fast_engine"] is None and d["strict_engine"]["kernel"] == "k_trunk_mx_c128"
+    assert d["strict_engine"]["meets_1e-3_abs_logit_and_value"] is True and d["strict_check"] is None
 
 
 @pytest.mark.gpu

@@ -494,3 +494,87 @@ def test_fp16_trunk_route_consistent(blocks, n):
     print("fp16 %d-block trunk route vs fused heads: max|dlogit| %.3g (max|logit| %.3g) max|dvalue| %.3g" % (blocks, dl, float(l3.abs().max()), dv))
     # measured: 5.5e-6 of the largest logit, 2e-7 on the value (fp32 summation order of the head convs only)
     assert dl <= 2e-5 * float(l3.abs().max()) and dv <= 1e-6
+
+
+def _heavy_tailed_(net, logit_scale=30.0, seed=17):
+    """A weight set that is harder on a max-scaled 16-channel E2M3 block than nethelpers.trained_like_: the
+    trained-like set, then heavy-tailed BN variances (log-normal, sigma 0.7: under quirk Q5 a trained checkpoint's activations
+    are unnormalised, a few channels dominate their block) and a policy FC rescaled to |logit| ~ logit_scale."""
+    H.trained_like_(net)
+    gen = torch.Generator().manual_seed(seed)
+    m = net.module
+    with torch.no_grad():
+        for cb in m.convbns()[:-2]:
+            cb.moving_var.copy_(torch.exp(torch.randn(cb.moving_var.shape, generator=gen) * 0.7).to(cb.moving_var.device))
+        x = torch.from_numpy(_positions(96, 123)).to(m.policy_fc.weight.device).permute(0, 3, 1, 2)
+        logits, _ = m(x)
+        m.policy_fc.weight.mul_(logit_scale / float(logits.max(dim=1).values.mean()))
+    net.refresh()
+    return net
+
+
+@pytest.mark.gpu
+def test_strict_is_measured_and_falls_over_when_mx6_misses(tmp_path):
+    """precision "strict" is a guarantee.  On TF-default weights the facade's 7-block net measures itself
+    (64 distinct positions, engine vs fp32 module) and stays on k_trunk_mx_c128; on a weight set that breaks mx6 at 7 blocks
+    (heavy-tailed BN variances, |logit| ~ 30: mx6's ~4e-5 of the largest logit is > 1e-3 absolute) the SAME facade object falls
+    over to k_trunk_split_c128, reports what it measured, and forward() still meets north_star's 1e-3 against the NumPy
+    restatement of the reference graph (policy_value_network.py:202-214); after benign weights are restored it is back on mx6."""
+    import warnings
+    from cchess_zero_amd.net import STRICT_CHECK_POSITIONS, STRICT_CHECK_TOL, PolicyValueNet
+    from policy_value_network import policy_value_network
+    pv = policy_value_network(7, save_dir=str(tmp_path))
+    rep = pv.strict_report()
+    assert rep["engine"] == "mx6" and rep["positions"] == STRICT_CHECK_POSITIONS >= 64 and not rep["fell_over_from"]
+    assert rep["dlogit"] <= 5e-5 and rep["dvalue"] <= 5e-5 and pv.net.mx and pv.net.fused_search
+    benign = {k: v.clone() for k, v in pv.module.state_dict().items()}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _heavy_tailed_(pv.net)
+        x = _positions(64, 2)
+        logits, v = pv.forward(x)                       # the pending measurement happens here
+    rep = pv.strict_report()
+    print("strict on heavy-tailed weights:", rep)
+    assert rep["fell_over_from"] and rep["fell_over_from"][0]["engine"] == "mx6"
+    assert max(rep["fell_over_from"][0]["dlogit"], rep["fell_over_from"][0]["dvalue"]) > STRICT_CHECK_TOL
+    assert rep["engine"] in ("fp16x2", "fp32") and max(rep["dlogit"], rep["dvalue"]) <= STRICT_CHECK_TOL
+    assert any("falling over" in str(i.message) for i in w)
+    assert not pv.net.mx and pv.net.engine_name == rep["engine"]
+    ln, vn = net_numpy.forward(pv.module.export_tf_layout(), x, 7)
+    e = H.errors(logits, v, ln, vn)
+    print("facade after fall-over: max|logit| %.3g dlogit %.3g dvalue %.3g" % (e["max_abs_logit"], e["dlogit"], e["dvalue"]))
+    assert e["max_abs_logit"] > 20 and e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3 and e["argmax_agree"] == 1.0
+    # the engine it fell over FROM, run by explicit choice on the same weights, does miss the contract on these inputs
+    mx = PolicyValueNet(7, "cuda:0", torch.float16, split="mx", module=pv.module)
+    lm, vm = mx.forward(x)
+    em = H.errors(lm, vm, ln, vn)
+    print("mx6 by explicit choice on the same weights: dlogit %.3g dvalue %.3g" % (em["dlogit"], em["dvalue"]))
+    assert max(em["dlogit"], em["dvalue"]) > STRICT_CHECK_TOL
+    # benign weights again (what a train_step / restore does: refresh() restarts the ladder)
+    pv.module.load_state_dict(benign)
+    pv.refresh()
+    assert pv.strict_report()["engine"] == "mx6" and pv.net.mx
+
+
+@pytest.mark.gpu
+def test_strict_last_rung_fp32_drives_the_fused_search_loop():
+    """The ladder's last rung (torch / MIOpen fp32) under a SearchEngine that was built for the fused engine (fp16 planes, 16
+    channels): forced by tol = 0, the lock-step loop switches to the full-logits expansion and finds the visit counts of a
+    plain fp32 engine."""
+    from cchess_zero_amd.engine import SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet
+    from cchess_zero_amd.rules import START_BOARD
+    G = 32
+    net = PolicyValueNet(2, "cuda:0", torch.float16, seed=3, split="strict")
+    rep = net.strict_check(tol=0.0)
+    assert rep["engine"] == "fp32" and [f["engine"] for f in rep["fell_over_from"]] == ["mx6", "fp16x2"] and not net.fused_search
+    assert rep["dlogit"] <= 1e-5 and rep["dvalue"] <= 1e-5
+    ref = PolicyValueNet(2, "cuda:0", torch.float32, module=net.module, backend="torch")
+    boards, side = np.tile(START_BOARD, (G, 1)), np.zeros(G, np.uint8)
+    ea = SearchEngine(G, 4096, plane_dtype=torch.float16, channels=16)
+    eb = SearchEngine(G, 4096, plane_dtype=torch.float32, channels=14)
+    for e, n in ((ea, net), (eb, ref)):
+        e.reset(boards, side, None)
+        e.search(n.forward_device, 24)
+    a, b = ea.root_stats_host(), eb.root_stats_host()
+    assert np.array_equal(a["N"], b["N"]) and np.array_equal(a["label"], b["label"])
