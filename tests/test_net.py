@@ -496,7 +496,7 @@ def test_fp16_trunk_route_consistent(blocks, n):
     assert dl <= 2e-5 * float(l3.abs().max()) and dv <= 1e-6
 
 
-def _heavy_tailed_(net, logit_scale=30.0, seed=17):
+def _heavy_tailed_(net, logit_scale=80.0, seed=17):
     """A weight set that is harder on a max-scaled 16-channel E2M3 block than nethelpers.trained_like_: the
     trained-like set, then heavy-tailed BN variances (log-normal, sigma 0.7: under quirk Q5 a trained checkpoint's activations
     are unnormalised, a few channels dominate their block) and a policy FC rescaled to |logit| ~ logit_scale."""
@@ -517,7 +517,8 @@ def _heavy_tailed_(net, logit_scale=30.0, seed=17):
 def test_strict_is_measured_and_falls_over_when_mx6_misses(tmp_path):
     """precision "strict" is a guarantee.  On TF-default weights the facade's 7-block net measures itself
     (64 distinct positions, engine vs fp32 module) and stays on k_trunk_mx_c128; on a weight set that breaks mx6 at 7 blocks
-    (heavy-tailed BN variances, |logit| ~ 30: mx6's ~4e-5 of the largest logit is > 1e-3 absolute) the SAME facade object falls
+    (heavy-tailed BN variances, |logit| ~ 80: mx6's ~1e-5 of the largest logit — measured on the MI355X 2.9e-4 at |logit| 32,
+    emulated 6.3e-4 / 1.3e-3 at 35 / 70 on the corpus positions — is above the 5e-4 it allows itself) the SAME facade object falls
     over to k_trunk_split_c128, reports what it measured, and forward() still meets north_star's 1e-3 against the NumPy
     restatement of the reference graph (policy_value_network.py:202-214); after benign weights are restored it is back on mx6."""
     import warnings
@@ -543,7 +544,7 @@ def test_strict_is_measured_and_falls_over_when_mx6_misses(tmp_path):
     ln, vn = net_numpy.forward(pv.module.export_tf_layout(), x, 7)
     e = H.errors(logits, v, ln, vn)
     print("facade after fall-over: max|logit| %.3g dlogit %.3g dvalue %.3g" % (e["max_abs_logit"], e["dlogit"], e["dvalue"]))
-    assert e["max_abs_logit"] > 20 and e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3 and e["argmax_agree"] == 1.0
+    assert e["max_abs_logit"] > 50 and e["dlogit"] <= 1e-3 and e["dvalue"] <= 1e-3 and e["argmax_agree"] == 1.0
     # the engine it fell over FROM, run by explicit choice on the same weights, does miss the contract on these inputs
     mx = PolicyValueNet(7, "cuda:0", torch.float16, split="mx", module=pv.module)
     lm, vm = mx.forward(x)
