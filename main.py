@@ -19,6 +19,7 @@ flight per tree because thousands of trees already fill the net batch.  Pseudo-l
 priors, the root never being backed up, and the 9-stride plane quirk are all reproduced.
 """
 import argparse
+import json
 import os
 import random
 import sys
@@ -584,10 +585,24 @@ class cchess_main(object):
                 # expands the mini-batch it draws (cchess_zero_amd/train.py)
                 order = np.random.RandomState(self.update_seed + batch_iter).permutation(n)   # same on every rank
                 self.data_buffer.extend(rec[i] for i in order)
+                t1 = time.time()
+                updates = 0
                 if len(self.data_buffer) > self.batch_size:
                     updates = max(1, min(64, n // self.batch_size))
                     for u in range(updates):   # the reference saves after its one update per game (main.py:1188): once per batch here
                         self.policy_update(save=(u == updates - 1))
+                # wall-clock of the product's default loop: one line per batch, also in the log file
+                rep = self.policy_value_netowrk.strict_report() if hasattr(self.policy_value_netowrk, "strict_report") else None
+                timing = {"batch": batch_iter, "game_slots": self.games, "playout": self.playout_counts, "games_finished": int(st["games"]),
+                          "samples_all_ranks": int(n), "simulations": int(self.last_selfplay_sims), "lock_steps": int(st.get("lock_steps", 0)),
+                          "selfplay_seconds": round(dt, 3), "sims_per_s": round(self.last_selfplay_sims / max(dt, 1e-9), 1),
+                          "policy_updates": updates, "policy_update_seconds": round(time.time() - t1, 3),
+                          "net_engine": getattr(self.policy_value_netowrk.net, "engine_name", None), "strict_check": rep,
+                          "eval_cache": bool(getattr(self._sp, "eval_cache", False)), "xcache_log2": int(getattr(self._sp, "xcache_log2", 0))}
+                msg = "batch_timing: " + json.dumps(timing)
+                print(msg, flush=True)
+                self.log_file.write(msg + '\n')
+                self.log_file.flush()
         except KeyboardInterrupt:
             self.log_file.close()
             self.policy_value_netowrk.save(self.global_step)
