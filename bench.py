@@ -178,7 +178,9 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
     sec = timed(want_mask=True, want_moves=False)
-    sec_list = timed(want_mask=True, want_moves=True)
+    sec_list_pad = timed(want_mask=True, want_moves=True)
+    sec_list = timed(want_mask=True, want_moves=True, pad=False)    # CZ_MOVES_NO_PAD: rows written up to their count (round 6)
+    mean_moves = float((rules.movegen(b[:65536], sd[:65536], want_mask=False, want_moves=False)[1].to(torch.int64) & 0xFFFF).float().mean().item())
     alg = 312.0 * n
     abi = (90 + 1 + 264 + 2) * float(n)
     abi_list = (90 + 1 + 256 + 264 + 2) * float(n)
@@ -196,10 +198,14 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
             "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": tr_mask, "traffic_source": tr_src,
             "positions": n, "positions_per_s": n / sec, "us_per_launch": sec * 1e6, "algorithmic_bytes_per_position": 312,
             "abi_bytes_per_position": abi / n, "abi_GBps": abi / sec / 1e9,
-            "ordered_list_kernel": {"kernel": "k_movegen_list<MASK> (ordered move list in the reference's generation order and the mask from one launch: one position per lane)",
+            "ordered_list_kernel": {"kernel": "k_movegen_list<MASK, no pad> (ordered move list in the reference's generation order, rows written up to their count — cz_movegen_ex CZ_MOVES_NO_PAD —, and the mask from one launch: one position per lane)",
                                     "positions_per_s": n / sec_list, "us_per_launch": sec_list * 1e6, "achieved": alg / sec_list / 1e9,
-                                    "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "traffic": tr_list, "abi_bytes_per_position": abi_list / n, "abi_GBps": abi_list / sec_list / 1e9,
-                                    "note": "issue-bound (VALU: the per-kind generation, the ordering by square, one LDS write per move), not bandwidth-bound: see DESIGN.md 4.6b"}}
+                                    "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "traffic": None, "mean_moves_per_position": mean_moves,
+                                    "abi_bytes_per_position": 90 + 1 + 264 + 2 + 16.0 * ((mean_moves + 7) // 8 + 0.5),
+                                    "padded": {"kernel": "k_movegen_list<MASK, pad> (cz_movegen: 0xFFFF padding to 128 labels)", "positions_per_s": n / sec_list_pad,
+                                               "us_per_launch": sec_list_pad * 1e6, "frac": alg / sec_list_pad / 1e9 / HBM_PEAK_GBS, "traffic": tr_list,
+                                               "abi_bytes_per_position": abi_list / n, "abi_GBps": abi_list / sec_list_pad / 1e9},
+                                    "note": "issue-bound (VALU: the per-kind generation, the ordering by square, one LDS write per move), not bandwidth-bound: see DESIGN.md 4.5"}}
 
 
 def _pick(d, keys):
@@ -255,7 +261,9 @@ def compact_line(full):
         o = dict(_pick(rr, ["bound", "achieved", "peak", "unit", "frac", "traffic", "positions", "positions_per_s", "us_per_launch"]), kernel="k_movegen_mask")
         ol = rr.get("ordered_list_kernel")
         if ol:
-            o["ordered_list_kernel"] = dict(_pick(ol, ["positions_per_s", "frac", "us_per_launch", "traffic"]), kernel="k_movegen_list<MASK>")
+            o["ordered_list_kernel"] = dict(_pick(ol, ["positions_per_s", "frac", "us_per_launch", "traffic"]), kernel="k_movegen_list<MASK>" + (" no pad" if "padded" in ol else ""))
+            if "padded" in ol:
+                o["ordered_list_kernel"]["padded"] = _pick(ol["padded"], ["positions_per_s", "frac", "us_per_launch", "traffic"])
         out["roofline_rules"] = o
     else:
         out["roofline_rules"] = rr

@@ -37,6 +37,7 @@ _SIGS = {
     "cz_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "cz_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "cz_movegen": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, _u16p, _u16p, _vp]),
+    "cz_movegen_ex": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, _u16p, _u16p, _vp, C.c_int]),
     "cz_apply_move": (C.c_int, [C.c_void_p, _u8p, _u8p, _u16p, C.c_int, _vp, _u8p, _vp]),
     "cz_hash": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, _vp]),
     "cz_encode_planes": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),

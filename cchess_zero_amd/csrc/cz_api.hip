@@ -178,6 +178,7 @@ void cz_destroy(cz_ctx *c) {
     if (c->pool_block) (void)hipFree(c->pool_block);
     if (c->sp_block) (void)hipFree(c->sp_block);
     if (c->ec_block) (void)hipFree(c->ec_block);
+    if (c->mx_xbuf) (void)hipFree(c->mx_xbuf);
     delete c;
 }
 
@@ -221,7 +222,15 @@ int cz_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uin
     CZ_REQUIRE(c && G >= 0, "cz_movegen: null ctx / negative G");
     if (G == 0) return CZ_OK;
     CZ_REQUIRE(boards && side && count, "cz_movegen: boards, side, count required");
-    return czk_movegen(c, boards, side, G, moves, count, mask);
+    return czk_movegen(c, boards, side, G, moves, count, mask, 0);
+}
+
+int cz_movegen_ex(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves, uint16_t *count, uint32_t *mask, int flags) {
+    CZ_REQUIRE(c && G >= 0, "cz_movegen_ex: null ctx / negative G");
+    CZ_REQUIRE((flags & ~CZ_MOVES_NO_PAD) == 0, "cz_movegen_ex: unknown flag");
+    if (G == 0) return CZ_OK;
+    CZ_REQUIRE(boards && side && count, "cz_movegen_ex: boards, side, count required");
+    return czk_movegen(c, boards, side, G, moves, count, mask, flags);
 }
 int cz_apply_move(cz_ctx *c, uint8_t *boards, uint8_t *side, const uint16_t *label, int G, uint64_t *hash, uint8_t *captured, int8_t *terminal) {
     CZ_REQUIRE(c && G >= 0, "cz_apply_move: null ctx / negative G");

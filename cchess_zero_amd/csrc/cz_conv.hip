@@ -3,6 +3,8 @@
 #include "cz_conv_kernel.h"
 #include "cz_trunk_split.h"
 #include "cz_trunk_mx.h"
+#include "cz_trunk_mx2.h"
+#include <cstdlib>
 
 extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, const void *residual,
                                     void *out, int B, int relu) {
@@ -118,11 +120,34 @@ extern "C" int cz_net_trunk_mx(cz_ctx *c, const void *planes16, const void *w0, 
     if (head_w && (reinterpret_cast<uintptr_t>(head_w) & 15u)) { cz_set_error("cz_net_trunk_mx: head_w must be 16-byte aligned"); return CZ_EINVAL; }
     if (reinterpret_cast<uintptr_t>(wpk) & 15u) { cz_set_error("cz_net_trunk_mx: wpk must be 16-byte aligned"); return CZ_EINVAL; }
     if (B == 0) return CZ_OK;
+    const int grid = (B + MX_P - 1) / MX_P;
+    if (!c->mx_kernel) {   // round 6: the 3 x 2-tile / K-split kernel is the default; CCHESS_MX_KERNEL=1 keeps round 5's for A/B runs
+        const char *e = getenv("CCHESS_MX_KERNEL");
+        c->mx_kernel = (e && e[0] == '1') ? 1 : 2;
+    }
+    if (c->mx_kernel == 2) {
+        if (!c->mx2_attr_set) {
+            CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trunk_mx2_c128), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
+            c->mx2_attr_set = true;
+        }
+        const size_t need = (size_t)grid * MX2_XBUF_FLOATS_PER_WG * sizeof(float);
+        if (need > c->mx_xbuf_bytes) {   // grown outside any capture: the first launch of a batch size allocates (as torch's allocator would)
+            CZ_HIP(hipStreamSynchronize(c->stream));
+            if (c->mx_xbuf) (void)hipFree(c->mx_xbuf);
+            c->mx_xbuf = nullptr; c->mx_xbuf_bytes = 0;
+            if (hipMalloc(&c->mx_xbuf, need) != hipSuccess) { c->mx_xbuf = nullptr; cz_set_error("cz_net_trunk_mx: hipMalloc(%zu B) for the block-input scratch failed", need); return CZ_ENOMEM; }
+            c->mx_xbuf_bytes = need;
+        }
+        hipLaunchKernelGGL(k_trunk_mx2_c128, dim3(grid), dim3(MX_THREADS), MX_LDS_BYTES, c->stream, (const unsigned char *)wpk, bias, trunk_out,
+                           head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count,
+                           clock_probe(c, grid), (float *)c->mx_xbuf);
+        CZ_HIP(hipGetLastError());
+        return CZ_OK;
+    }
     if (!c->mx_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trunk_mx_c128), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
         c->mx_attr_set = true;
     }
-    const int grid = (B + MX_P - 1) / MX_P;
     hipLaunchKernelGGL(k_trunk_mx_c128, dim3(grid), dim3(MX_THREADS), MX_LDS_BYTES, c->stream, (const unsigned char *)wpk, bias, trunk_out,
                        head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count,
                        clock_probe(c, grid));

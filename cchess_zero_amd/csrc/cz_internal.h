@@ -156,6 +156,10 @@ struct cz_ctx {
     bool adv_attr_set;   // dynamic-LDS opt-in of k_advance_lds done
     bool adv_force_global;   // cz_search_debug_advance_in_global_memory (tests): take the path of pools whose bitmap exceeds LDS
     bool conv_attr_set, tower_attr_set, split_attr_set, mx_attr_set;  // dynamic-LDS opt-in of the MFMA kernels done for this device
+    bool mx2_attr_set;
+    int mx_kernel;       // cz_net_trunk_mx: 0 = not chosen yet, 1 = k_trunk_mx_c128, 2 = k_trunk_mx2_c128 (default; CCHESS_MX_KERNEL=1 selects the former)
+    void *mx_xbuf;       // k_trunk_mx2_c128's block-input scratch (98,304 B per workgroup), grown on demand
+    size_t mx_xbuf_bytes;
     int width;         // simulations in flight per tree the pending arrays are sized for (cz_search_set_width)
     void *pend_block;  // separate allocation of the pending arrays when width > 1
     int terminal_extra;   // cz_search_set_terminal_extra: terminal simulations a tree may complete inside one select launch
@@ -218,7 +222,7 @@ __device__ __forceinline__ void ec_clear_tree(const CzTrees &t, int g, int tid, 
 }
 
 // kernels' launch wrappers (cz_rules.hip / cz_search.hip)
-int czk_movegen(cz_ctx *, const uint8_t *, const uint8_t *, int, uint16_t *, uint16_t *, uint32_t *);
+int czk_movegen(cz_ctx *, const uint8_t *, const uint8_t *, int, uint16_t *, uint16_t *, uint32_t *, int flags);
 int czk_apply_move(cz_ctx *, uint8_t *, uint8_t *, const uint16_t *, int, uint64_t *, uint8_t *, int8_t *);
 int czk_hash(cz_ctx *, const uint8_t *, const uint8_t *, int, uint64_t *);
 int czk_encode_planes(cz_ctx *, const uint8_t *, const uint8_t *, int, void *, int, int, int);

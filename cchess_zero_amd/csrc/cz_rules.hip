@@ -194,7 +194,10 @@ __global__ void k_apply_move(CzTables tab, uint8_t *__restrict__ boards, uint8_t
 // With mask != NULL the same launch writes the 2086-bit masks too: czm_list hands out the set's 15 (bit, field) pairs beside the
 // list (registers), and once the list rows have left the LDS holds 32 mask rows at a time, as in k_movegen_mask (here each
 // lane applies its own position's pairs while its half-wave has the rows).
-template <bool MASK>
+// PAD = false (cz_movegen_ex, CZ_MOVES_NO_PAD; round 6): a row is written up to its count only (in 16-byte pieces: the labels behind
+// `count` in the last piece are undefined) — the 0xFFFF padding is 2/3 of the list's 256 bytes (~40 moves per position), 65 LDS
+// stores per lane to make and 1.97x the kernel's algorithmic HBM traffic to write.
+template <bool MASK, bool PAD>
 __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
                                                      const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ moves,
                                                      uint16_t *__restrict__ count, uint32_t *__restrict__ mask) {
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict
             [&](int i) -> uint32_t & { return rows[(i & 15) * 64 + lane]; },
             [&]() {   // the scratch has been read: fill the rows with the 0xFFFF padding of the ABI
                 CZK_WAVE_SYNC();
-                for (int i = lane; i < 64 * CZK_LROW; i += 64) rows[i] = 0xFFFFFFFFu;
+                if (PAD)
+                    for (int i = lane; i < 64 * CZK_LROW; i += 64) rows[i] = 0xFFFFFFFFu;
                 CZK_WAVE_SYNC();
             },
             [&](int bit, uint32_t f) { if (MASK) recs[ne] = (f << 12) | (uint32_t)bit; ++ne; });
@@ -275,7 +279,8 @@ __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict
 #pragma unroll 4
         for (int k = 0; k < 16; ++k) {
             const int idx = lane + 64 * k, pp = idx >> 4, j = idx & 15;
-            if (pp < np) {
+            const int npp = PAD ? 128 : __shfl(n, pp, 64);     // position pp's count (negative: not a Xiangqi set, nothing to write)
+            if (pp < np && 8 * j < npp) {
                 const uint32_t *src = rows + pp * CZK_LROW + 4 * j;
                 dst[idx] = make_uint4(src[0], src[1], src[2], src[3]);
             }
@@ -376,14 +381,18 @@ inline int grid_for(int G) { return G < 65536 ? G : 65536; }
 
 }  // namespace
 
-int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves, uint16_t *count, uint32_t *mask) {
+int czk_movegen(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves, uint16_t *count, uint32_t *mask, int flags) {
     if (G == 0) return CZ_OK;
+    const bool pad = !(flags & CZ_MOVES_NO_PAD);
     if (moves && (reinterpret_cast<uintptr_t>(moves) & 15u)) { cz_set_error("cz_movegen: moves must be 16-byte aligned"); return CZ_EINVAL; }
     const int ngroups = (G + 63) / 64;
     if (moves) {    // the reference's ordered list (and, from the same launch, the set): one lane per position, 8-9 persistent waves per CU
         const int chip = 256 * 8;
-        if (mask) hipLaunchKernelGGL(k_movegen_list<true>, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
-        else hipLaunchKernelGGL(k_movegen_list<false>, dim3(ngroups < 256 * 9 ? ngroups : 256 * 9), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
+        const dim3 gm(ngroups < chip ? ngroups : chip), gl(ngroups < 256 * 9 ? ngroups : 256 * 9);
+        if (mask && pad) hipLaunchKernelGGL((k_movegen_list<true, true>), gm, dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
+        else if (mask) hipLaunchKernelGGL((k_movegen_list<true, false>), gm, dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
+        else if (pad) hipLaunchKernelGGL((k_movegen_list<false, true>), gl, dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
+        else hipLaunchKernelGGL((k_movegen_list<false, false>), gl, dim3(64), 0, c->stream, c->mask_tab, boards, side, G, moves, count, mask);
     } else {        // the set alone (k_movegen_mask: mask and count; mask may be NULL: counts only): 12 persistent waves per CU
         const int chip = 256 * 12;
         hipLaunchKernelGGL(k_movegen_mask, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->mask_tab, boards, side, G, count, mask);

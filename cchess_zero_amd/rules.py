@@ -51,9 +51,12 @@ class Rules:
             return a.to(self.dev).to(dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a)).to(self.dev).to(dtype).contiguous()
 
-    def movegen(self, boards, side, want_mask=True, want_moves=True):
+    def movegen(self, boards, side, want_mask=True, want_moves=True, pad=True, strict=False):
         """GameBoard.get_legal_moves for G positions -> (moves [G,128] i16(u16 bits), count [G], mask [G,66] i32).
-        want_moves=False: only the legal-move SET (mask) and the count — the mask-only kernel (k_movegen_mask), moves is None."""
+        want_moves=False: only the legal-move SET (mask) and the count — the mask-only kernel (k_movegen_mask), moves is None.
+        pad=False (CZ_MOVES_NO_PAD): rows are valid up to their count only, the rest of the (uninitialised) buffer is not written.
+        strict=True: raise if a board answered count 0xFFFF (not a Xiangqi set: its list / mask row is undefined; include/
+        cchess_hip.h) — synchronises; without it a caller checks `count == -1` (0xFFFF as int16) itself before it reads rows."""
         self.ctx.bind_stream()   # torch's current stream
         boards = self._dev(boards, torch.uint8).reshape(-1, NSQ)
         side = self._dev(side, torch.uint8)
@@ -61,8 +64,23 @@ class Rules:
         moves = torch.empty((G, MAXMOVES), dtype=torch.int16, device=self.dev) if want_moves else None
         count = torch.empty(G, dtype=torch.int16, device=self.dev)
         mask = torch.empty((G, MASK_WORDS), dtype=torch.int32, device=self.dev) if want_mask else None
-        check(lib().cz_movegen(self.ctx.h, _ptr(boards), _ptr(side), G, _ptr(moves), _ptr(count), _ptr(mask)), "cz_movegen")
+        if pad:
+            check(lib().cz_movegen(self.ctx.h, _ptr(boards), _ptr(side), G, _ptr(moves), _ptr(count), _ptr(mask)), "cz_movegen")
+        else:
+            check(lib().cz_movegen_ex(self.ctx.h, _ptr(boards), _ptr(side), G, _ptr(moves), _ptr(count), _ptr(mask), 1), "cz_movegen_ex")
+        if strict:
+            self.check_counts(count)
         return moves, count, mask
+
+    @staticmethod
+    def check_counts(count):
+        """Raises if any position answered count 0xFFFF (k_movegen_list / k_movegen_mask refuse boards that are not a Xiangqi
+        set; their rows are undefined and must not be consumed)."""
+        bad = (count == -1).nonzero().flatten()
+        if bad.numel():
+            from ._lib import CchessHipError
+            raise CchessHipError("cz_movegen: %d position(s) are not a Xiangqi set (count 0xFFFF), first at index %d: their move rows are undefined"
+                                 % (int(bad.numel()), int(bad[0])))
 
     def apply_move(self, boards, side, labels, hash_=None):
         """In-place GameBoard.sim_do_action for G games -> (captured [G] u8, terminal [G] i8)."""

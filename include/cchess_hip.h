@@ -123,6 +123,15 @@ int cz_download(cz_ctx *, void *dst_host, const void *src_device, size_t bytes);
  *     set), or an advisor / bishop step the 2086-label vocabulary has no label for. */
 int cz_movegen(cz_ctx *, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves,
                uint16_t *count, uint32_t *mask);
+/*     cz_movegen_ex: the same with flags.  CZ_MOVES_NO_PAD: row g of `moves` is written up to count[g] only (in 16-byte pieces; the
+ *     labels behind count[g] are UNDEFINED, not 0xFFFF) — the padding is two thirds of a row (~40 moves per position, main.py:743)
+ *     and was 1.97x the ordered kernel's algorithmic HBM traffic; a caller that reads rows up to `count`, as every consumer of
+ *     get_legal_moves' list does, loses nothing.  flags = 0 is cz_movegen.
+ *     The count-0xFFFF restriction above is the stand-alone kernels' only: the generator INSIDE the search (k_select, lane =
+ *     piece, csrc/cz_device.h) generates moves for any board the reference's get_legal_moves does. */
+#define CZ_MOVES_NO_PAD 1
+int cz_movegen_ex(cz_ctx *, const uint8_t *boards, const uint8_t *side, int G, uint16_t *moves,
+                  uint16_t *count, uint32_t *mask, int flags);
 /* K2  replaces GameBoard.sim_do_action (main.py:647-702), is_kill_move (:226) and the king test
  *     (:409-413).  Updates boards/side in place.  hash: in/out incremental Zobrist (may be NULL);
  *     captured [G] = captured piece code or 0; terminal [G]: bit0 'K' missing, bit1 'k' missing.

@@ -105,7 +105,7 @@ def test_generated_slab_asm_is_in_sync(tmp_path):
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("MX_ABLATE", "MX_DMA_PLACE")}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tower_asm.py"), str(tmp_path)], check=True, stdout=subprocess.DEVNULL, env=env)
-    for f in ("cz_tower_slab_asm.inc", "cz_trunk_split_asm.inc", "cz_trunk_mx_asm.inc"):
+    for f in ("cz_tower_slab_asm.inc", "cz_trunk_split_asm.inc", "cz_trunk_mx_asm.inc", "cz_trunk_mx2_asm.inc"):
         assert open(str(tmp_path / f)).read() == open(os.path.join(ROOT, "cchess_zero_amd", "csrc", f)).read(), f
 
 

@@ -38,6 +38,46 @@ def test_movegen_golden(rules, rules_golden):
     assert nomask is None and np.array_equal(_u16(count3), g["counts"])
 
 
+def test_movegen_golden_no_pad(rules, rules_golden):
+    """CZ_MOVES_NO_PAD (cz_movegen_ex): the same 4 381 reference lists, counts and masks with rows written
+    up to their count only.  The buffer is pre-filled with a sentinel: a row holds the golden labels up to its count, the
+    sentinel from the next 16-byte piece on (nothing is written there), and never 0xFFFF padding beyond the last piece."""
+    import ctypes as C
+    from cchess_zero_amd._lib import check, lib
+    g = rules_golden
+    G = len(g["counts"])
+    for want_mask in (True, False):
+        boards = torch.from_numpy(g["boards"]).cuda().contiguous()
+        side = torch.from_numpy(g["side"]).cuda().contiguous()
+        moves = torch.full((G, 128), 0x5A5A, dtype=torch.int16, device="cuda")
+        count = torch.empty(G, dtype=torch.int16, device="cuda")
+        mask = torch.empty((G, 66), dtype=torch.int32, device="cuda") if want_mask else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        rules.ctx.bind_stream()
+        check(lib().cz_movegen_ex(rules.ctx.h, p(boards), p(side), G, p(moves), p(count), p(mask), 1), "cz_movegen_ex")
+        mv, cnt = _u16(moves), _u16(count)
+        assert np.array_equal(cnt, g["counts"])
+        col = np.arange(128)[None, :]
+        valid = col < cnt[:, None]
+        assert np.array_equal(mv[valid], g["moves"][valid])
+        untouched = col >= ((cnt[:, None] + 7) // 8) * 8          # behind the last 16-byte piece of a row
+        assert (mv[untouched] == 0x5A5A).all() and untouched.sum() > 0.6 * mv.size
+        if want_mask:
+            _, _, m0 = rules.movegen(g["boards"], g["side"], want_moves=False)
+            assert torch.equal(mask, m0)
+    # the Python wrapper: pad=False is the same call; strict=True raises on a board that is not a Xiangqi set
+    mv2, cnt2, _ = rules.movegen(g["boards"][:100], g["side"][:100], want_mask=False, pad=False)
+    assert np.array_equal(_u16(cnt2), g["counts"][:100])
+    for i in range(100):
+        assert np.array_equal(_u16(mv2)[i, :g["counts"][i]], g["moves"][i, :g["counts"][i]])
+    bad = g["boards"][:4].copy()
+    bad[2, :] = 0
+    bad[2, :3] = 3 if g["side"][2] == 0 else 10               # three rooks of the side to move
+    from cchess_zero_amd._lib import CchessHipError
+    with pytest.raises(CchessHipError, match="not a Xiangqi set"):
+        rules.movegen(bad, g["side"][:4], strict=True)
+
+
 def test_apply_move_golden(rules, rules_golden):
     g = rules_golden
     boards = torch.from_numpy(g["boards"].copy()).cuda()

@@ -211,6 +211,86 @@ def slabMX(hs):
     return L
 
 
+# ---- k_trunk_mx2_c128 (cz_trunk_mx2.h, round 6): the same arithmetic, LDS layout and slab format as k_trunk_mx_c128 with a 3 x 2
+# register tile per wave and the K range of a layer split between the two waves of a pair (wave & 1 = kp handles the slabs
+# 2 p + kp): 18 MFMAs per body instead of 9 with 20 + 5 LDS reads per body instead of 2 x (12 + 4) per 18 MFMAs, one barrier
+# per PAIR of slabs, the partial sums exchanged once per layer.
+MX2_AX = ["v[226:231]", "v[232:237]", "v[238:243]"]   # fp6 activation blocks of the three cell tiles
+MX2_WX = ["v[244:249]", "v[250:255]"]                 # fp6 weight blocks of the two channel tiles (the body clobbers v226..v255)
+
+
+def slabMX2(first):
+    """One body = one 16 KB slab (32 input channels of one tap) for a 3 cell x 2 channel tile: 12 fp16 MFMAs + 6 fp6 MFMAs.
+    A wave sees two bodies per tap: `first` (quarter kp; the next body is quarter kp + 2 of the SAME tap: ab / key) and second
+    (quarter kp + 2; the next body is quarter kp of the NEXT tap: nab / nkey) — the C++ side passes the right address operands
+    as nab / nkey, and the quarter-dependent numbers as scalars (cba / cbb: 16-byte chunk of the next body's two k-steps; xo / yo:
+    plane offsets of this body's fp6 blocks; kp8 = 8 kp: the tap's scale dword is shifted so that bytes 0 / 2 are this wave's
+    quarters).  Channel tile j = 1 of the wave is 32 output channels = 512 / 256 / 128 bytes behind tile j = 0 in a slab's parts.
+      A (k-step 0, set a0h* / w0*)  waits for its set (the 5 reads of set B may be in flight); requests this body's 12 fp6
+                                    operand reads (+ 3 scale dwords in the first body of a tap)
+      B (k-step 1, set a1h* / w1*)  every read of this wave has returned (lgkmcnt 0: the pair the DMAs below overwrite is no
+                                    longer being read by anyone behind the barrier), its 4 DMA pieces have landed (vmcnt 0), barrier:
+                                    the next pair is published; requests the next body's set A; 2 DMA pieces of the pair after next
+      C (fp6, hard registers)       requests the next body's set B; the other 2 DMA pieces."""
+    f = lambda i, j, s: "v_mfma_f32_32x32x16_f16 %%[c%d%d], %%[w%d%d], %%[a%dh%d], %%[c%d%d]" % (i, j, s, j, s, i, i, j)
+    mx = lambda i, j: ("v_mfma_scale_f32_32x32x64_f8f6f4 %%[c%d%d], %s, %s, %%[c%d%d], %%[ws%d], %%[sb%d] op_sel:[0,0,0] op_sel_hi:[0,%d,0] cbsz:2 blgp:2"
+                       % (i, j, MX2_WX[j], MX2_AX[i], i, j, j, i, 0 if first else 1))
+    sub = lambda r, lo, hi: "v[%d:%d]" % (int(r[2:].split(":")[0]) + lo, int(r[2:].split(":")[0]) + hi)
+    L = ["s_mov_b32 %[keep], m0"]
+    # ---- step A
+    L += ["s_waitcnt lgkmcnt(5)"]
+    for i in range(3):
+        L += [f(i, 0, 0)]
+        L += ["v_add_u32 %%[t0], %%[xo], %%[xr%d]" % i, "v_add_u32 %%[t1], %%[yo], %%[yr%d]" % i,
+              "ds_read_b128 %s, %%[t0]" % sub(MX2_AX[i], 0, 3), "ds_read_b64 %s, %%[t1]" % sub(MX2_AX[i], 4, 5)]
+        L += [f(i, 1, 0)]
+        if i < 2:
+            j = i
+            L += ["ds_read_b128 %s, %%[vb] offset:%d" % (sub(MX2_WX[j], 0, 3), 8192 + 512 * j), "ds_read_b64 %s, %%[vy] offset:%d" % (sub(MX2_WX[j], 4, 5), 256 * j),
+                  "ds_read_b32 %%[ws%d], %%[vs] offset:%d" % (j, 128 * j)]
+        elif first:   # the tap's activation scales: one dword per cell = the four 32-channel quarters' E8M0 bytes of this lane's half
+            L += ["v_lshrrev_b32 %%[t%d], 1, %%[yr%d]" % (k, k) for k in range(3)]
+            L += ["ds_read_b32 %%[sb%d], %%[t%d] offset:%d" % (k, k, MX_S_OFF) for k in range(3)]
+    # ---- step B
+    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
+    # piece k of the wave: 1 KB at byte 8192 k + 16 tid of the 32 KB pair, to the same offset of the pair's two ring buffers
+    dma = [["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]]
+    dma += [["s_add_u32 m0, %%[ldst], 0x%x" % (0x2000 * k), "v_add_u32 %%[t3], 0x%x, %%[voff0]" % (0x2000 * k),
+             "global_load_lds_dwordx4 %[t3], %[sbase]"] for k in (1, 2, 3)]
+
+    def half(s, cb, woff, d0, d1, pre=None):
+        """6 MFMAs of operand set s (fp16 k-step 1, or the fp6 step when s is None) with the requests of the next body's set
+        1 - s... interleaved: address VALU, 5 reads, two DMA pieces"""
+        X = 0 if s == 1 else 1          # the set being requested
+        m = (lambda i, j: f(i, j, 1)) if s == 1 else (lambda i, j: mx(i, j))
+        o = list(pre or [])
+        o += [m(0, 0)]
+        o += ["v_xor_b32 %%[t%d], %%[%s], %%[nkey%d]" % (k, cb, k) for k in range(3)]
+        o += [m(0, 1)]
+        o += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[nab%d]" % (k, k, k) for k in range(3)]
+        o += d0
+        o += [m(1, 0)]
+        o += ["ds_read_b128 %%[a%dh0], %%[t0]" % X, "ds_read_b128 %%[a%dh1], %%[t1]" % X]
+        o += [m(1, 1)]
+        o += ["ds_read_b128 %%[a%dh2], %%[t2]" % X, "ds_read_b128 %%[w%d0], %%[vbn] offset:%d" % (X, woff)]
+        o += d1
+        o += [m(2, 0)]
+        o += ["ds_read_b128 %%[w%d1], %%[vbn] offset:%d" % (X, woff + 512)]
+        o += [m(2, 1)]
+        return o
+    L += half(1, "cba", 0, dma[0], dma[1])
+    # ---- step C
+    pre = ["v_lshrrev_b32 %%[sb%d], %%[kp8], %%[sb%d]" % (k, k) for k in range(3)] if first else []
+    L += half(None, "cbb", 4096, dma[2], dma[3], pre)
+    L += ["s_mov_b32 m0, %[keep]"]
+    ab = [a for a in os.environ.get("MX_ABLATE", "").split(",") if a]
+    if "nodma" in ab:
+        L = [l for l in L if not l.startswith("global_load_lds")]
+    if "nobarrier" in ab:
+        L = [l for l in L if l != "s_barrier"]
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -276,8 +356,14 @@ def main():
     for hs in range(4):
         txt += emit("MX_SKIP0_ASM_Q%d" % hs, branchy(slabMX(hs), ("%[c0],",))) + "\n"
     open(os.path.join(csrc, "cz_trunk_mx_asm.inc"), "w").write(txt)
-    print("wrote cz_tower_slab_asm.inc (%d instructions per slab), cz_trunk_split_asm.inc (%d), cz_trunk_mx_asm.inc (%d)" %
-          (len(slab8(0)), len(slabX(0, XS_LO_OFF)), len(slabMX(1))))
+    txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
+    txt += "// k_trunk_mx2_c128: 8 waves / 2 positions, 3 x 2 tiles per wave, K split between the waves of a pair: 12 fp16 + 6 fp6 MFMAs per body\n"
+    for name, first in (("A", True), ("B", False)):
+        txt += emit("MX2_BODY_%s" % name, slabMX2(first)) + "\n"
+        txt += emit("MX2_SKIP0_%s" % name, branchy(slabMX2(first), ("%[c00],", "%[c01],"))) + "\n"
+    open(os.path.join(csrc, "cz_trunk_mx2_asm.inc"), "w").write(txt)
+    print("wrote cz_tower_slab_asm.inc (%d instructions per slab), cz_trunk_split_asm.inc (%d), cz_trunk_mx_asm.inc (%d), cz_trunk_mx2_asm.inc (%d per body)" %
+          (len(slab8(0)), len(slabX(0, XS_LO_OFF)), len(slabMX(1)), len(slabMX2(False))))
 
 
 if __name__ == "__main__":
