@@ -49,6 +49,7 @@ _SIGS = {
     "cz_search_debug_advance_in_global_memory": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_set_xcache": (C.c_int, [C.c_void_p, C.c_int]),
     "cz_search_xcache_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "cz_search_xcache_stats5": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "cz_search_reload": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, _i32p]),
     "cz_search_select": (C.c_int, [C.c_void_p, C.c_int, _u8p, _vp, C.c_int, C.c_int, _u8p]),
     "cz_search_expand_backup": (C.c_int, [C.c_void_p, _vp, _vp, C.c_int]),

@@ -319,9 +319,9 @@ int cz_search_set_xcache(cz_ctx *c, int log2_entries) {
     }
     if (!c->t.ec_key) { cz_set_error("cz_search_set_xcache: switch the per-tree evaluation cache on first (cz_search_set_eval_cache(ctx, 1))"); return CZ_EINVAL; }
     const size_t n = (size_t)1 << log2_entries;
-    // per entry: key 8, value 4, count 4, position 48, labels 256, (src, dst) 256, priors 512 = 1088 bytes; + 16 bytes of counters per tree
+    // per entry: key 8, value 4, count 4, position 48, labels 256, (src, dst) 256, priors 512 = 1088 bytes; + 32 bytes of counters per tree
     if (!c->xc_block) {
-        const size_t bytes = n * 1088 + 64 + (size_t)c->max_games * 16;
+        const size_t bytes = n * 1088 + 64 + (size_t)c->max_games * 32;
         if (hipMalloc(&c->xc_block, bytes) != hipSuccess) { c->xc_block = nullptr; cz_set_error("cz_search_set_xcache: hipMalloc(%zu B) failed", bytes); return CZ_ENOMEM; }
         c->xc_log2_entries = log2_entries;
         c->t.xc_base = (char *)c->xc_block;
@@ -329,19 +329,26 @@ int cz_search_set_xcache(cz_ctx *c, int log2_entries) {
     }
     // an empty table (new weights => remembered evaluations are stale): only the keys and the counters need clearing
     CZ_HIP(hipMemsetAsync(c->xc_block, 0, n * 8 + 64, c->stream));
-    CZ_HIP(hipMemsetAsync(czx_tree_stats(c->t), 0, (size_t)c->max_games * 16, c->stream));
+    CZ_HIP(hipMemsetAsync(czx_tree_stats(c->t), 0, (size_t)c->max_games * 32, c->stream));
+    return CZ_OK;
+}
+static int xcache_stats5(cz_ctx *c, unsigned long long *stats, int n) {
+    for (int k = 0; k < n; ++k) stats[k] = 0;
+    if (!c->t.xc_base) return CZ_OK;
+    std::vector<uint32_t> per((size_t)c->max_games * 8);     // per tree: hits, lookups, written, no room, replaced, 3 spare
+    CZ_HIP(hipMemcpyAsync(per.data(), czx_tree_stats(c->t), per.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    CZ_HIP(hipStreamSynchronize(c->stream));
+    for (size_t g = 0; g < (size_t)c->max_games; ++g)
+        for (int k = 0; k < n; ++k) stats[k] += per[g * 8 + k];
     return CZ_OK;
 }
 int cz_search_xcache_stats(cz_ctx *c, unsigned long long *stats4) {
     CZ_REQUIRE(c && stats4, "cz_search_xcache_stats: null argument");
-    stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0;
-    if (!c->t.xc_base) return CZ_OK;
-    std::vector<uint32_t> per((size_t)c->max_games * 4);
-    CZ_HIP(hipMemcpyAsync(per.data(), czx_tree_stats(c->t), per.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    CZ_HIP(hipStreamSynchronize(c->stream));
-    for (size_t g = 0; g < (size_t)c->max_games; ++g)
-        for (int k = 0; k < 4; ++k) stats4[k] += per[g * 4 + k];
-    return CZ_OK;
+    return xcache_stats5(c, stats4, 4);
+}
+int cz_search_xcache_stats5(cz_ctx *c, unsigned long long *stats5) {
+    CZ_REQUIRE(c && stats5, "cz_search_xcache_stats5: null argument");
+    return xcache_stats5(c, stats5, 5);
 }
 int cz_search_debug_eval_cache_key_bits(cz_ctx *c, int bits) {
     CZ_REQUIRE(c && (bits == 64 || (bits >= 8 && bits <= 24)), "cz_search_debug_eval_cache_key_bits: bits must be 8..24 or 64");

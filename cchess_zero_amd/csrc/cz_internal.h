@@ -75,7 +75,10 @@ struct CzSelfplay {
 // syntax — t.status[g] — through CzRecField: every field of the union below IS the record pointer plus a constant offset.
 struct CzTreeRec {
     int32_t root_rr, root_node, n_nodes, status;      //  0
-    int32_t sims, last_depth, pend_kind, pend_leaf;   // 16  pending leaf between select and expand_backup (width 1)
+    int32_t sims;                                     // 16
+    int16_t last_depth;                               // 20  depth of the last simulation (statistics)
+    uint16_t root_ply;                                // 22  re-roots since the tree was (re)set: the root's ply in its game (cross-tree cache priority)
+    int32_t pend_kind, pend_leaf;                     // 24  pending leaf between select and expand_backup (width 1)
     float pend_value;                                 // 32
     int32_t pend_depth;                               // 36  levels of the pending path (pend_path)
     uint32_t ec_hits, ec_lookups;                     // 40  evaluation cache statistics of the tree
@@ -104,7 +107,7 @@ struct CzTrees {
     union {              // [max_games] records; t.<field>[g] addresses rec[g].<field>
         CzTreeRec *rec;
         CZ_REC_FIELD(int32_t, root_rr); CZ_REC_FIELD(int32_t, root_node); CZ_REC_FIELD(int32_t, n_nodes);
-        CZ_REC_FIELD(int32_t, status); CZ_REC_FIELD(int32_t, sims); CZ_REC_FIELD(int32_t, last_depth);
+        CZ_REC_FIELD(int32_t, status); CZ_REC_FIELD(int32_t, sims); CZ_REC_FIELD(int16_t, last_depth); CZ_REC_FIELD(uint16_t, root_ply);
         CZ_REC_FIELD(int32_t, pend_kind); CZ_REC_FIELD(int32_t, pend_leaf); CZ_REC_FIELD(float, pend_value);
         CZ_REC_FIELD(int32_t, pend_depth); CZ_REC_FIELD(uint32_t, ec_hits); CZ_REC_FIELD(uint32_t, ec_lookups); CZ_REC_FIELD(uint32_t, ec_collisions);
         CZ_REC_FIELD(unsigned long long, pend_key); CZ_REC_FIELD(uint16_t, pend_nmoves);
@@ -130,9 +133,12 @@ struct CzTrees {
     // cross-tree level of the evaluation cache (cz_search_set_xcache): ONE table per context, shared by all of its trees.  An
     // entry cannot lend node indices (the lender tree's nodes move at its next re-root), so it is self-contained: key, packed
     // position, the value the evaluation backed up, the move count, the <= 128 labels / (src, dst) pairs / priors.  Entries are
-    // written once: k_expand_backup claims an empty slot of the key's 64-entry bucket with an atomic compare-and-swap on the key
-    // and fills it; k_select (a later launch: the kernel boundary publishes the payload) only reads.  Emptied by the host
-    // whenever the weights change.
+    // claimed by k_expand_backup with an atomic compare-and-swap on the key — an empty slot of the key's 64-entry bucket, or,
+    // when the bucket is full (round 6), the entry whose position lies DEEPEST in its game (game ply = re-roots of the filing tree
+    // + depth of the leaf, kept in the upper half of the move-count word) if the new position is shallower: the table converges
+    // to the shallowest positions ever evaluated — the openings every restarted game walks through again — instead of whatever
+    // arrived first.  k_select (a later launch: the kernel boundary publishes the payload) only reads, and verifies the stored
+    // position on every hit.  Emptied by the host whenever the weights change.
     // ONE base pointer (the kernels are short of scalar registers): with n = (xc_mask + 1) * 64 entries the block holds
     //   keys u64 [n] | counters u64 [8] | value f32 [n] | move count u32 [n] | position u32 [n][12] | labels u16 [n][128] |
     //   (src, dst) u16 [n][128] | priors f32 [n][128]        (czx_* below)

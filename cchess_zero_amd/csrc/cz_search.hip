@@ -24,7 +24,7 @@ __device__ __forceinline__ void reset_tree(const CzTrees &t, int g, int lane, co
     if (lane == 0) {
         t.root_side[g] = side[g] ? 1 : 0;
         t.root_rr[g] = rr ? rr[g] : 0;
-        t.root_node[g] = 0; t.n_nodes[g] = 1; t.status[g] = 0; t.sims[g] = 0; t.last_depth[g] = 0;
+        t.root_node[g] = 0; t.n_nodes[g] = 1; t.status[g] = 0; t.sims[g] = 0; t.last_depth[g] = 0; t.root_ply[g] = 0;
         t.pend_kind[g] = 0; t.pend_leaf[g] = 0; t.pend_value[g] = 0.f; t.pend_side[g] = 0; t.pend_nmoves[g] = 0;
         init_root(view_of(t, g), 0);
     }
@@ -311,12 +311,12 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
                             if (__ballot(lb != pk) == 0ull) { xe = (long long)(xb0 + hl); break; }
                         }
                         if (xe >= 0) { pend = czx_val(t)[xe]; hit = true; }
-                        if (lane == 0) { uint32_t *xs = czx_tree_stats(t) + (size_t)g * 4; xs[1] += 1u; if (xe >= 0) xs[0] += 1u; }
+                        if (lane == 0) { uint32_t *xs = czx_tree_stats(t) + (size_t)g * 8; xs[1] += 1u; if (xe >= 0) xs[0] += 1u; }
                     }
                     if (!hit) break;
                     // the lender: an expanded node of this tree (its children's arrays) or a cross-tree entry's arrays
                     const int scb = (XC && xe >= 0) ? 0 : v.child_begin[src];
-                    const int n = (XC && xe >= 0) ? (int)czx_cnt(t)[xe] : (int)v.child_count[src];
+                    const int n = (XC && xe >= 0) ? (int)(czx_cnt(t)[xe] & 0xFFFFu) : (int)v.child_count[src];
                     const int begin = t.n_nodes[g];
                     if (begin + n <= t.cap) {   // leaf_node.expand with the lender's priors
 #pragma unroll
@@ -399,7 +399,7 @@ __device__ __forceinline__ void select_body(const CzTrees &t, const CzTables &ta
         t.pend_kind[g] = kind; t.pend_leaf[g] = leaf; t.pend_value[g] = pend;
         t.pend_side[g] = (uint8_t)side; t.pend_nmoves[g] = (uint16_t)nmoves;
         t.pend_depth[g] = depth;
-        if (!parked) t.last_depth[g] = depth;
+        if (!parked) t.last_depth[g] = (int16_t)depth;
         if (needs_eval) needs_eval[g] = (kind == 1 || kind == 3) ? 1 : 0;
     }
 }
@@ -638,22 +638,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
                 const size_t xb0 = (size_t)(xc_bucket(key) & t.xc_mask) * 64;
                 const unsigned long long xk = czx_key(t)[xb0 + lane];
                 const unsigned long long xm = __ballot(xk == 0ull);
-                if (__ballot(xk == key) == 0ull && xm) {
-                    // the first empty slot at or behind a key-dependent position: trees filing different positions into one
-                    // bucket in the same launch do not all go for slot 0 (the loser of a swap does not retry: write-once table)
-                    // (a tree that loses the swap to ANOTHER position tries the next empty slot, up to three times — a lost
-                    // swap no longer drops the entry while the bucket has room; losing it to the SAME position means it is filed)
-                    const int rot = (int)((key >> 40) & 63);
-                    unsigned long long xr = rot ? (xm >> rot) | (xm << (64 - rot)) : xm;
-                    int slot = 0, won = 0;
-                    for (int attempt = 0; attempt < 3 && xr && !won; ++attempt) {
-                        slot = (__ffsll((long long)xr) - 1 + rot) & 63;
-                        xr &= xr - 1ull;
-                        unsigned long long seen = 0ull;
-                        if (lane == 0) seen = atomicCAS(&czx_key(t)[xb0 + slot], 0ull, key);
-                        seen = __shfl(seen, 0, 64);
-                        won = seen == 0ull ? 1 : 0;
-                        if (seen == key) break;
+                if (__ballot(xk == key) == 0ull) {
+                    // this position's game ply: re-roots of the tree + levels below the root (the priority of the entry: low = shared)
+                    const uint32_t myply = (uint32_t)min((int)t.root_ply[g] + (int)t.pend_depth[g], 0xFFFF);
+                    int slot = 0, won = 0, dup = 0;
+                    if (xm) {
+                        // the first empty slot at or behind a key-dependent position: trees filing different positions into one
+                        // bucket in the same launch do not all go for slot 0; a tree that loses the swap to ANOTHER position tries the
+                        // next empty slot, up to three times; losing it to the SAME position means it is filed
+                        const int rot = (int)((key >> 40) & 63);
+                        unsigned long long xr = rot ? (xm >> rot) | (xm << (64 - rot)) : xm;
+                        for (int attempt = 0; attempt < 3 && xr && !won && !dup; ++attempt) {
+                            slot = (__ffsll((long long)xr) - 1 + rot) & 63;
+                            xr &= xr - 1ull;
+                            unsigned long long seen = 0ull;
+                            if (lane == 0) seen = atomicCAS(&czx_key(t)[xb0 + slot], 0ull, key);
+                            seen = __shfl(seen, 0, 64);
+                            won = seen == 0ull ? 1 : 0;
+                            dup = seen == key ? 1 : 0;
+                        }
+                    } else {
+                        // full bucket: the entry deepest in its game makes room if this position is shallower.  One attempt: a lost
+                        // swap (another tree of this launch took the victim) drops the filing.
+                        const uint32_t ep = czx_cnt(t)[xb0 + lane] >> 16;
+                        uint32_t best = (ep << 6) | (uint32_t)lane;
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 64));
+                        if ((best >> 6) > myply) {
+                            slot = (int)(best & 63u);
+                            const unsigned long long old = __shfl(xk, slot, 64);
+                            unsigned long long seen = 0ull;
+                            if (lane == 0) seen = atomicCAS(&czx_key(t)[xb0 + slot], old, key);
+                            seen = __shfl(seen, 0, 64);
+                            won = seen == old ? 1 : 0;
+                            if (won && lane == 0) czx_tree_stats(t)[(size_t)g * 8 + 4] += 1u;
+                        }
                     }
                     if (won) {
                         const size_t e = xb0 + slot;
@@ -669,9 +688,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_
                                 czx_sd(t)[e * CZD_MAXMOVES + i] = v.sd[cb2 + i];
                             }
                         }
-                        if (lane == 0) { czx_val(t)[e] = val; czx_cnt(t)[e] = (uint32_t)n2; czx_tree_stats(t)[(size_t)g * 4 + 2] += 1u; }
-                    } else if (lane == 0) {
-                        czx_tree_stats(t)[(size_t)g * 4 + 3] += 1u;
+                        if (lane == 0) { czx_val(t)[e] = val; czx_cnt(t)[e] = (uint32_t)n2 | (myply << 16); czx_tree_stats(t)[(size_t)g * 8 + 2] += 1u; }
+                    } else if (!dup && lane == 0) {
+                        czx_tree_stats(t)[(size_t)g * 8 + 3] += 1u;     // filings that found no room (deeper than everything in a full bucket, or lost every swap)
                     }
                 }
             }
@@ -876,7 +895,7 @@ __global__ __launch_bounds__(64) void k_select_k(CzTrees t, CzTables tab, int G,
         if (lane == 0) {
             t.pk_kind[slot] = kind; t.pk_leaf[slot] = leaf; t.pk_value[slot] = 0.f;
             t.pk_side[slot] = (uint8_t)side; t.pk_nmoves[slot] = (uint16_t)nmoves;
-            if (kind) t.last_depth[g] = depth;
+            if (kind) t.last_depth[g] = (int16_t)depth;
             if (needs_eval) needs_eval[slot] = kind ? 1 : 0;
         }
         __threadfence_block();
@@ -1025,6 +1044,7 @@ __global__ __launch_bounds__(256) void k_advance_global(CzTrees t, CzTables tab,
         rb[dst] = rb[src]; rb[src] = 0;
         t.root_side[g] ^= 1;
         t.root_rr[g] = cap ? 0 : t.root_rr[g] + 1;
+        t.root_ply[g] = (uint16_t)min((int)t.root_ply[g] + 1, 65535);
         t.sims[g] = 0;
     }
     __syncthreads();
@@ -1167,6 +1187,7 @@ __device__ __forceinline__ void advance_tree_lds(const CzTrees &t, const CzTable
         rb[dst] = rb[src]; rb[src] = 0;
         t.root_side[g] ^= 1;
         t.root_rr[g] = cap ? 0 : t.root_rr[g] + 1;
+        t.root_ply[g] = (uint16_t)min((int)t.root_ply[g] + 1, 65535);
         t.sims[g] = 0;
     }
     __syncthreads();

@@ -44,7 +44,7 @@ __device__ __forceinline__ void seed_slot(const CzTrees &t, const CzSelfplay &sp
     if (lane == 0) {
         t.root_side[g] = sp.start_side[g];
         t.root_rr[g] = sp.start_rr[g];
-        t.root_node[g] = 0; t.n_nodes[g] = 1; t.status[g] = 0; t.sims[g] = 0; t.last_depth[g] = 0;
+        t.root_node[g] = 0; t.n_nodes[g] = 1; t.status[g] = 0; t.sims[g] = 0; t.last_depth[g] = 0; t.root_ply[g] = 0;
         init_root(view_of(t, g), 0);
         sp.ply[g] = 0; sp.stalled[g] = 0;
     }

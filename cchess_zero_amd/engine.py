@@ -115,10 +115,12 @@ class SearchEngine:
         self.xcache_log2 = int(log2_entries)
 
     def xcache_stats(self):
-        """-> dict(hits, lookups, written, lost) of the cross-tree level since it was last emptied."""
-        a = (C.c_ulonglong * 4)()
-        check(lib().cz_search_xcache_stats(self.ctx.h, a), "cz_search_xcache_stats")
-        return dict(hits=int(a[0]), lookups=int(a[1]), written=int(a[2]), lost=int(a[3]))
+        """-> dict(hits, lookups, written, lost, replaced) of the cross-tree level since it was last emptied: lost = filings that
+        found no room (a full bucket of shallower positions, or every swap lost), replaced = entries that took a deeper one's
+        place (part of `written`)."""
+        a = (C.c_ulonglong * 5)()
+        check(lib().cz_search_xcache_stats5(self.ctx.h, a), "cz_search_xcache_stats5")
+        return dict(hits=int(a[0]), lookups=int(a[1]), written=int(a[2]), lost=int(a[3]), replaced=int(a[4]))
 
     def eval_cache_stats(self):
         """-> (hits, lookups) summed over the trees since the cache was turned on."""

@@ -228,14 +228,19 @@ int cz_search_eval_cache_stats(cz_ctx *, unsigned long long *hits, unsigned long
 int cz_search_eval_cache_collisions(cz_ctx *, unsigned long long *collisions);
 int cz_search_debug_eval_cache_key_bits(cz_ctx *, int bits);
 /* Cross-tree level of the evaluation cache (needs cz_search_set_eval_cache(ctx, 1)): one table of 2^log2_entries self-contained,
- * write-once entries (key, packed position, value, the <= 128 labels and priors: 1088 bytes each) shared by all trees of the
+ * entries (key, packed position, value, the <= 128 labels and priors: 1088 bytes each) shared by all trees of the
  * context — in self-play from the start position the games share their openings, and the reference evaluates the same position
  * once per game (main.py:357-384).  A leaf whose position ANY tree has evaluated is expanded inside the select launch from the
  * remembered row, verified against the stored position; trees stay bit-identical (the net's row for a position does not depend
  * on the tree it is asked for).  log2_entries 0 frees the table; calling it again (or cz_search_set_eval_cache(ctx, 1)) empties
- * it — do so whenever the weights change.  stats4: hits, lookups, entries written, slot claims lost to another tree. */
+ * it — do so whenever the weights change.  Round 6: a FULL bucket is no longer closed — the entry whose position lies deepest in
+ * its game (re-roots of the filing tree + depth of the leaf) is replaced when the new position is shallower, so the table converges
+ * to the openings every restarted game walks through again.  stats4: hits, lookups, entries written, filings that found no room
+ * (a full bucket of shallower positions, or every swap lost to another tree of the launch); stats5 adds: entries that replaced
+ * a deeper one (included in `written`). */
 int cz_search_set_xcache(cz_ctx *, int log2_entries);
 int cz_search_xcache_stats(cz_ctx *, unsigned long long *stats4);
+int cz_search_xcache_stats5(cz_ctx *, unsigned long long *stats5);
 /* tests: cz_search_advance keeps the kept-node bitmap of a tree in LDS when it fits (12 bytes per 64 nodes) and in global memory
  * otherwise; on != 0 forces the global-memory kernel so that it is exercised at test sizes. */
 int cz_search_debug_advance_in_global_memory(cz_ctx *, int on);

@@ -169,6 +169,13 @@ def test_eval_cache_and_terminal_extra_leave_real_net_selfplay_unchanged():
     rec0, st0, _, _ = run(False)
     rec1, st1, hits, _ = run(True)
     rec2, st2, hits2, xst = run(True, 14)      # + the cross-tree level: all 64 games start from the same position
+    # a table far too small for the run (2^8 entries = four buckets): full buckets replace their deepest-in-game entry by a
+    # shallower position (round 6) — records still byte-identical, replacements and refusals both seen
+    rec3, st3, _, xst3 = run(True, 8)
+    print("cross-tree level with 256 entries:", xst3)
+    assert rec0.shape == rec3.shape and np.array_equal(rec0, rec3)
+    assert xst3["replaced"] > 0 and xst3["lost"] > 0 and xst3["written"] >= 256 + xst3["replaced"] - 8 and xst3["hits"] > 0
+    assert xst["replaced"] == 0 or xst["written"] > xst["replaced"]
     print("real net, %d games x %d plies x %d playouts: %d records; cache hits %d / %d lookups; with the cross-tree level %s" %
           (G, plies, playouts, len(rec0), hits[0], hits[1], xst))
     assert len(rec0) > 0 and rec0.shape == rec1.shape and np.array_equal(rec0, rec1)
