@@ -241,7 +241,7 @@ def compact_line(full):
     c = full.get("config") or {}
     out["config"] = _pick(c, ["workload", "games_per_gpu", "playout", "res_block_nums", "world_size", "dist_backend", "per_rank_sims_per_s",
                               "efficiency_vs_min_rank", "efficiency_vs_max_rank", "per_rank_spread", "per_rank_busy_seconds", "rank_cpus", "search_threads", "simulations_per_net_row", "net_rows_per_step",
-                              "terminal_extra", "record_gather", "trees_with_error_status", "mean_leaf_depth", "node_pool_GB"])
+                              "terminal_extra", "record_gather", "trees_with_error_status", "mean_leaf_depth", "node_pool_GB", "ms_per_move", "launches_per_lock_step", "lock_steps_per_move"])
     if c.get("selfplay"):
         out["config"]["selfplay"] = _pick(c["selfplay"], ["games_finished", "records", "dropped_records", "stalled_games", "timed_gather", "gathers",
                                                           "gathered_records", "pending_after_flush"])
@@ -925,6 +925,10 @@ def main():
         "fast_engine": strict_out if alt_key == "fast_engine" else None, "net_error": None, "config": cfg,
         "roofline": roof, "roofline_tree": tree_roof, "roofline_rules": None,
     }
+    # the --mode play shape (one tree, search_threads in flight: main.py:1433-1491,231): what a move costs, and how many launches
+    cfg["ms_per_move"] = playout / max(1e-9, head_val / (world * G)) * 1e3     # `playout` simulations of ONE tree at the measured rate
+    cfg["launches_per_lock_step"] = (4 if fused_fc else (5 if net.backend == "hip" else None))   # select, trunk, value / FC heads, expand (+ k_policy_fc without the folded FC)
+    cfg["lock_steps_per_move"] = head_ms and cfg["ms_per_move"] / head_ms
     cfg["efficiency_vs_min_rank"] = head_val / (world * min(own_rate))
     cfg["efficiency_vs_max_rank"] = head_val / (world * max(own_rate))
     if rank == 0:
