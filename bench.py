@@ -45,9 +45,9 @@ START = START_BOARD
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp16x2": 2500.0, "bf16x2": 2500.0, "mx6": 2500.0}  # dense peaks, same guide (x2 / mx6: the strict engines; algorithmic flops of the fp32 graph against the 16-bit MFMA peak)
-MX_KERNEL = "k_trunk_mx_c128" if os.environ.get("CCHESS_MX_KERNEL", "")[:1] == "1" else "k_trunk_mx2_c128"   # what cz_net_trunk_mx launches (csrc/cz_conv.hip)
+MX_KERNEL = "k_trunk_mx_c128"   # what cz_net_trunk_mx launches (csrc/cz_conv.hip; experiment builds with CCHESS_MX_KERNEL=2: k_trunk_mx2_c128)
 TRUNK_KERNEL = {"fp16": "k_tower8_c128", "bf16": "k_tower8_c128", "fp16x2": "k_trunk_split_c128", "bf16x2": "k_trunk_split_c128", "mx6": MX_KERNEL}
-TRAFFIC_FILE = {"k_tower8_c128": "pmc_traffic.json", "k_trunk_split_c128": "pmc_traffic_strict.json", "k_trunk_mx_c128": "pmc_traffic_mx.json", "k_trunk_mx2_c128": "pmc_traffic_mx2.json"}
+TRAFFIC_FILE = {"k_tower8_c128": "pmc_traffic.json", "k_trunk_split_c128": "pmc_traffic_strict.json", "k_trunk_mx_c128": "pmc_traffic_mx.json"}
 
 # The unmodified reference (pure Python) timed in the build container — it cannot run on the GPU box, where
 # /root/reference does not exist; recorded in BASELINE.md and attached to the line as static, labelled fields.
@@ -776,7 +776,7 @@ def main():
     ISSUE_FAST = (96.0 / 90.0) * (93.0 / 108.0)
     ISSUE_SPLIT = 3.0 * (96.0 / 90.0) * (17.0 / 18.0)
     ISSUE_MX = 1.5 * (96.0 / 90.0) * (17.0 / 18.0)      # two fp16 MFMAs + one 8-pass fp6 MFMA per 32 input channels, in fp16-MFMA passes
-    issue_of = lambda kernel: {"k_trunk_split_c128": ISSUE_SPLIT, "k_trunk_mx_c128": ISSUE_MX, "k_trunk_mx2_c128": ISSUE_MX}.get(kernel, ISSUE_FAST)
+    issue_of = lambda kernel: {"k_trunk_split_c128": ISSUE_SPLIT, "k_trunk_mx_c128": ISSUE_MX}.get(kernel, ISSUE_FAST)
 
     def trunk_roofline(conv_ms_, n_launches, issued_factor, kernel_name, clock_, telemetry_, traffic=traffic, traffic_src=traffic_src):
         nl_ = 2 * args.blocks

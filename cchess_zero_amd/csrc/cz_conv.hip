@@ -3,8 +3,10 @@
 #include "cz_conv_kernel.h"
 #include "cz_trunk_split.h"
 #include "cz_trunk_mx.h"
+#ifdef CZ_EXPERIMENT_MX2   /* tools/experiments/mx_ablate.sh: the 3 x 2-tile / K-split variant of round 6 (measured, not adopted: DESIGN.md 4.2) */
 #include "cz_trunk_mx2.h"
 #include <cstdlib>
+#endif
 
 extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, const void *residual,
                                     void *out, int B, int relu) {
@@ -121,9 +123,10 @@ extern "C" int cz_net_trunk_mx(cz_ctx *c, const void *planes16, const void *w0, 
     if (reinterpret_cast<uintptr_t>(wpk) & 15u) { cz_set_error("cz_net_trunk_mx: wpk must be 16-byte aligned"); return CZ_EINVAL; }
     if (B == 0) return CZ_OK;
     const int grid = (B + MX_P - 1) / MX_P;
-    if (!c->mx_kernel) {   // round 6: the 3 x 2-tile / K-split kernel is the default; CCHESS_MX_KERNEL=1 keeps round 5's for A/B runs
+#ifdef CZ_EXPERIMENT_MX2
+    if (!c->mx_kernel) {   // experiment builds only: CCHESS_MX_KERNEL=2 selects k_trunk_mx2_c128
         const char *e = getenv("CCHESS_MX_KERNEL");
-        c->mx_kernel = (e && e[0] == '1') ? 1 : 2;
+        c->mx_kernel = (e && e[0] == '2') ? 2 : 1;
     }
     if (c->mx_kernel == 2) {
         if (!c->mx2_attr_set) {
@@ -144,6 +147,7 @@ extern "C" int cz_net_trunk_mx(cz_ctx *c, const void *planes16, const void *w0, 
         CZ_HIP(hipGetLastError());
         return CZ_OK;
     }
+#endif
     if (!c->mx_attr_set) {
         CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trunk_mx_c128), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
         c->mx_attr_set = true;

@@ -68,7 +68,7 @@ def test_bench_two_ranks_search_loop_default_engine():
     assert len(d["steady_state"]["per_rank_sims_per_s"]) == 2 and len(d["fast_engine"]["per_rank_sims_per_s"]) == 2
     assert d["contract_steps"]["steps"] == 24 and d["config"]["record_gather"] is True
     assert d["config"]["trees_with_error_status"] == 0
-    assert d["dtype"] == "mx6" and d["roofline"]["kernel"] == "k_trunk_mx2_c128" and d["engine"].startswith("k_trunk_mx2_c128")
+    assert d["dtype"] == "mx6" and d["roofline"]["kernel"] == "k_trunk_mx_c128" and d["engine"].startswith("k_trunk_mx_c128")
     assert d["strict_check"]["engine"] == "mx6" and d["strict_check"]["positions"] >= 64 and not d["strict_check"]["fell_over_from"]
     assert max(d["strict_check"]["dlogit"], d["strict_check"]["dvalue"]) <= 5e-4
     ne = d["net_error"]
@@ -82,7 +82,7 @@ def test_bench_two_ranks_search_loop_default_engine():
     # the fast engine by explicit choice: the strict engine is then the extra leg (round 5's layout)
     d = _bench(["--dtype", "fp16", "--games", "512", "--playout", "64", "--steps", "24", "--warmup", "4", "--age-steps", "48", "--steady-steps", "0",
                 "--strict-steps", "16", "--no-cpu-baseline"])
-    assert d["dtype"] == "fp16" and d["fast_engine"] is None and d["strict_engine"]["kernel"] == "k_trunk_mx2_c128"
+    assert d["dtype"] == "fp16" and d["fast_engine"] is None and d["strict_engine"]["kernel"] == "k_trunk_mx_c128"
     assert d["strict_engine"]["meets_1e-3_abs_logit_and_value"] is True and d["strict_check"] is None
 
 

@@ -33,6 +33,22 @@ namespace czconv {
 
 constexpr int MX2_XBUF_FLOATS_PER_WG = 8 * 48 * 64;   // 8 waves x 3 tiles x 16 registers x 64 lanes (98,304 B)
 
+// A thread's place in the workgroup, RECOMPUTED from an opaque copy of threadIdx.x wherever the code outside the slab loops needs
+// it: the loops run on every register a wave of two per SIMD has, so whatever is merely live ACROSS them is parked in scratch
+// and comes back as one dependent global-memory round trip per use — the first version of this kernel spent as long at the ends
+// of a layer (60 serialised scratch reloads) as in its slab loops.
+struct Mx2Th {
+    int tid, lane, wave, wr, cg, kp, ct, l31, khalf;
+    __device__ __forceinline__ static Mx2Th here() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        Mx2Th g;
+        g.tid = t; g.lane = t & 63; g.wave = t >> 6; g.wr = g.wave >> 2; g.cg = (g.wave >> 1) & 1; g.kp = g.wave & 1;
+        g.ct = 2 * g.cg + g.kp; g.l31 = g.lane & 31; g.khalf = g.lane >> 5;
+        return g;
+    }
+};
+
 // planes / w0 / wpk / bias / b0 / out / head_out: as k_trunk_mx_c128; xbuf: [gridDim.x][MX2_XBUF_FLOATS_PER_WG] fp32 scratch.
 __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *__restrict__ wpk,
                                                             const float *__restrict__ bias,
@@ -93,13 +109,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
     }
     // zero row of the hi halves; zero aliases 192 .. 223 of the X / Y planes; scale 127 (= 2^0) in the aliases of SC (again after
     // every exchange, which borrows the planes)
-    auto init_aliases = [&]() {
+    auto init_aliases = [&](int tid) {
         if (tid < 256) *reinterpret_cast<uint4 *>(smem + Geo::X_OFF + (tid >> 5) * Geo::XPLANE + (192 + (tid & 31)) * 16) = make_uint4(0, 0, 0, 0);
         else *reinterpret_cast<uint2 *>(smem + Geo::Y_OFF + ((tid - 256) >> 5) * Geo::YPLANE + (192 + (tid & 31)) * 8) = make_uint2(0, 0);
         if (tid < 64) *reinterpret_cast<uint32_t *>(smem + Geo::S_OFF + (tid >> 5) * Geo::SPLANE + (192 + (tid & 31)) * 4) = 0x7f7f7f7fu;
     };
     if (tid < 16) *reinterpret_cast<uint4 *>(smem + Geo::ZERO_OFF + (tid << 4)) = make_uint4(0, 0, 0, 0);
-    init_aliases();
+    init_aliases(tid);
     if (head_out && tid < 3 * 128 / 4)
         reinterpret_cast<float4 *>(smem + Geo::HEADW_OFF)[tid] = reinterpret_cast<const float4 *>(head_w)[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
         }
         tapmask[i] = m;
     }
-    auto tap_addr = [&](int tap, int (&ab)[3], int (&key)[3], int (&xr)[3], int (&yr)[3]) {   // as k_trunk_mx_c128
+    auto tap_addr = [&](int khalf, int tap, int (&ab)[3], int (&key)[3], int (&xr)[3], int (&yr)[3]) {   // as k_trunk_mx_c128
         const int delta = (tap / 3 - 1) * 20 + (tap - (tap / 3) * 3 - 1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -150,7 +166,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
     // epilogue of one tile (k_trunk_mx_c128's): ReLU + clamp, hi = rn16(v) to the HI row, the fp6 block [hi | 2^11 (v - hi)] under the
     // scale 2^(exponent(max v) - 2) to the X / Y planes of group 2 ct + khalf, the scale byte to SC; keep_x: v is a block input and
     // goes to the workgroup's scratch
-    auto store_tile = [&](f32x16 a, int i, bool keep_x) {
+    auto store_tile = [&](const Mx2Th &th, float *xw, f32x16 a, int i, bool keep_x) {
+        const int ct = th.ct, khalf = th.khalf;
         f32x16 v;
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_fmed3f(a[r], 0.0f, 65504.0f);
@@ -189,7 +206,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
         }
     };
     // the last layer: fp32 rows for the heads / the trunk dump, 16-byte chunk c of a row at c ^ (row & 31)
-    auto store_tile_f32 = [&](f32x16 a, int i) {
+    auto store_tile_f32 = [&](const Mx2Th &th, f32x16 a, int i) {
+        const int ct = th.ct, khalf = th.khalf;
         if (rowk[i] < 0) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -198,10 +216,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
                 make_float4(fmaxf(a[4 * q + 0], 0.0f), fmaxf(a[4 * q + 1], 0.0f), fmaxf(a[4 * q + 2], 0.0f), fmaxf(a[4 * q + 3], 0.0f));
         }
     };
-    auto bias_acc = [&](f32x16 (&dst)[3], const float *bl) {   // accumulator registers 4 q + r = channel 32 ct + 8 q + 4 khalf + r
+    auto bias_acc = [&](const Mx2Th &th, f32x16 (&dst)[3], const float *bl) {   // accumulator registers 4 q + r = channel 32 ct + 8 q + 4 khalf + r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 bq = *reinterpret_cast<const float4 *>(bl + ct * 32 + 8 * q + 4 * khalf);
+            const float4 bq = *reinterpret_cast<const float4 *>(bl + th.ct * 32 + 8 * q + 4 * th.khalf);
 #pragma unroll
             for (int i = 0; i < 3; ++i) { dst[i][4 * q + 0] = bq.x; dst[i][4 * q + 1] = bq.y; dst[i][4 * q + 2] = bq.z; dst[i][4 * q + 3] = bq.w; }
         }
@@ -210,7 +228,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
     {   // first layer: conv3x3(14 -> 128) + BN + ReLU of the wave's three FINAL tiles (no K split: 18 k-steps of 16 padded channels);
         // the planes are exact in 16 bits, the weights are hi + lo (two fp16 MFMAs)
         f32x16 acc[3];
-        bias_acc(acc, b0);
+        const Mx2Th th = Mx2Th::here();
+        bias_acc(th, acc, b0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
@@ -231,16 +250,21 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
         }
         refresh_rk();
 #pragma unroll
-        for (int i = 0; i < 3; ++i) store_tile(acc[i], i, true);
+        for (int i = 0; i < 3; ++i) store_tile(th, xw, acc[i], i, true);
         __syncthreads();
-        dma_slab(3);   // the planes are done with ring buffer 3: the second slab of pair 1 (landed by body 0's vmcnt(0), published by its barrier)
+        dma_slab(3);   // the planes are done with ring buffer 3: the second slab of pair 1 (published by body 0's barrier; a layer's
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first body does not wait for vector memory, so it has to have landed here)
     }
 
 #define MX2_OPERANDS()                                                                                               \
-            : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),              \
-              [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),                                                           \
-              [a0h0] "+v"(fa.a[0]), [a0h1] "+v"(fa.a[1]), [a0h2] "+v"(fa.a[2]), [w00] "+v"(fa.w[0]), [w01] "+v"(fa.w[1]), \
-              [a1h0] "+v"(fb.a[0]), [a1h1] "+v"(fb.a[1]), [a1h2] "+v"(fb.a[2]), [w10] "+v"(fb.w[0]), [w11] "+v"(fb.w[1]), \
+            /* accumulators and operand sets in FIXED registers: with six 16-register tuples tied through six asm statements */ \
+            /* and two loops the allocator otherwise re-homes them between statements (copies, 200+ bytes of scratch) */         \
+            : [c00] "+{v[0:15]}"(acc[0][0]), [c01] "+{v[16:31]}"(acc[0][1]), [c10] "+{v[32:47]}"(acc[1][0]),                   \
+              [c11] "+{v[48:63]}"(acc[1][1]), [c20] "+{v[64:79]}"(acc[2][0]), [c21] "+{v[80:95]}"(acc[2][1]),                  \
+              [a0h0] "+{v[96:99]}"(fa.a[0]), [a0h1] "+{v[100:103]}"(fa.a[1]), [a0h2] "+{v[104:107]}"(fa.a[2]),                 \
+              [w00] "+{v[108:111]}"(fa.w[0]), [w01] "+{v[112:115]}"(fa.w[1]),                                                  \
+              [a1h0] "+{v[116:119]}"(fb.a[0]), [a1h1] "+{v[120:123]}"(fb.a[1]), [a1h2] "+{v[124:127]}"(fb.a[2]),               \
+              [w10] "+{v[128:131]}"(fb.w[0]), [w11] "+{v[132:135]}"(fb.w[1]),                                                  \
               [sb0] "+v"(sb[0]), [sb1] "+v"(sb[1]), [sb2] "+v"(sb[2]),                                                \
               [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [ws0] "=&v"(ws0), [ws1] "=&v"(ws1), [keep] "=&s"(keep)
 #define MX2_INPUTS(NAB, NKEY)                                                                                        \
@@ -281,27 +305,33 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
     asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cselect_b32 %0, 1, 0" : "=s"(skipm) : "s"(wave_u) : "scc");
     // the tower, instantiated for both values of kp (a wave-uniform branch around the whole loop: nothing is live where the paths
     // join): channel tile j of the wave is 2 cg + j, the one it finalises j = KP
+#ifdef MX2_TIMING   /* diagnostic build (tools/mx_timing.py): where a workgroup's cycles go; the clock-probe buffer carries the sums */
+    unsigned long long tm_loop = 0, tm_xch = 0, tm_epi = 0, tm_t0 = 0, tm_x1 = 0, tm_x2 = 0, tm_x3 = 0, tm_x4 = 0;
+#define MX2_TM(acc) { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - tm_t0; tm_t0 = n_; }
+#else
+#define MX2_TM(acc)
+#endif
     auto tower = [&](auto kpc) {
     constexpr int KP = decltype(kpc)::value;
     constexpr int kp8 = KP * 8;
     int g = 0;     // pair (= body) counter over the whole tower
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
-        f32x16 acc[3][2];
-        {
-            f32x16 b3[3];
-            bias_acc(b3, bias + layer * 128);
+        f32x16 acc[3][2];   // both start at zero: the layer's bias joins in the epilogue, with the partner's partial sums
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                acc[i][KP] = b3[i];
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][1 - KP][r] = 0.0f;
-            }
-        }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
         int ab[3], key[3], nab[3], nkey[3], xr[3], yr[3], nxr[3], nyr[3], t0, t1, t2, t3, ws0, ws1;
+        // per layer: what the addresses are made of is made opaque, or the compiler computes the (layer-invariant) addresses of
+        // every tap once, before the layer loop, and parks them in scratch
+        asm volatile("" : "+v"(rowk[0]), "+v"(rowk[1]), "+v"(rowk[2]), "+v"(tapmask[0]), "+v"(tapmask[1]), "+v"(tapmask[2]));
+        const int kh0 = Mx2Th::here().khalf;
         int sb[3] = {0, 0, 0};
         Mx2Frag fa, fb;
-        tap_addr(0, ab, key, xr, yr);
+        tap_addr(kh0, 0, ab, key, xr, yr);
         {   // the first body's two fp16 operand sets (quarter kp of tap 0)
             const int vb = vb0 + (((unsigned)(2 * g + KP) & 3u) << Geo::SLAB_SHIFT);
 #pragma unroll
@@ -317,48 +347,66 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
             asm volatile("" : "+v"(fa.a[0]), "+v"(fa.a[1]), "+v"(fa.a[2]), "+v"(fa.w[0]), "+v"(fa.w[1]),
                               "+v"(fb.a[0]), "+v"(fb.a[1]), "+v"(fb.a[2]), "+v"(fb.w[0]), "+v"(fb.w[1]));
         }
-        int tap = 0;
+        MX2_TM(tm_epi)
+        // tap 0, peeled: the layer's first body does not wait for vector memory (see slabMX2)
+        MX2_RUNV(MX2_SKIP0_A_FIRST, KP, KP + 2, ab, key)
+        tap_addr(kh0, 1, nab, nkey, nxr, nyr);
+        MX2_RUNV(MX2_SKIP0_B, KP + 2, KP, nab, nkey)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; xr[i] = nxr[i]; yr[i] = nyr[i]; }
+        int tap = 1;
 #pragma unroll 1
         for (; tap < 3; ++tap) {   // dy = -1: cell group 0 branches around the MFMAs of its all-rank-0 row tile
             MX2_RUNV(MX2_SKIP0_A, KP, KP + 2, ab, key)
-            tap_addr(tap + 1, nab, nkey, nxr, nyr);
+            tap_addr(kh0, tap + 1, nab, nkey, nxr, nyr);
             MX2_RUNV(MX2_SKIP0_B, KP + 2, KP, nab, nkey)
 #pragma unroll
             for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; xr[i] = nxr[i]; yr[i] = nyr[i]; }
         }
 #pragma unroll 1
-        for (; tap < 9; ++tap) {
+        for (; tap < 8; ++tap) {
             MX2_RUN(MX2_BODY_A, KP, KP + 2, ab, key)
-            tap_addr(tap + 1, nab, nkey, nxr, nyr);
+            tap_addr(kh0, tap + 1, nab, nkey, nxr, nyr);
             MX2_RUN(MX2_BODY_B, KP + 2, KP, nab, nkey)
 #pragma unroll
             for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; xr[i] = nxr[i]; yr[i] = nyr[i]; }
         }
-        // the last body requested operands of a body that does not exist: drain them, let the MFMAs retire, the DMAs land (the
-        // last layer's fp32 rows reach into the weight ring)
+        // tap 8: the layer's last body requests nothing
+        MX2_RUN(MX2_BODY_A, KP, KP + 2, ab, key)
+        MX2_RUN(MX2_BODY_B_LAST, KP + 2, KP, ab, key)
+        // let the MFMAs retire (the compiler does not see them), the DMAs land (the last layer's fp32 rows reach into the weight
+        // ring).  Behind the last body's barrier (which waited for every LDS read of its wave) nobody reads the activation planes any
+        // more: they are the exchange area from here on, without another barrier
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        MX2_TM(tm_loop)
         const bool last = layer + 1 == nlayers;
         const bool add_x = (layer & 1) != 0;
+        const Mx2Th th = Mx2Th::here();      // everything from here to the end of the layer is addressed from this copy
+        float *xw = xbuf + (size_t)blockIdx.x * MX2_XBUF_FLOATS_PER_WG + (size_t)th.wave * (48 * 64) + th.lane * 4;
+        float4 bq[4];                        // the layer's bias at this lane's accumulator positions (channel 32 ct + 8 q + 4 khalf + r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4 *>(bias + layer * 128 + th.ct * 32 + 8 * q + 4 * th.khalf);
+        auto load_x = [&](f32x16 &dst, int i) {   // the block input, written two layers ago: in flight during the exchange
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4 *>(xw + (4 * i + q) * 256);
+                dst[4 * q] = t.x; dst[4 * q + 1] = t.y; dst[4 * q + 2] = t.z; dst[4 * q + 3] = t.w;
+            }
+        };
+        // exchange: the partial sums of the tile the partner finalises (j = 1 - KP) go to it (wave ^ 1), its partial sums of MY tile
+        // come back.  4 KB per wave and cell tile: tiles 0, 1 at once (64 KB), then tile 2
+        unsigned char *exw = smem + th.wave * 4096 + th.lane * 16, *exr = smem + (th.wave ^ 1) * 4096 + th.lane * 16;
         f32x16 xin[3];
-        if (add_x) {   // the block input, written two layers ago: in flight during the exchange
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 t = *reinterpret_cast<const float4 *>(xw + (4 * i + q) * 256);
-                    xin[i][4 * q] = t.x; xin[i][4 * q + 1] = t.y; xin[i][4 * q + 2] = t.z; xin[i][4 * q + 3] = t.w;
-                }
-        }
-        __syncthreads();   // every wave is done reading the activations: the planes become the exchange area
-        // exchange: the partial sums of tile j = 1 go to the partner (wave ^ 1, which finalises that channel tile), its partial
-        // sums of MY tile come back.  4 KB per wave and cell tile: tiles 0, 1 at once (64 KB), then tile 2
-        unsigned char *exw = smem + wave * 4096 + lane * 16, *exr = smem + (wave ^ 1) * 4096 + lane * 16;
+#ifndef MX2_ABLATE_NO_EXCHANGE   /* timing ablation (tools/experiments/mx_ablate.sh; wrong results) */
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<float4 *>(exw + i * 32768 + q * 1024) = make_float4(acc[i][1 - KP][4 * q], acc[i][1 - KP][4 * q + 1], acc[i][1 - KP][4 * q + 2], acc[i][1 - KP][4 * q + 3]);
+        if (add_x) { load_x(xin[0], 0); load_x(xin[1], 1); }    // into the registers the two tiles just left
+        MX2_TM(tm_x1)
         __syncthreads();
+        MX2_TM(tm_x2)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -370,12 +418,29 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4 *>(exw + q * 1024) = make_float4(acc[2][1 - KP][4 * q], acc[2][1 - KP][4 * q + 1], acc[2][1 - KP][4 * q + 2], acc[2][1 - KP][4 * q + 3]);
+        MX2_TM(tm_x3)
+        if (add_x) load_x(xin[2], 2);
         __syncthreads();
+        MX2_TM(tm_x4)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 t = *reinterpret_cast<const float4 *>(exr + q * 1024);
             acc[2][KP][4 * q] += t.x; acc[2][KP][4 * q + 1] += t.y; acc[2][KP][4 * q + 2] += t.z; acc[2][KP][4 * q + 3] += t.w;
         }
+#else
+        (void)exw; (void)exr;
+        if (add_x) { load_x(xin[0], 0); load_x(xin[1], 1); load_x(xin[2], 2); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][KP][r] += acc[i][1 - KP][r];
+#endif
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[i][KP][4 * q] += bq[q].x; acc[i][KP][4 * q + 1] += bq[q].y; acc[i][KP][4 * q + 2] += bq[q].z; acc[i][KP][4 * q + 3] += bq[q].w;
+            }
         if (add_x) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -383,23 +448,33 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx2_c128(const unsigned char *
                 for (int r = 0; r < 16; ++r) acc[i][KP][r] += xin[i][r];
         }
         __syncthreads();
+        MX2_TM(tm_xch)
         refresh_rk();
         if (last) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) store_tile_f32(acc[i][KP], i);
+            for (int i = 0; i < 3; ++i) store_tile_f32(th, acc[i][KP], i);
         } else {
-            init_aliases();
+            init_aliases(th.tid);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) store_tile(acc[i][KP], i, add_x);
+            for (int i = 0; i < 3; ++i) store_tile(th, xw, acc[i][KP], i, add_x);
         }
         __syncthreads();
     }
     };   // tower
+#ifdef MX2_TIMING
+    tm_t0 = __builtin_readcyclecounter();
+    const unsigned long long tm_first = tm_t0 - clk_c0;
+#endif
     if (kp_u) tower(std::integral_constant<int, 1>{});
     else tower(std::integral_constant<int, 0>{});
     if (clk && tid == 0) {
         clk[blockIdx.x * 4 + 0] = clk_c0; clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
         clk[blockIdx.x * 4 + 2] = clk_r0; clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#ifdef MX2_TIMING
+        clk[blockIdx.x * 4 + 0] = tm_first; clk[blockIdx.x * 4 + 1] = tm_loop; clk[blockIdx.x * 4 + 2] = tm_xch; clk[blockIdx.x * 4 + 3] = tm_epi;
+        unsigned long long *c2 = clk + (size_t)(gridDim.x + blockIdx.x) * 4;     // tools/mx_timing.py arms a buffer of twice the grid
+        c2[0] = tm_x1; c2[1] = tm_x2; c2[2] = tm_x3; c2[3] = tm_x4;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (out) {   // trunk activations as fp32, 4 channels per thread and step

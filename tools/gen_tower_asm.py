@@ -219,7 +219,7 @@ MX2_AX = ["v[226:231]", "v[232:237]", "v[238:243]"]   # fp6 activation blocks of
 MX2_WX = ["v[244:249]", "v[250:255]"]                 # fp6 weight blocks of the two channel tiles (the body clobbers v226..v255)
 
 
-def slabMX2(first):
+def slabMX2(first, layer_first=False, layer_last=False):
     """One body = one 16 KB slab (32 input channels of one tap) for a 3 cell x 2 channel tile: 12 fp16 MFMAs + 6 fp6 MFMAs.
     A wave sees two bodies per tap: `first` (quarter kp; the next body is quarter kp + 2 of the SAME tap: ab / key) and second
     (quarter kp + 2; the next body is quarter kp of the NEXT tap: nab / nkey) — the C++ side passes the right address operands
@@ -231,57 +231,70 @@ def slabMX2(first):
       B (k-step 1, set a1h* / w1*)  every read of this wave has returned (lgkmcnt 0: the pair the DMAs below overwrite is no
                                     longer being read by anyone behind the barrier), its 4 DMA pieces have landed (vmcnt 0), barrier:
                                     the next pair is published; requests the next body's set A; 2 DMA pieces of the pair after next
-      C (fp6, hard registers)       requests the next body's set B; the other 2 DMA pieces."""
+      C (fp6, hard registers)       requests the next body's set B; the other 2 DMA pieces.
+    layer_first: the first body of a layer — its DMAs were waited for when the previous layer drained, and the only vector-memory
+    operations in flight are the epilogue's block-input stores, which the barrier need not wait for (no vmcnt wait).
+    layer_last: the last body of a layer requests no operands (there is no next body: the activations are about to be replaced),
+    so behind its barrier no wave reads the activation planes any more and the exchange may start without another barrier."""
     f = lambda i, j, s: "v_mfma_f32_32x32x16_f16 %%[c%d%d], %%[w%d%d], %%[a%dh%d], %%[c%d%d]" % (i, j, s, j, s, i, i, j)
     mx = lambda i, j: ("v_mfma_scale_f32_32x32x64_f8f6f4 %%[c%d%d], %s, %s, %%[c%d%d], %%[ws%d], %%[sb%d] op_sel:[0,0,0] op_sel_hi:[0,%d,0] cbsz:2 blgp:2"
                        % (i, j, MX2_WX[j], MX2_AX[i], i, j, j, i, 0 if first else 1))
     sub = lambda r, lo, hi: "v[%d:%d]" % (int(r[2:].split(":")[0]) + lo, int(r[2:].split(":")[0]) + hi)
     L = ["s_mov_b32 %[keep], m0"]
-    # ---- step A
+    # ---- step A: the reads of THIS pair's buffers (the fp6 weight blocks and their scales) go out first, so that the counted
+    # wait in front of the barrier covers them while the activation blocks may still be in flight
     L += ["s_waitcnt lgkmcnt(5)"]
+    wreads = [["ds_read_b128 %s, %%[vb] offset:%d" % (sub(MX2_WX[j], 0, 3), 8192 + 512 * j), "ds_read_b64 %s, %%[vy] offset:%d" % (sub(MX2_WX[j], 4, 5), 256 * j),
+               "ds_read_b32 %%[ws%d], %%[vs] offset:%d" % (j, 128 * j)] for j in range(2)]
+    areads = [["v_add_u32 %%[t0], %%[xo], %%[xr%d]" % i, "v_add_u32 %%[t1], %%[yo], %%[yr%d]" % i,
+               "ds_read_b128 %s, %%[t0]" % sub(MX2_AX[i], 0, 3), "ds_read_b64 %s, %%[t1]" % sub(MX2_AX[i], 4, 5)] for i in range(3)]
+    sreads = (["v_lshrrev_b32 %%[t%d], 1, %%[yr%d]" % (k, k) for k in range(3)] +
+              ["ds_read_b32 %%[sb%d], %%[t%d] offset:%d" % (k, k, MX_S_OFF) for k in range(3)]) if first else []
+    fill = [wreads[0], wreads[1], areads[0], areads[1], areads[2], sreads]
+    k = 0
     for i in range(3):
-        L += [f(i, 0, 0)]
-        L += ["v_add_u32 %%[t0], %%[xo], %%[xr%d]" % i, "v_add_u32 %%[t1], %%[yo], %%[yr%d]" % i,
-              "ds_read_b128 %s, %%[t0]" % sub(MX2_AX[i], 0, 3), "ds_read_b64 %s, %%[t1]" % sub(MX2_AX[i], 4, 5)]
-        L += [f(i, 1, 0)]
-        if i < 2:
-            j = i
-            L += ["ds_read_b128 %s, %%[vb] offset:%d" % (sub(MX2_WX[j], 0, 3), 8192 + 512 * j), "ds_read_b64 %s, %%[vy] offset:%d" % (sub(MX2_WX[j], 4, 5), 256 * j),
-                  "ds_read_b32 %%[ws%d], %%[vs] offset:%d" % (j, 128 * j)]
-        elif first:   # the tap's activation scales: one dword per cell = the four 32-channel quarters' E8M0 bytes of this lane's half
-            L += ["v_lshrrev_b32 %%[t%d], 1, %%[yr%d]" % (k, k) for k in range(3)]
-            L += ["ds_read_b32 %%[sb%d], %%[t%d] offset:%d" % (k, k, MX_S_OFF) for k in range(3)]
+        for j in range(2):
+            L += [f(i, j, 0)] + fill[k]
+            k += 1
+    behind_w = 6 + (3 if first else 0)      # reads issued behind the last read of the weight ring
     # ---- step B
-    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
-    # piece k of the wave: 1 KB at byte 8192 k + 16 tid of the 32 KB pair, to the same offset of the pair's two ring buffers
+    L += ["s_waitcnt lgkmcnt(%d)" % behind_w if layer_first else "s_waitcnt vmcnt(0) lgkmcnt(%d)" % (0 if layer_last else behind_w), "s_barrier"]
+    # piece k of the wave: 1 KB at byte 8192 k + 16 tid of the 32 KB pair, to the same offset of the pair's two ring buffers; all four
+    # right behind the barrier: they have the whole body to land (the next barrier waits for them)
     dma = [["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]]
     dma += [["s_add_u32 m0, %%[ldst], 0x%x" % (0x2000 * k), "v_add_u32 %%[t3], 0x%x, %%[voff0]" % (0x2000 * k),
              "global_load_lds_dwordx4 %[t3], %[sbase]"] for k in (1, 2, 3)]
+    place = os.environ.get("MX2_DMA_PLACE", "B")
 
-    def half(s, cb, woff, d0, d1, pre=None):
-        """6 MFMAs of operand set s (fp16 k-step 1, or the fp6 step when s is None) with the requests of the next body's set
-        1 - s... interleaved: address VALU, 5 reads, two DMA pieces"""
+    def half(s, cb, woff, d, pre=None):
+        """6 MFMAs of operand set s (fp16 k-step 1, or the fp6 step when s is None) with the requests of the next body's other
+        set interleaved: address VALU, 5 reads; d: DMA pieces behind MFMAs 0..3"""
         X = 0 if s == 1 else 1          # the set being requested
         m = (lambda i, j: f(i, j, 1)) if s == 1 else (lambda i, j: mx(i, j))
         o = list(pre or [])
-        o += [m(0, 0)]
-        o += ["v_xor_b32 %%[t%d], %%[%s], %%[nkey%d]" % (k, cb, k) for k in range(3)]
-        o += [m(0, 1)]
-        o += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[nab%d]" % (k, k, k) for k in range(3)]
-        o += d0
-        o += [m(1, 0)]
-        o += ["ds_read_b128 %%[a%dh0], %%[t0]" % X, "ds_read_b128 %%[a%dh1], %%[t1]" % X]
-        o += [m(1, 1)]
-        o += ["ds_read_b128 %%[a%dh2], %%[t2]" % X, "ds_read_b128 %%[w%d0], %%[vbn] offset:%d" % (X, woff)]
-        o += d1
+        rq = not layer_last
+        o += [m(0, 0)] + d[0]
+        o += ["v_xor_b32 %%[t%d], %%[%s], %%[nkey%d]" % (k, cb, k) for k in range(3)] if rq else []
+        o += [m(0, 1)] + d[1]
+        o += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[nab%d]" % (k, k, k) for k in range(3)] if rq else []
+        o += [m(1, 0)] + d[2]
+        o += ["ds_read_b128 %%[a%dh0], %%[t0]" % X, "ds_read_b128 %%[a%dh1], %%[t1]" % X] if rq else []
+        o += [m(1, 1)] + d[3]
+        o += ["ds_read_b128 %%[a%dh2], %%[t2]" % X, "ds_read_b128 %%[w%d0], %%[vbn] offset:%d" % (X, woff)] if rq else []
         o += [m(2, 0)]
-        o += ["ds_read_b128 %%[w%d1], %%[vbn] offset:%d" % (X, woff + 512)]
+        o += ["ds_read_b128 %%[w%d1], %%[vbn] offset:%d" % (X, woff + 512)] if rq else []
         o += [m(2, 1)]
         return o
-    L += half(1, "cba", 0, dma[0], dma[1])
+    none = [[], [], [], []]
+    if place == "B":        # one piece behind each of step B's first four MFMAs
+        L += half(1, "cba", 0, dma)
+        dC = none
+    else:                   # "BC": two in step B, two in step C (the first version: 36 % slower than k_trunk_mx_c128)
+        L += half(1, "cba", 0, [dma[0], [], dma[1], []])
+        dC = [dma[2], [], dma[3], []]
     # ---- step C
-    pre = ["v_lshrrev_b32 %%[sb%d], %%[kp8], %%[sb%d]" % (k, k) for k in range(3)] if first else []
-    L += half(None, "cbb", 4096, dma[2], dma[3], pre)
+    pre = ["s_waitcnt lgkmcnt(%d)" % (0 if layer_last else 5)] + (["v_lshrrev_b32 %%[sb%d], %%[kp8], %%[sb%d]" % (k, k) for k in range(3)] if first else [])
+    L += half(None, "cbb", 4096, dC, pre)
     L += ["s_mov_b32 m0, %[keep]"]
     ab = [a for a in os.environ.get("MX_ABLATE", "").split(",") if a]
     if "nodma" in ab:
@@ -361,7 +374,12 @@ def main():
     for name, first in (("A", True), ("B", False)):
         txt += emit("MX2_BODY_%s" % name, slabMX2(first)) + "\n"
         txt += emit("MX2_SKIP0_%s" % name, branchy(slabMX2(first), ("%[c00],", "%[c01],"))) + "\n"
-    open(os.path.join(csrc, "cz_trunk_mx2_asm.inc"), "w").write(txt)
+    txt += "// the first body of a layer (tap 0: with the skip; no vmcnt wait) and the last (no operand requests)\n"
+    txt += emit("MX2_SKIP0_A_FIRST", branchy(slabMX2(True, layer_first=True), ("%[c00],", "%[c01],"))) + "\n"
+    txt += emit("MX2_BODY_B_LAST", slabMX2(False, layer_last=True)) + "\n"
+    # an experiment (tools/experiments/cz_trunk_mx2.h; built by tools/experiments/mx_ablate.sh with -DCZ_EXPERIMENT_MX2): written next
+    # to that header unless an output directory was given (then into it, as for the ablation builds)
+    open(os.path.join(csrc if len(sys.argv) > 1 else os.path.join(here, "experiments"), "cz_trunk_mx2_asm.inc"), "w").write(txt)
     print("wrote cz_tower_slab_asm.inc (%d instructions per slab), cz_trunk_split_asm.inc (%d), cz_trunk_mx_asm.inc (%d), cz_trunk_mx2_asm.inc (%d per body)" %
           (len(slab8(0)), len(slabX(0, XS_LO_OFF)), len(slabMX(1)), len(slabMX2(False))))
 
