@@ -36,6 +36,10 @@ def timed(fn, iters=5):
 
 t = timed(lambda: rules.movegen(boards, side, want_mask=True))
 print("K1 movegen (list + mask): %.3f ms for %d positions = %.2f G positions/s, %.1f GB/s of ABI traffic (613 B/position)" % (t * 1e3, N, N / t / 1e9, N * 613 / t / 1e9))
+t = timed(lambda: rules.movegen(boards, side, want_mask=True, pad=False))
+print("K1 movegen (list + mask, CZ_MOVES_NO_PAD): %.3f ms = %.2f G positions/s, %.1f GB/s algorithmic (312 B/position)" % (t * 1e3, N / t / 1e9, N * 312 / t / 1e9))
+t = timed(lambda: rules.movegen(boards, side, want_mask=False, pad=False))
+print("K1 movegen (list only, CZ_MOVES_NO_PAD)  : %.3f ms = %.2f G positions/s" % (t * 1e3, N / t / 1e9))
 t = timed(lambda: rules.movegen(boards, side, want_mask=True, want_moves=False))
 print("K1 movegen (mask only)  : %.3f ms = %.2f G positions/s, %.1f GB/s of ABI traffic (357 B/position), %.1f GB/s algorithmic (312 B)" % (t * 1e3, N / t / 1e9, N * 357 / t / 1e9, N * 312 / t / 1e9))
 t = timed(lambda: rules.movegen(boards, side, want_mask=False))
