@@ -251,3 +251,37 @@ def test_hip_search_width_k_exact_playouts_equals_oracle(rules_golden, K, playou
     assert np.array_equal(hs["N"], os_["N"]) and np.array_equal(hs["Q"].view(np.uint32), os_["Q"].view(np.uint32))
     for t in range(0, G, 5):
         assert np.array_equal(hip.tree_dump(t), orc.tree_dump(t))
+
+
+@pytest.mark.gpu
+def test_graph_captured_lock_step_equals_eager_search():
+    """SearchEngine.search(graph=True) (round 6: the --mode play shape, one tree x 16 simulations in flight, is host-bound without
+    it): the lock-step replayed as a captured HIP graph builds the trees the eager loop builds — bit for bit, over two consecutive
+    searches with a re-root in between (the second search replays the first one's capture: same budget), and through the
+    facade's MCTS_tree.main with search_threads = 16, which uses it."""
+    import torch
+    from cchess_zero_amd.engine import SearchEngine
+    from cchess_zero_amd.net import PolicyValueNet
+    net = PolicyValueNet(2, "cuda:0", torch.float16, seed=5, split="strict")
+    b0 = O.fen_to_board(O.START_FEN)
+    G, K, playouts = 3, 16, 96
+    boards, side = np.tile(b0, (G, 1)), np.zeros(G, np.uint8)
+    engs = [SearchEngine(G, 20000, plane_dtype=torch.float32, channels=14, width=K) for _ in range(2)]
+    for ply in range(2):
+        stats = []
+        for e, graph in zip(engs, (False, True)):
+            if ply == 0:
+                e.reset(boards, side, None)
+            e.search(net.forward_device, playouts, graph=graph)
+            stats.append(e.root_stats_host())
+        a, b = stats
+        assert (a["N"].sum(axis=1) == playouts).all() and np.array_equal(a["N"], b["N"]) and np.array_equal(a["label"], b["label"])
+        assert np.array_equal(a["W"].view(np.uint32), b["W"].view(np.uint32)) and np.array_equal(a["Q"].view(np.uint32), b["Q"].view(np.uint32))
+        for g in range(G):
+            assert np.array_equal(engs[0].tree_dump(g), engs[1].tree_dump(g))
+        n = a["N"].astype(np.int64).copy()
+        n[np.arange(128)[None, :] >= a["count"].astype(np.int64)[:, None]] = -1
+        played = a["label"][np.arange(G), n.argmax(axis=1)].astype(np.uint16)
+        for e in engs:
+            e.advance(played)
+    assert getattr(engs[1], "_graph_key", None) is not None and getattr(engs[0], "_graph_key", None) is None
