@@ -38,7 +38,6 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-from cchess_zero_amd.net import MX_DEPTH_LIMIT   # precision "strict": mx6 up to this depth (before the self-check), fp16x2 beyond
 from cchess_zero_amd.rules import START_BOARD
 
 START = START_BOARD
@@ -324,7 +323,7 @@ def main():
     ap.add_argument("--playout", type=int, default=1600)
     ap.add_argument("--blocks", type=int, default=7)
     ap.add_argument("--dtype", default="strict", choices=["bf16", "fp16", "fp32", "fp16x2", "bf16x2", "mx6", "strict"],
-                    help="engine of the tower (fp32 accumulate).  strict (default since round 6: the engine policy_value_network() and main.py run, so `value` and `roofline` are the product's): the net measures itself against fp32 on its weights and runs the cheapest engine of mx6 -> fp16x2 -> fp32 inside 5e-4 (mx6 up to 8 blocks on the bench's weights, fp16x2 beyond); the fast fp16 engine is then timed as the fast_engine leg.  mx6 = fp16 hi halves + both cross terms of the hi + lo split on one block-scaled fp6 MFMA (k_trunk_mx_c128, 1.5 MFMA-equivalents per product); fp16x2 / bf16x2 = hi + lo halves of that type, three MFMAs per product (k_trunk_split_c128; also 19 blocks); fp16: one fp16 per operand (k_tower8_c128), twice the rate, 1e-3 only relative to the logit scale (see net_error in the output); with fp16 / bf16 the strict engine is the extra leg")
+                    help="engine of the tower (fp32 accumulate).  strict (default since round 6: the engine policy_value_network() and main.py run, so `value` and `roofline` are the product's): the net measures itself against fp32 on its weights and runs the cheapest engine of mx6 -> fp16x2 -> fp32 inside 5e-4 (mx6 on the bench's TF-default weights at 7 and at 19 blocks; fp16x2 on the peaked trained-like set at 19); the fast fp16 engine is then timed as the fast_engine leg.  mx6 = fp16 hi halves + both cross terms of the hi + lo split on one block-scaled fp6 MFMA (k_trunk_mx_c128, 1.5 MFMA-equivalents per product); fp16x2 / bf16x2 = hi + lo halves of that type, three MFMAs per product (k_trunk_split_c128; also 19 blocks); fp16: one fp16 per operand (k_tower8_c128), twice the rate, 1e-3 only relative to the logit scale (see net_error in the output); with fp16 / bf16 the strict engine is the extra leg")
     ap.add_argument("--age-steps", type=int, default=800, help="untimed lock-steps BEFORE --warmup that bring every tree to a representative phase of its search: each tree's first search is cut at its own threshold (uniform in [8, age-steps] simulations), so when the timed region starts the trees are spread over the phases of a playout-long search on subtrees kept from a previous ply — the state of a long run — instead of all standing 25 simulations into a fresh search")
     ap.add_argument("--steady-steps", type=int, default=2000, help="extra lock-steps timed AFTER the K contract steps (own barrier-bracketed region) for the steady_state block of the output; 0 = off")
     ap.add_argument("--alt-steps", "--strict-steps", dest="alt_steps", type=int, default=240, help="lock-steps of a third timed region in which the SAME trees are searched with the OTHER engine: the fast fp16 engine (k_tower8_c128; the fast_engine block of the output) when the run's engine is a strict one, the strict engine of this depth (the strict_engine block) when --dtype is fp16 / bf16; 0 = off")
@@ -350,7 +349,7 @@ def main():
     args = ap.parse_args()
     asked_strict = args.dtype == "strict"
     if asked_strict:   # where the ladder starts; the net's own measurement (strict_check, below) has the last word
-        args.dtype = "mx6" if args.blocks <= MX_DEPTH_LIMIT else "fp16x2"
+        args.dtype = "mx6"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))

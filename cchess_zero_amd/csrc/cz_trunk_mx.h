@@ -192,10 +192,21 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
         }
     };
     f32x16 xreg[3];   // block input x (fp32) at this lane's accumulator positions
+    float4 bqn[4];   // the NEXT tower layer's bias at this lane's accumulator positions, requested before the epilogue of the layer in
+                     // front of it (round 6: the four loads at the top of a layer cost their full L2 latency once per layer)
+    auto load_bias = [&](const float *bl) {
+        // the lane's offset is recomputed from an opaque copy of the thread index: kept across the slab loops as a 64-bit per-lane
+        // pointer it would be parked in scratch and cost a dependent global round trip per layer, which is what this is here to remove
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        const int boff = ((t >> 6) & 3) * 32 + 4 * ((t & 63) >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bqn[q] = *reinterpret_cast<const float4 *>(bl + boff + 8 * q);
+    };
     auto init_acc = [&](f32x16 (&acc)[3], const float *bl, bool add_x) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 bq = *reinterpret_cast<const float4 *>(bl + ct * 32 + 8 * q + 4 * khalf);
+            const float4 bq = bl ? *reinterpret_cast<const float4 *>(bl + ct * 32 + 8 * q + 4 * khalf) : bqn[q];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 acc[i][4 * q + 0] = bq.x + (add_x ? xreg[i][4 * q + 0] : 0.0f);
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
     {   // first layer: conv3x3(14 -> 128) + BN + ReLU; the planes are exact in 16 bits, the weights are hi + lo (two fp16 MFMAs)
         f32x16 acc[3];
         init_acc(acc, b0, false);
+        load_bias(bias);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int shift = (t / 3 - 1) * 10 + (t % 3 - 1);
@@ -309,6 +321,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
             ++g;                                                                                                     \
         }
 
+#ifdef MX_TIMING   /* diagnostic build (tools/mx_timing.py): where a workgroup's cycles go; the clock-probe buffer carries the sums */
+    unsigned long long tm_loop = 0, tm_epi = 0, tm_set = 0, tm_t0 = __builtin_readcyclecounter();
+    const unsigned long long tm_first = tm_t0 - clk_c0;
+#define MX_TM(acc) { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - tm_t0; tm_t0 = n_; }
+#else
+#define MX_TM(acc)
+#endif
     struct MxFrag { bf16x8 a[3], w; };
     int g = 0;
     int skipm;   // cell group 0 (waves 0..3): its first row tile skips the dy = -1 taps
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
 #pragma unroll 1
     for (int layer = 0; layer < nlayers; ++layer) {
         f32x16 acc[3];
-        init_acc(acc, bias + layer * 128, (layer & 1) != 0);
+        init_acc(acc, nullptr, (layer & 1) != 0);
         int ab[3], key[3], nab[3], nkey[3], xr[3], yr[3], nxr[3], nyr[3], t0, t1, t2, wsr;
         int sb[3] = {0, 0, 0};
         MxFrag fa, fb;
@@ -332,6 +351,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
             fb.w = *reinterpret_cast<const bf16x8 *>(smem + vb + 4096);
             asm volatile("" : "+v"(fa.a[0]), "+v"(fa.a[1]), "+v"(fa.a[2]), "+v"(fa.w), "+v"(fb.a[0]), "+v"(fb.a[1]), "+v"(fb.a[2]), "+v"(fb.w));
         }
+        MX_TM(tm_set)
         int tap = 0;
 #pragma unroll 1
         for (; tap < 3; ++tap) {   // dy = -1: cell group 0 branches around the MFMAs of its all-rank-0 row tile
@@ -344,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
             for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; xr[i] = nxr[i]; yr[i] = nyr[i]; }
         }
 #pragma unroll 1
-        for (; tap < 9; ++tap) {
+        for (; tap < 8; ++tap) {
             MX_RUN(MX_SLAB_ASM_Q0, ab, key)
             MX_RUN(MX_SLAB_ASM_Q1, ab, key)
             MX_RUN(MX_SLAB_ASM_Q2, ab, key)
@@ -353,12 +373,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
 #pragma unroll
             for (int i = 0; i < 3; ++i) { ab[i] = nab[i]; key[i] = nkey[i]; xr[i] = nxr[i]; yr[i] = nyr[i]; }
         }
-        // the last slab requested operands of a slab that does not exist: drain them, let the MFMAs retire, and make sure
-        // every wave is done reading the activations before anyone overwrites them in place
+        MX_RUN(MX_SLAB_ASM_Q0, ab, key)      // tap 8; its last slab requests nothing and has waited for every LDS read of the wave in
+        MX_RUN(MX_SLAB_ASM_Q1, ab, key)      // front of its barrier: behind that barrier nobody reads the activation planes any more,
+        MX_RUN(MX_SLAB_ASM_Q2, ab, key)      // and the epilogue may overwrite them in place without a barrier of its own
+        MX_RUN(MX_SLAB_ASM_Q3_LAST, ab, key)
         const bool last = layer + 1 == nlayers;
         if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fp32 rows reach into the weight ring
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        __syncthreads();
+        else load_bias(bias + (layer + 1) * 128);
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // let the MFMAs retire (the compiler does not see them)
+        MX_TM(tm_loop)
         refresh_rk();
         if (last) {
 #pragma unroll
@@ -368,10 +391,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_mx_c128(const unsigned char *_
             for (int i = 0; i < 3; ++i) store_tile(acc[i], i, (layer & 1) != 0);
         }
         __syncthreads();
+        MX_TM(tm_epi)
     }
     if (clk && tid == 0) {
         clk[blockIdx.x * 4 + 0] = clk_c0; clk[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
         clk[blockIdx.x * 4 + 2] = clk_r0; clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#ifdef MX_TIMING
+        clk[blockIdx.x * 4 + 0] = tm_first; clk[blockIdx.x * 4 + 1] = tm_loop; clk[blockIdx.x * 4 + 2] = tm_epi; clk[blockIdx.x * 4 + 3] = tm_set;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (out) {   // trunk activations as fp32, 4 channels per thread and step

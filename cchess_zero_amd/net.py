@@ -204,7 +204,10 @@ def to_tf_variables(module, global_step=None):
     return out
 
 
-MX_DEPTH_LIMIT = 8   # precision "strict": k_trunk_mx_c128 up to this many residual blocks, k_trunk_split_c128 beyond
+# (Round 5 had MX_DEPTH_LIMIT = 8 here: precision "strict" used k_trunk_mx_c128 up to 8 residual blocks and k_trunk_split_c128
+# beyond, a depth constant with a 2x margin on one synthetic weight family.  Since round 6 "strict" MEASURES: the ladder starts at
+# mx6 at any depth and PolicyValueNet.strict_check decides — TF-default weights at 19 blocks measure 1.5e-5 and stay on mx6, the
+# peaked trained-like set of the tests measures 1.0e-3 there and falls over to the three-MFMA engine.)
 
 
 def _e2m3_codes(x):
@@ -302,12 +305,12 @@ class PolicyValueNet:
         product — north_star's 1e-3 against the fp32 graph also on peaked, trained-like weights and at 19 blocks (measured
         2e-5 / 1e-4), at a third of the 16-bit engine's rate.  "mx" = k_trunk_mx_c128 (fp16 only): the hi halves on fp16 MFMAs,
         both cross terms of the split on one block-scaled fp6 MFMA: 1.5 MFMA-equivalents per product, half the 16-bit engine's
-        rate, 5e-4 / 2e-4 at 7 blocks (1.0e-3 / 1.1e-3 at 19).  "strict" = "mx" up to MX_DEPTH_LIMIT blocks, "x3" beyond."""
+        rate, 5e-4 / 2e-4 at 7 blocks (1.0e-3 / 1.1e-3 at 19).  "strict" = the ladder mx6 -> fp16x2 -> fp32, measured (strict_check)."""
         self.device = torch.device(device)
         self.dtype = dtype
         # split: False | True (= "x3": k_trunk_split_c128, three MFMAs per product) | "mx" (k_trunk_mx_c128: fp16 hi halves +
-        # both cross terms on one block-scaled fp6 MFMA, 1.5 MFMA-equivalents per product, fp16 only) | "strict" (the cheaper
-        # of the two that holds 1e-3 with a factor of two to spare at this depth: mx up to MX_DEPTH_LIMIT blocks)
+        # both cross terms on one block-scaled fp6 MFMA, 1.5 MFMA-equivalents per product, fp16 only) | "strict" (the cheapest
+        # engine that MEASURES within STRICT_CHECK_TOL of fp32 on the live weights)
         # "strict" is a GUARANTEE, not a depth constant (round 6): the depth rule picks where to start, then every refresh() —
         # construction, restore(), each train_step — is followed (lazily, at the next evaluation) by strict_check(): the engine
         # is measured against the fp32 module on the live weights and the net falls over mx6 -> fp16x2 -> fp32 above
@@ -317,7 +320,7 @@ class PolicyValueNet:
         self._check_pending = False
         self._fp32_fallback = False
         if split == "strict":
-            split = "mx" if (module.res_block_nums if module is not None else res_block_nums) <= MX_DEPTH_LIMIT and dtype == torch.float16 else True
+            split = "mx" if dtype == torch.float16 else True
         if split == "x3":
             split = True
         if split not in (False, True, "mx"):
@@ -348,7 +351,7 @@ class PolicyValueNet:
         """Re-fold BN and re-cast after a weight change.  Precision "strict": the engine ladder starts over and the new
         weights are measured at the next evaluation (strict_check)."""
         if self.strict_auto:
-            self._strict_select(0 if (self.res_block_nums <= MX_DEPTH_LIMIT and self.dtype == torch.float16) else 1)
+            self._strict_select(0 if self.dtype == torch.float16 else 1)
             self._check_pending = self.device.type == "cuda"
         self._pack()
 

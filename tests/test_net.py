@@ -107,7 +107,7 @@ def test_facade_default_forward_meets_1e3(tmp_path):
     1.2e-4 / 1.1e-4)."""
     from policy_value_network import policy_value_network
     deep = policy_value_network(9, save_dir=str(tmp_path / "deep"))
-    assert deep.net.split and not deep.net.mx            # deeper than MX_DEPTH_LIMIT: three fp16 MFMAs per product
+    assert deep.strict_report()["engine"] == "mx6" and deep.net.mx     # round 6: no depth constant, the measurement decides (TF-default weights: mx6)
     pv = policy_value_network(7, save_dir=str(tmp_path))
     assert pv.net.dtype == torch.float16 and pv.net.backend == "hip" and pv.net.fused_search and pv.net.split and pv.net.mx
     x = _positions(64, 2)
@@ -377,24 +377,29 @@ def test_mx_engine_meets_1e3_absolute(blocks, wset):
 
 
 @pytest.mark.gpu
-def test_mx_engine_at_19_blocks_is_at_the_edge_and_strict_does_not_pick_it():
-    """Why precision "strict" stops using k_trunk_mx_c128 at MX_DEPTH_LIMIT blocks: at 19 blocks its error on the peaked trained-like
-    set of this suite sits AT north_star's 1e-3 (measured on the MI355X 1.02e-3 / 7.2e-4, emulated 1.02e-3 / 1.14e-3; on TF-default
-    weights 1.5e-5) — inside 2e-3, not inside 1e-3 with room to spare; split="strict" selects the three-MFMA engine there
-    (test_strict_engine_meets_1e3_absolute: 4.1e-5 / 1.8e-4)."""
-    from cchess_zero_amd.net import MX_DEPTH_LIMIT, PolicyValueNet
-    assert MX_DEPTH_LIMIT == 8
+def test_mx_engine_at_19_blocks_is_at_the_edge_and_strict_measures_it():
+    """At 19 blocks k_trunk_mx_c128's error on the peaked trained-like set of this suite sits AT north_star's 1e-3 (measured on the
+    MI355X 1.02e-3 / 7.2e-4, emulated 1.02e-3 / 1.14e-3; on TF-default weights 1.5e-5).  Round 5 kept it away from deep nets with a
+    depth constant; since round 6 precision "strict" measures: on these weights it falls over to the three-MFMA engine (4.1e-5 /
+    1.8e-4), on TF-default weights of the same depth it stays on mx6."""
+    from cchess_zero_amd.net import STRICT_CHECK_TOL, PolicyValueNet
     net = PolicyValueNet(19, "cuda:0", torch.float16, seed=1, split="mx")
-    H.trained_like_(net)
     x = _positions(64, 2)
+    auto0 = PolicyValueNet(19, "cuda:0", torch.float16, split="strict", module=net.module)       # TF-default weights
+    rep0 = auto0.strict_check()
+    assert rep0["engine"] == "mx6" and not rep0["fell_over_from"] and max(rep0["dlogit"], rep0["dvalue"]) <= 1e-4
+    H.trained_like_(net)
     logits, v = net.forward(x)
     ln, vn = net_numpy.forward(net.module.export_tf_layout(), x, 19)
     e = H.errors(logits, v, ln, vn)
     print("mx6 19-block trained_like (explicit choice): dlogit %.3g dvalue %.3g argmax agreement %.3f" % (e["dlogit"], e["dvalue"], e["argmax_agree"]))
     assert e["dlogit"] <= 2e-3 and e["dvalue"] <= 2e-3 and e["argmax_agree"] == 1.0
     auto = PolicyValueNet(19, "cuda:0", torch.float16, split="strict", module=net.module)
-    assert auto.split and not auto.mx
-    l2, v2 = auto.forward(x)
+    l2, v2 = auto.forward(x)                             # the pending measurement happens here
+    rep = auto.strict_report
+    print("strict on the 19-block trained-like set:", rep)
+    assert rep["engine"] == "fp16x2" and rep["fell_over_from"][0]["engine"] == "mx6" and auto.split and not auto.mx
+    assert max(rep["fell_over_from"][0]["dlogit"], rep["fell_over_from"][0]["dvalue"]) > STRICT_CHECK_TOL
     e2 = H.errors(l2, v2, ln, vn)
     assert e2["dlogit"] <= 2e-4 and e2["dvalue"] <= 2.5e-4
 

@@ -123,13 +123,16 @@ MX_AX = ["v[232:237]", "v[238:243]", "v[244:249]"]   # fp6 activation blocks of 
 MX_WX = "v[250:255]"                                  # one slab body, so they are hard registers (the body clobbers v232..v255)
 
 
-def slabMX(hs):
+def slabMX(hs, layer_last=False):
     """One 16 KB slab = 32 input channels of one tap: [fp16 hi: 2 k-steps x 2 halves x 128 co x 8][fp6 blocks: X 2 x 128 x 16 B,
     Y 2 x 128 x 8 B][E8M0 scale dwords 2 x 128].  Three steps of three MFMAs; operands are requested TWO steps ahead:
       A (k-step 0, set a0*/w0)  waits for its set (the next step's 4 reads may be in flight), requests this slab's fp6 set
       B (k-step 1, set a1*/w1)  vmcnt(2) + barrier first (slab g+1 published, slab g-1's buffer free), requests the NEXT slab's
                                 set A (after the fourth slab of a tap: at the next tap's addresses)
-      C (fp6, hard registers)   requests the next slab's set B, issues the wave's 2 DMA pieces of slab g+3."""
+      C (fp6, hard registers)   requests the next slab's set B, issues the wave's 2 DMA pieces of slab g+3.
+    layer_last (round 6): the LAST slab of a layer requests no operands (the activations are about to be replaced) and waits
+    for all of its LDS reads in front of its barrier — behind it no wave reads the activation planes any more, so the epilogue
+    needs no barrier of its own in front."""
     nab, nkey = ("nab", "nkey") if hs == 3 else ("ab", "key")
     ca = ((hs + 1) % 4) * 4
     f = lambda i, w, a: "v_mfma_f32_32x32x16_f16 %%[c%d], %%[%s], %%[%s%d], %%[c%d]" % (i, w, a, i, i)
@@ -153,14 +156,18 @@ def slabMX(hs):
     L += [f(2, "w0", "a0h")]
     L += ["ds_read_b128 %s, %%[vb] offset:8192" % sub(MX_WX, 0, 3), "ds_read_b64 %s, %%[vy]" % sub(MX_WX, 4, 5), "ds_read_b32 %[ws], %[vs]"]
     # step B
-    L += ["s_waitcnt vmcnt(2)", "s_barrier", "s_waitcnt lgkmcnt(%d)" % nc]
-    L += [f(0, "w1", "a1h")]
-    L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca, nkey, i) for i in range(3)]
-    L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(3)]
-    L += [f(1, "w1", "a1h")]
-    L += ["ds_read_b128 %[a0h0], %[t0]", "ds_read_b128 %[a0h1], %[t1]"]
-    L += [f(2, "w1", "a1h")]
-    L += ["ds_read_b128 %[a0h2], %[t2]", "ds_read_b128 %[w0], %[vbn]"]
+    if layer_last:
+        L += ["s_waitcnt vmcnt(2) lgkmcnt(0)", "s_barrier"]
+        L += [f(0, "w1", "a1h"), f(1, "w1", "a1h"), f(2, "w1", "a1h")]
+    else:
+        L += ["s_waitcnt vmcnt(2)", "s_barrier", "s_waitcnt lgkmcnt(%d)" % nc]
+        L += [f(0, "w1", "a1h")]
+        L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca, nkey, i) for i in range(3)]
+        L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(3)]
+        L += [f(1, "w1", "a1h")]
+        L += ["ds_read_b128 %[a0h0], %[t0]", "ds_read_b128 %[a0h1], %[t1]"]
+        L += [f(2, "w1", "a1h")]
+        L += ["ds_read_b128 %[a0h2], %[t2]", "ds_read_b128 %[w0], %[vbn]"]
     # step C
     dma1 = ["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]
     dma2 = ["s_add_u32 m0, %[ldst], 0x2000", "s_nop 0", "global_load_lds_dwordx4 %[voff1], %[sbase]"]
@@ -171,20 +178,21 @@ def slabMX(hs):
     elif place == "B0C0":   # one behind the barrier, one at the top of step C
         i = L.index("s_barrier") + 1
         L[i:i] = dma1
-    L += ["s_waitcnt lgkmcnt(4)"]
+    L += [] if layer_last else ["s_waitcnt lgkmcnt(4)"]
     if place == "B0C0":
         L += dma2
     L += [mx(0)]
-    L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca + 2, nkey, i) for i in range(3)]
-    L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(3)]
+    if not layer_last:
+        L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca + 2, nkey, i) for i in range(3)]
+        L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(3)]
     if place == "C":
         L += dma1
     L += [mx(1)]
-    L += ["ds_read_b128 %[a1h0], %[t0]", "ds_read_b128 %[a1h1], %[t1]"]
+    L += [] if layer_last else ["ds_read_b128 %[a1h0], %[t0]", "ds_read_b128 %[a1h1], %[t1]"]
     if place == "C":
         L += dma2
     L += [mx(2)]
-    L += ["ds_read_b128 %[a1h2], %[t2]", "ds_read_b128 %[w1], %[vbn] offset:4096"]
+    L += [] if layer_last else ["ds_read_b128 %[a1h2], %[t2]", "ds_read_b128 %[w1], %[vbn] offset:4096"]
     if place == "Cend":
         L += dma1 + dma2
     L += ["s_mov_b32 m0, %[keep]"]
@@ -368,6 +376,8 @@ def main():
     txt += "// the same with the first-row-tile MFMAs (3 of 9) behind a scalar branch (dy = -1 taps, cell group 0)\n"
     for hs in range(4):
         txt += emit("MX_SKIP0_ASM_Q%d" % hs, branchy(slabMX(hs), ("%[c0],",))) + "\n"
+    txt += "// the last slab of a layer: no operand requests, every LDS read of the wave waited for in front of the barrier\n"
+    txt += emit("MX_SLAB_ASM_Q3_LAST", slabMX(3, layer_last=True)) + "\n"
     open(os.path.join(csrc, "cz_trunk_mx_asm.inc"), "w").write(txt)
     txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
     txt += "// k_trunk_mx2_c128: 8 waves / 2 positions, 3 x 2 tiles per wave, K split between the waves of a pair: 12 fp16 + 6 fp6 MFMAs per body\n"
