@@ -19,7 +19,7 @@ for step in "$@"; do
     profile) d=${arg:-fp16}; tools/profile_round.sh $TAG/prof_$d ${arg:+--dtype $arg} > $O/profile_$d.log 2>&1
              # summarised HERE (the raw traces are tens of MB and gpurun merges at most 64 MiB back): profiles_out/ holds what goes to profiles/
              case $d in mx6) k=k_trunk_mx; sfx=_mx;; fp16x2) k=k_trunk_split; sfx=_strict;; *) k=k_tower8; sfx="";; esac
-             PROFILES_OUT=$O/profiles_out python tools/summarize_profile.py gpurun_out/$TAG/prof_$d r05_$d $k $sfx > $O/summary_$d.log 2>&1; tail -4 $O/summary_$d.log
+             PROFILES_OUT=$O/profiles_out python tools/summarize_profile.py gpurun_out/$TAG/prof_$d ${ROUND:-r06}_$d $k $sfx > $O/summary_$d.log 2>&1; tail -4 $O/summary_$d.log
              rm -rf gpurun_out/$TAG/prof_$d/stats gpurun_out/$TAG/prof_$d/pmc_f gpurun_out/$TAG/prof_$d/pmc_w;;
     pmcsq) tools/pmc_mx.sh $O/pmcsq_$arg $arg 2>&1 | tail -8 | tee $O/pmcsq_$arg.txt;;
     rules) timeout 600 python tools/rules_bench.py > $O/rules_bench.log 2>&1; tail -12 $O/rules_bench.log; tools/rules_profile.sh $O/rules_prof; rm -rf $O/rules_prof/stats;;
