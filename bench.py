@@ -333,7 +333,7 @@ def main():
     ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--search-threads", type=int, default=1, help="simulations in flight per tree and step (the reference's search_threads; virtual loss 3); batch = games * search_threads")
-    ap.add_argument("--graph", action="store_true", help="replay the launches of a lock-step as one captured HIP graph (8192 trees: no gain, the host already runs ahead of the GPU; one tree x 16 search threads — the --mode play shape — is host-bound without it)")
+    ap.add_argument("--graph", action="store_true", help="replay the launches of a lock-step as one captured HIP graph (measured: no gain at 8192 trees — the host already runs ahead of the GPU — and none at one tree x 16 search threads, 0.407 vs 0.410 ms per lock-step: five serial small launches, not host time)")
     ap.add_argument("--compact", action="store_true", help="compact evaluation batches: no net row for terminal / drawn leaves (no gain at 8192 trees: the trunk runs in rounds of 1024 rows)")
     ap.add_argument("--full-policy-fc", action="store_true", help="compute all 2086 logits per leaf (k_policy_fc) instead of folding the policy FC into the expansion")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool capacity per tree (default (playout + 2) * 128)")

@@ -356,38 +356,16 @@ class SearchEngine:
             return torch.from_numpy(buf).to(self.dev).bool()
         return torch.as_tensor(active).to(self.dev).bool()
 
-    def _graphed_step(self, forward, active, target):
-        """One mode-1 lock-step captured as a HIP graph (its launches have static arguments): -> a callable that replays it, or
-        None when capture is not possible (then the caller steps eagerly).  For latency-bound shapes — one tree with 16
-        simulations in flight is five launches of 10-200 us each, and the Python loop around them costs as much again."""
-        # the kernels take the simulation budget, the tree arrays and the batch shape BY VALUE: a capture is good for exactly these
-        key = (id(getattr(forward, "__self__", forward)), None if active is None else id(active), self.G, self.width, int(target),
-               self.eval_cache, self.xcache_log2, self.terminal_extra)
-        if getattr(self, "_graph_key", None) == key:
-            return self._graph.replay
-        try:
-            self.step(forward, mode=1, active=active)          # warm: kernel attributes, allocator
-            torch.cuda.synchronize(self.dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.step(forward, mode=1, active=active)
-            self.ctx.bind_stream()
-        except Exception as e:   # a forward that cannot be captured (host round trip): eager
-            import warnings
-            warnings.warn("SearchEngine: HIP graph capture of the lock-step failed (%r); stepping eagerly" % (e,))
-            self.ctx.bind_stream()
-            self._graph_key = None
-            return None
-        self._graph, self._graph_key = g, key
-        return g.replay
-
-    def search(self, forward, playouts, active=None, graph=False, root_done=False):
+    def search(self, forward, playouts, active=None, root_done=False):
         """MCTS_tree.main (main.py:473-493) for all trees: expand unexpanded roots, then EXACTLY `playouts` simulations
         per (active, unparked) tree.  With width k > 1 up to k simulations are in flight per tree and step; a descent
         that runs into a pending expansion is abandoned (see k_select_k), so a step can complete fewer than k — the
         per-tree budget (cz_search_set_sim_target) and a few extra steps make up for it.  Returns the number of steps.
-        graph=True (width > 1, a device-resident forward): the lock-step is replayed as one captured HIP graph.
-        root_done=True: the caller has already run the mode-0 step (root expansion)."""
+        root_done=True: the caller has already run the mode-0 step (root expansion).
+        (Round 6 replayed the k-wide lock-step as one captured HIP graph for the --mode play shape — one tree, 16 simulations in
+        flight — and measured no gain, 0.407 against 0.410 ms per lock-step: the step is five SERIAL small launches on the GPU, a
+        203 us trunk for 16 positions and a k-wide select / expand that walk their 16 descents one after the other in one wave,
+        not host time; the capture was removed again.)"""
         playouts = int(playouts)
         if not root_done:
             self.step(forward, mode=0, active=active)
@@ -440,18 +418,18 @@ class SearchEngine:
         try:
             if uniform:
                 check(lib().cz_search_set_sim_target(self.ctx.h, target), "cz_search_set_sim_target")
-            one = None
-            if graph and uniform:     # the budget is a launch argument: the capture is keyed by it (a game's searches share one)
-                one = self._graphed_step(forward, active, target)
-            if one is None:
-                one = lambda: self.step(forward, mode=1, active=active)
+            one = lambda: self.step(forward, mode=1, active=active)
             n = (playouts + self.width - 1) // self.width
             for _ in range(n):
                 one()
             steps = n
             if uniform:
+                # the shortfall of abandoned descents: usually 1-3 steps — but behind a FRESH root every descent of a step picks the
+                # same child (the reference never updates the root's N, quirk Q2: U = 0 there, and its virtual loss leaves Q alone),
+                # so all but one are abandoned and a step completes ONE simulation: up to `playouts` steps, like the reference's
+                # sixteen coroutines queueing behind one expansion (round 6: the cap of 4 n + 8 extra steps ended such a search short)
                 act = self._active_bool(active)
-                for _ in range(4 * n + 8):   # the shortfall of abandoned descents, usually 1-3 steps
+                while steps < 5 * playouts + 8:
                     st, _, sims, _ = self.status()
                     live = (st & ~8) == 0
                     if act is not None:

@@ -251,10 +251,9 @@ class MCTS_tree(object):
             for _ in range(int(playouts)):
                 self._step(1)               # one simulation (main.py:350-435)
         elif self._device_forward() is not None and not os.environ.get("CCHESS_PLAY_EAGER"):
-            # up to `search_threads` simulations in flight, exactly `playouts` in total (the per-tree budget of SearchEngine.search);
-            # the net is ours and device-resident: the lock-step (five launches of 10-200 us) is replayed as one captured HIP graph —
-            # measured at one tree x 16 threads: the Python loop around the launches cost as much as the launches
-            self._eng.search(self._device_forward(), int(playouts), graph=True, root_done=True)
+            # up to `search_threads` simulations in flight, exactly `playouts` in total (the per-tree budget of SearchEngine.search:
+            # one status read-back per step instead of two, no host-side bookkeeping of k)
+            self._eng.search(self._device_forward(), int(playouts), root_done=True)
         else:                               # a host `forward`: one host round trip per step, counted on the host
             base = int(self._eng.status()[2].cpu().numpy()[0])
             done, stall = 0, 0

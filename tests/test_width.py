@@ -254,11 +254,13 @@ def test_hip_search_width_k_exact_playouts_equals_oracle(rules_golden, K, playou
 
 
 @pytest.mark.gpu
-def test_graph_captured_lock_step_equals_eager_search():
-    """SearchEngine.search(graph=True) (round 6: the --mode play shape, one tree x 16 simulations in flight, is host-bound without
-    it): the lock-step replayed as a captured HIP graph builds the trees the eager loop builds — bit for bit, over two consecutive
-    searches with a re-root in between (the second search replays the first one's capture: same budget), and through the
-    facade's MCTS_tree.main with search_threads = 16, which uses it."""
+def test_search_width_16_from_a_fresh_root_reaches_its_budget():
+    """Behind a FRESH root every descent of a k-wide step picks the same child (the reference never updates the root's N — quirk Q2:
+    U = 0 at the root — and its virtual loss leaves Q alone, main.py:403-404), so all but one are abandoned and a lock-step
+    completes ONE simulation, like the reference's sixteen coroutines queueing behind one expansion.  SearchEngine.search must
+    still deliver exactly `playouts` (round 6: its cap of 4 n + 8 catch-up steps ended such a search at 38 of 96), with the real
+    net, over two consecutive searches with a re-root in between — and so must MCTS_tree.main with search_threads = 16, which
+    uses it."""
     import torch
     from cchess_zero_amd.engine import SearchEngine
     from cchess_zero_amd.net import PolicyValueNet
@@ -266,22 +268,19 @@ def test_graph_captured_lock_step_equals_eager_search():
     b0 = O.fen_to_board(O.START_FEN)
     G, K, playouts = 3, 16, 96
     boards, side = np.tile(b0, (G, 1)), np.zeros(G, np.uint8)
-    engs = [SearchEngine(G, 20000, plane_dtype=torch.float32, channels=14, width=K) for _ in range(2)]
+    e = SearchEngine(G, 20000, plane_dtype=torch.float32, channels=14, width=K)
+    e.reset(boards, side, None)
     for ply in range(2):
-        stats = []
-        for e, graph in zip(engs, (False, True)):
-            if ply == 0:
-                e.reset(boards, side, None)
-            e.search(net.forward_device, playouts, graph=graph)
-            stats.append(e.root_stats_host())
-        a, b = stats
-        assert (a["N"].sum(axis=1) == playouts).all() and np.array_equal(a["N"], b["N"]) and np.array_equal(a["label"], b["label"])
-        assert np.array_equal(a["W"].view(np.uint32), b["W"].view(np.uint32)) and np.array_equal(a["Q"].view(np.uint32), b["Q"].view(np.uint32))
+        steps = e.search(net.forward_device, playouts)
+        a = e.root_stats_host()
+        sims = e.status()[2].cpu().numpy()
+        assert (sims == playouts).all() and (a["N"].sum(axis=1) == playouts).all() and playouts // K <= steps <= playouts + 8
         for g in range(G):
-            assert np.array_equal(engs[0].tree_dump(g), engs[1].tree_dump(g))
+            _invariants(e.tree_dump(g), playouts)
         n = a["N"].astype(np.int64).copy()
         n[np.arange(128)[None, :] >= a["count"].astype(np.int64)[:, None]] = -1
-        played = a["label"][np.arange(G), n.argmax(axis=1)].astype(np.uint16)
-        for e in engs:
-            e.advance(played)
-    assert getattr(engs[1], "_graph_key", None) is not None and getattr(engs[0], "_graph_key", None) is None
+        e.advance(a["label"][np.arange(G), n.argmax(axis=1)].astype(np.uint16))
+    import main as M
+    tree = M.MCTS_tree(M.START_STATE, net.forward, 16)
+    tree.main(tree._state, "w", 0, 80)
+    assert sum(c.N for c in tree.root.child.values()) == 80

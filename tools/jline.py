@@ -30,7 +30,7 @@ if rr and "achieved" in rr:
     print("  rules K1: %.2f G positions/s, %.0f GB/s algorithmic (frac %.3f), ABI %.0f GB/s" % (rr["positions_per_s"] / 1e9, rr["achieved"], rr["frac"], rr["abi_GBps"]))
     ol = rr.get("ordered_list_kernel")
     if ol:
-        print("    ordered-list kernel: %.2f G positions/s (frac %.3f), ABI %.0f GB/s" % (ol["positions_per_s"] / 1e9, ol["frac"], ol["abi_GBps"]))
+        print("    ordered-list kernel: %.2f G positions/s (frac %.3f), ABI %.0f GB/s" % (ol["positions_per_s"] / 1e9, ol["frac"], ol.get("abi_GBps", float("nan"))))
 t = d.get("roofline_tree")
 if t:
     print("  tree side: select %.1f us, expand %.1f us, %.0f GB/s (frac %.4f)" % (t["us_select"], t["us_expand_backup"], t["achieved"], t["frac"]))
