@@ -839,11 +839,11 @@ def main():
     tree_roof = None
     tree_traffic, tree_traffic_src = None, None
     try:   # committed counter traffic of the same launch shapes (tools/profile_round.sh -> tools/summarize_profile.py)
-        tt = json.load(open(os.path.join(ROOT, "profiles", "pmc_tree_traffic.json")))
+        tt = json.load(open(os.path.join(ROOT, "profiles", "pmc_tree_traffic%s.json" % {"mx6": "_mx", "fp16x2": "_strict"}.get(args.dtype, ""))))
         if {k: tt["config"].get(k) for k in ("B", "res_block_nums", "dtype")} == {"B": G, "res_block_nums": args.blocks, "dtype": args.dtype} and fused_fc and not compact:
             kk = tt["kernels"]
             tree_traffic = sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in ("k_select", "k_expand_backup") if n in kk)
-            tree_traffic_src = "profiles/pmc_tree_traffic.json (FETCH_SIZE x2 + WRITE_SIZE of k_select + k_expand_backup, per step)"
+            tree_traffic_src = "profiles/pmc_tree_traffic*.json of this engine's run (FETCH_SIZE x2 + WRITE_SIZE of k_select + k_expand_backup, per step)"
     except Exception:
         pass
     if ev and K == 1:
