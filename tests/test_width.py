@@ -274,12 +274,15 @@ def test_search_width_16_from_a_fresh_root_reaches_its_budget():
         steps = e.search(net.forward_device, playouts)
         a = e.root_stats_host()
         sims = e.status()[2].cpu().numpy()
-        assert (sims == playouts).all() and (a["N"].sum(axis=1) == playouts).all() and playouts // K <= steps <= playouts + 8
+        kept = 0 if ply == 0 else kept_visits            # a re-rooted tree keeps the visits of the subtree it moved into
+        assert (sims == playouts).all() and (a["N"].sum(axis=1) == playouts + kept).all() and playouts // K <= steps <= playouts + 8
         for g in range(G):
-            _invariants(e.tree_dump(g), playouts)
+            _invariants(e.tree_dump(g), playouts + int(np.atleast_1d(kept)[g if ply else 0]))
         n = a["N"].astype(np.int64).copy()
         n[np.arange(128)[None, :] >= a["count"].astype(np.int64)[:, None]] = -1
-        e.advance(a["label"][np.arange(G), n.argmax(axis=1)].astype(np.uint16))
+        best = n.argmax(axis=1)
+        kept_visits = a["N"][np.arange(G), best] - 1       # the played child's visits, minus the one that expanded it
+        e.advance(a["label"][np.arange(G), best].astype(np.uint16))
     import main as M
     tree = M.MCTS_tree(M.START_STATE, net.forward, 16)
     tree.main(tree._state, "w", 0, 80)
