@@ -115,3 +115,27 @@ def test_trained_like_probe_is_informative_cpu():
     net2 = PolicyValueNet(2, "cpu", torch.float32, seed=4, backend="torch")
     with pytest.raises(ValueError, match="distinct positions"):
         trained_like_(net2, np.repeat(x[:1], 96, axis=0))
+
+
+def test_round6_record_compacts_to_the_committed_line():
+    """profiles/r06f_bench_default_detail.json (the complete record of `python bench.py` at the round-6 code) -> compact_line == the
+    line that run printed (profiles/r06f_bench_default.json), under 8 KB, and it is the STRICT engine's line: value / roofline of
+    k_trunk_mx_c128 selected by the net's own measurement, the fast engine as a leg, an informative trained-like probe."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06f_bench_default_detail.json")))
+    line = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r06f_bench_default.json")) if l.startswith("{")][-1])
+    got = json.loads(json.dumps(bench.compact_line(full)))
+    got["detail_file"] = line["detail_file"]
+    assert {k: got[k] for k in line} == line and len(json.dumps(line)) < 8000
+    assert line["dtype"] == "mx6" and line["roofline"]["kernel"] == "k_trunk_mx_c128" and line["engine"].startswith("k_trunk_mx_c128")
+    assert 1.8e6 < line["value"] < 2.4e6 and 0.27 < line["roofline"]["frac"] < 0.36 and line["roofline"]["traffic"] > 1e9
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
+    sc = line["strict_check"]
+    assert sc["engine"] == "mx6" and sc["positions"] >= 64 and max(sc["dlogit"], sc["dvalue"]) <= sc["tol"] == 5e-4 and not sc["fell_over_from"]
+    fe = line["fast_engine"]
+    assert line["strict_engine"] is None and fe["kernel"] == "k_tower8_c128" and fe["value"] > 1.7 * line["value"] and fe["frac"] > 0.55
+    assert fe["meets_1e-3_abs_logit_and_value"] is False                      # the reason it is not the default
+    ne = line["net_error"]
+    assert ne["meets_1e-3_abs_logit_and_value_as_benchmarked"] and ne["meets_1e-3_abs_logit_and_value_trained_like"] and ne["probe_informative"]
+    assert ne["trained_like"]["dvalue"] > 0 and ne["strict_on_trained_like"]["engine"] in ("mx6", "fp16x2")
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["reference_python"]["measured_in_this_run"] is False
