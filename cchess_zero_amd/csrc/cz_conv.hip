@@ -7,6 +7,10 @@
 #include "cz_trunk_mx2.h"
 #include <cstdlib>
 #endif
+#ifdef CZ_EXPERIMENT_MX12  /* the same arithmetic with twelve waves per workgroup, two cell tiles per wave */
+#include "cz_trunk_mx12.h"
+#include <cstdlib>
+#endif
 
 extern "C" int cz_conv3x3_c128_bf16(cz_ctx *c, const void *in, const void *wpk, const float *bias, const void *residual,
                                     void *out, int B, int relu) {
@@ -123,6 +127,22 @@ extern "C" int cz_net_trunk_mx(cz_ctx *c, const void *planes16, const void *w0, 
     if (reinterpret_cast<uintptr_t>(wpk) & 15u) { cz_set_error("cz_net_trunk_mx: wpk must be 16-byte aligned"); return CZ_EINVAL; }
     if (B == 0) return CZ_OK;
     const int grid = (B + MX_P - 1) / MX_P;
+#ifdef CZ_EXPERIMENT_MX12
+    {
+        const char *e = getenv("CCHESS_MX_KERNEL");
+        if (e && e[0] == '1' && e[1] == '2') {
+            if (!c->mx2_attr_set) {
+                CZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trunk_mx12_c128), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
+                c->mx2_attr_set = true;
+            }
+            hipLaunchKernelGGL(k_trunk_mx12_c128, dim3(grid), dim3(768), MX_LDS_BYTES, c->stream, (const unsigned char *)wpk, bias, trunk_out,
+                               head_w, head_b, head_out, (const uint16_t *)planes16, (const uint16_t *)w0, b0, B, 2 * nblocks, c->batch_count,
+                               clock_probe(c, grid));
+            CZ_HIP(hipGetLastError());
+            return CZ_OK;
+        }
+    }
+#endif
 #ifdef CZ_EXPERIMENT_MX2
     if (!c->mx_kernel) {   // experiment builds only: CCHESS_MX_KERNEL=2 selects k_trunk_mx2_c128
         const char *e = getenv("CCHESS_MX_KERNEL");

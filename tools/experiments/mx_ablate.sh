@@ -11,11 +11,13 @@ mkdir -p tools/ab
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   top=$(mktemp -d /tmp/mxab.XXXX); d=$top/pkg/csrc; mkdir -p $d $top/include
-  cp -r cchess_zero_amd/csrc/. $d/; cp include/cchess_hip.h $top/include/; cp tools/experiments/cz_trunk_mx2.h $d/
+  cp -r cchess_zero_amd/csrc/. $d/; cp include/cchess_hip.h $top/include/; cp tools/experiments/cz_trunk_mx2.h tools/experiments/cz_trunk_mx12.h $d/
   DEF=""
   case $flags in place:*) MX_DMA_PLACE=${flags#place:} python3 tools/gen_tower_asm.py $d > /dev/null;;
                  place2:*) MX2_DMA_PLACE=${flags#place2:} python3 tools/gen_tower_asm.py $d > /dev/null;;
                  mx2) DEF="-DCZ_EXPERIMENT_MX2"; python3 tools/gen_tower_asm.py $d > /dev/null;;
+                 mx12) DEF="-DCZ_EXPERIMENT_MX12"; python3 tools/gen_tower_asm.py $d > /dev/null;;
+                 mx12:*) DEF="-DCZ_EXPERIMENT_MX12 -D${flags#mx12:}"; python3 tools/gen_tower_asm.py $d > /dev/null;;
                  mx2:*) DEF="-DCZ_EXPERIMENT_MX2 -D${flags#mx2:}"; python3 tools/gen_tower_asm.py $d > /dev/null;;
                  define:*) DEF="-D${flags#define:}"; python3 tools/gen_tower_asm.py $d > /dev/null;;
                  *) MX_ABLATE=$flags python3 tools/gen_tower_asm.py $d > /dev/null;; esac

@@ -312,6 +312,59 @@ def slabMX2(first, layer_first=False, layer_last=False):
     return L
 
 
+# ---- k_trunk_mx12_c128 (tools/experiments/cz_trunk_mx12.h, round 6): k_trunk_mx_c128's arithmetic, layout and slab format with TWELVE
+# waves per workgroup (three per SIMD), two cell tiles per wave: the same MFMAs per slab and SIMD, a third wave to cover the waits.
+MX12_AX = ["v[144:149]", "v[150:155]"]      # fp6 activation blocks of the two cell tiles
+MX12_WX = "v[156:161]"                      # (the body clobbers v144..v161: below the 168 registers a wave of three per SIMD has)
+
+
+def slabMX12(hs, pieces, layer_last=False):
+    """slabMX for two cell tiles per wave: three steps of TWO MFMAs.  pieces: LDS-DMA pieces the wave issues per slab (waves 0-3: 2,
+    waves 4-11: 1 — sixteen 1 KB pieces over twelve waves); its vmcnt wait lets exactly the previous body's pieces stay in flight."""
+    nab, nkey = ("nab", "nkey") if hs == 3 else ("ab", "key")
+    ca = ((hs + 1) % 4) * 4
+    f = lambda i, w, a: "v_mfma_f32_32x32x16_f16 %%[c%d], %%[%s], %%[%s%d], %%[c%d]" % (i, w, a, i, i)
+    mx = lambda i: ("v_mfma_scale_f32_32x32x64_f8f6f4 %%[c%d], %s, %s, %%[c%d], %%[ws], %%[sb%d] op_sel:[0,%d,0] op_sel_hi:[0,%d,0] cbsz:2 blgp:2"
+                    % (i, MX12_WX, MX12_AX[i], i, i, hs & 1, hs >> 1))
+    sub = lambda r, lo, hi: "v[%d:%d]" % (int(r[2:].split(":")[0]) + lo, int(r[2:].split(":")[0]) + hi)
+    xo, yo = hs * 2 * MX_XPLANE, MX_Y_OFF + hs * 2 * MX_YPLANE
+    L = ["s_mov_b32 %[keep], m0"]
+    # step A
+    L += ["s_waitcnt lgkmcnt(3)", f(0, "w0", "a0h")]
+    L += ["ds_read_b128 %s, %%[xr0] offset:%d" % (sub(MX12_AX[0], 0, 3), xo), "ds_read_b64 %s, %%[yr0] offset:%d" % (sub(MX12_AX[0], 4, 5), yo),
+          "ds_read_b128 %s, %%[xr1] offset:%d" % (sub(MX12_AX[1], 0, 3), xo), "ds_read_b64 %s, %%[yr1] offset:%d" % (sub(MX12_AX[1], 4, 5), yo)]
+    nc = 7
+    if hs == 0:
+        L += ["v_lshrrev_b32 %[t0], 1, %[yr0]", "v_lshrrev_b32 %[t1], 1, %[yr1]"]
+        L += ["ds_read_b32 %%[sb%d], %%[t%d] offset:%d" % (i, i, MX_S_OFF) for i in range(2)]
+        nc = 9
+    L += [f(1, "w0", "a0h")]
+    L += ["ds_read_b128 %s, %%[vb] offset:8192" % sub(MX12_WX, 0, 3), "ds_read_b64 %s, %%[vy]" % sub(MX12_WX, 4, 5), "ds_read_b32 %[ws], %[vs]"]
+    # step B
+    if layer_last:
+        L += ["s_waitcnt vmcnt(%d) lgkmcnt(0)" % pieces, "s_barrier", f(0, "w1", "a1h"), f(1, "w1", "a1h")]
+    else:
+        L += ["s_waitcnt vmcnt(%d)" % pieces, "s_barrier", "s_waitcnt lgkmcnt(%d)" % nc]
+        L += [f(0, "w1", "a1h")]
+        L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca, nkey, i) for i in range(2)]
+        L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(2)]
+        L += [f(1, "w1", "a1h")]
+        L += ["ds_read_b128 %[a0h0], %[t0]", "ds_read_b128 %[a0h1], %[t1]", "ds_read_b128 %[w0], %[vbn]"]
+    # step C
+    dma1 = ["s_mov_b32 m0, %[ldst]", "s_nop 0", "global_load_lds_dwordx4 %[voff0], %[sbase]"]
+    dma2 = ["s_add_u32 m0, %[ldst], 0x3000", "s_nop 0", "global_load_lds_dwordx4 %[voff1], %[sbase]"] if pieces == 2 else []
+    L += [] if layer_last else ["s_waitcnt lgkmcnt(3)"]
+    L += [mx(0)]
+    if not layer_last:
+        L += ["v_xor_b32 %%[t%d], %d, %%[%s%d]" % (i, ca + 2, nkey, i) for i in range(2)]
+        L += ["v_lshl_add_u32 %%[t%d], %%[t%d], 4, %%[%s%d]" % (i, i, nab, i) for i in range(2)]
+    L += dma1 + dma2
+    L += [mx(1)]
+    L += [] if layer_last else ["ds_read_b128 %[a1h0], %[t0]", "ds_read_b128 %[a1h1], %[t1]", "ds_read_b128 %[w1], %[vbn] offset:4096"]
+    L += ["s_mov_b32 m0, %[keep]"]
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -390,6 +443,14 @@ def main():
     # an experiment (tools/experiments/cz_trunk_mx2.h; built by tools/experiments/mx_ablate.sh with -DCZ_EXPERIMENT_MX2): written next
     # to that header unless an output directory was given (then into it, as for the ablation builds)
     open(os.path.join(csrc if len(sys.argv) > 1 else os.path.join(here, "experiments"), "cz_trunk_mx2_asm.inc"), "w").write(txt)
+    txt = "// GENERATED by tools/gen_tower_asm.py — do not edit.  See that script for the issue plan.\n"
+    txt += "// k_trunk_mx12_c128: 12 waves / 2 positions, 2 cell tiles per wave: 4 fp16 + 2 fp6 MFMAs per slab and wave\n"
+    for hs in range(4):
+        txt += emit("MX12_SKIP0_P2_Q%d" % hs, branchy(slabMX12(hs, 2), ("%[c0],",))) + "\n"    # waves 0-3: two DMA pieces, dy = -1 skip of tile 0
+        txt += emit("MX12_SLAB_P2_Q%d" % hs, slabMX12(hs, 2)) + "\n"
+        txt += emit("MX12_SLAB_P1_Q%d" % hs, slabMX12(hs, 1)) + "\n"
+    txt += emit("MX12_SLAB_P2_Q3_LAST", slabMX12(3, 2, layer_last=True)) + "\n" + emit("MX12_SLAB_P1_Q3_LAST", slabMX12(3, 1, layer_last=True)) + "\n"
+    open(os.path.join(csrc if len(sys.argv) > 1 else os.path.join(here, "experiments"), "cz_trunk_mx12_asm.inc"), "w").write(txt)
     print("wrote cz_tower_slab_asm.inc (%d instructions per slab), cz_trunk_split_asm.inc (%d), cz_trunk_mx_asm.inc (%d), cz_trunk_mx2_asm.inc (%d per body)" %
           (len(slab8(0)), len(slabX(0, XS_LO_OFF)), len(slabMX(1)), len(slabMX2(False))))
 

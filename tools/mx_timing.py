@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 check(lib().cz_set_clock_probe(net._hip_ctx().h, None, 0), "cz_set_clock_probe")
 b = pr.buf[:4096].cpu().numpy().astype(np.float64)
 b2 = pr.buf[4096:8192].cpu().numpy().astype(np.float64)
-if os.environ.get("CCHESS_MX_KERNEL", "1") != "2":     # k_trunk_mx_c128 built with -DMX_TIMING: before the tower | slab loops | barrier + epilogue + barrier | bias / x init + address set-up + operand preload
+if os.environ.get("CCHESS_MX_KERNEL", "1") != "2" or os.environ.get("CCHESS_MX_TIMING_V1"):     # k_trunk_mx_c128 built with -DMX_TIMING: before the tower | slab loops | barrier + epilogue + barrier | bias / x init + address set-up + operand preload
     tot = b.sum(axis=1)
     print("k_trunk_mx_c128 per workgroup (wave 0): before the tower %.0f | slab loops %.0f (%.1f %%) = %.0f per layer = %.0f per slab | barrier + epilogue + barrier %.0f per layer | init + set-up + preload %.0f per layer | sum %.0f"
           % (b[:, 0].mean(), b[:, 1].mean(), 100 * b[:, 1].mean() / tot.mean(), b[:, 1].mean() / 14, b[:, 1].mean() / 14 / 36, b[:, 2].mean() / 14, b[:, 3].mean() / 14, tot.mean()))
