@@ -106,10 +106,12 @@ def test_trained_like_probe_is_informative_cpu():
     net = PolicyValueNet(2, "cpu", torch.float32, seed=4, backend="torch")
     with torch.no_grad():
         net.module.value_conv.conv.bias.fill_(-50.0)      # dead: every pre-activation far below zero
-    _, v0 = net.module(torch.from_numpy(x).permute(0, 3, 1, 2))
+    with torch.no_grad():
+        _, v0 = net.module(torch.from_numpy(x).permute(0, 3, 1, 2))
     assert float(v0.std()) == 0.0
     trained_like_(net, x)
-    lg, v = net.module(torch.from_numpy(x).permute(0, 3, 1, 2))
+    with torch.no_grad():
+        lg, v = net.module(torch.from_numpy(x).permute(0, 3, 1, 2))
     assert float(v.std()) > 0.05 and float(v.abs().max()) < 1.0 and 5.0 < float(lg.max(dim=1).values.mean()) < 15.0
     import pytest
     net2 = PolicyValueNet(2, "cpu", torch.float32, seed=4, backend="torch")

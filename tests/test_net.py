@@ -584,3 +584,52 @@ def test_strict_last_rung_fp32_drives_the_fused_search_loop():
         e.search(n.forward_device, 24)
     a, b = ea.root_stats_host(), eb.root_stats_host()
     assert np.array_equal(a["N"], b["N"]) and np.array_equal(a["label"], b["label"])
+
+
+def test_strict_ladder_logic_cpu():
+    """The control flow of precision "strict" without a GPU: a stand-in whose engines deviate from the fp32 module by a chosen
+    amount per rung.  The ladder goes mx6 -> fp16x2 -> fp32 exactly as far as the measurement demands, reports what it measured
+    and what it fell over from, treats a non-finite engine as a failure, starts over after refresh(), and never leaves the last
+    rung."""
+    import warnings
+    from cchess_zero_amd.net import STRICT_CHECK_TOL, PolicyValueModule, PolicyValueNet
+
+    class Fake(PolicyValueNet):
+        def __init__(self, err_by_rung):
+            self.device, self.dtype = torch.device("cpu"), torch.float16
+            self.module = PolicyValueModule(1, seed=2)
+            self.res_block_nums = 1
+            self.strict_auto, self.strict_report, self._check_pending, self._fp32_fallback = True, None, False, False
+            self.err_by_rung, self.packs = err_by_rung, []
+            self.refresh()
+
+        def _pack(self):
+            self.packs.append(self._rung)
+
+        @torch.no_grad()
+        def forward_device(self, planes):
+            lg, v = self.module(planes.permute(0, 3, 1, 2).contiguous())
+            e = self.err_by_rung[self._rung]
+            return lg + e, v + (0.5 * e if e == e else e)
+
+    x = torch.from_numpy(_positions(8, 4))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        n = Fake({0: 1e-5, 1: 0.0, 2: 0.0})
+        r = n.strict_check(x)
+        assert r["engine"] == "mx6" and not r["fell_over_from"] and abs(r["dlogit"] - 1e-5) < 2e-6 and r["positions"] == 8 and r["tol"] == STRICT_CHECK_TOL
+        assert n.mx and n.split and n.backend == "hip" and not w
+        n = Fake({0: 8e-4, 1: 2e-5, 2: 0.0})
+        r = n.strict_check(x)
+        assert r["engine"] == "fp16x2" and [f["engine"] for f in r["fell_over_from"]] == ["mx6"] and abs(r["fell_over_from"][0]["dlogit"] - 8e-4) < 2e-5
+        assert not n.mx and n.split and n.backend == "hip" and n.packs == [0, 1] and len(w) == 1 and "falling over to fp16x2" in str(w[0].message)
+        n.refresh()                                   # new weights: the ladder starts over, the measurement is pending
+        assert n.mx and n._rung == 0 and n._check_pending is False      # (pending only with a GPU: this stand-in lives on the CPU)
+        n = Fake({0: float("nan"), 1: 6e-4, 2: 1e-7})
+        r = n.strict_check(x)
+        assert r["engine"] == "fp32" and [f["engine"] for f in r["fell_over_from"]] == ["mx6", "fp16x2"] and n.backend == "torch" and n._fp32_fallback
+        assert r["fell_over_from"][0]["dlogit"] != r["fell_over_from"][0]["dlogit"]       # NaN recorded, counted as a failure
+        n = Fake({0: 1.0, 1: 1.0, 2: 1.0})          # nothing meets the tolerance: the last rung is where it stays, and says so
+        r = n.strict_check(x)
+        assert r["engine"] == "fp32" and r["dlogit"] > STRICT_CHECK_TOL and len(r["fell_over_from"]) == 2
+        assert n.strict_check(x, tol=2.0)["engine"] == "fp32"           # a later check does not climb back up by itself (refresh does)
