@@ -376,8 +376,9 @@ int cz_net_trunk_split(cz_ctx *, const void *planes16, const void *w0, const flo
  * (v_mfma_scale_f32_32x32x64_f8f6f4, E2M3 operands, one E8M0 scale per cell / output channel and 16 input channels):
  * 1.5 instead of 3 fp16-MFMA-equivalents per product, the cross terms to 4 significant bits per operand (~2^-16 of a product).
  * Replaces the same fp32 sess.run (policy_value_network.py:202-214); |dlogit|, |dvalue| <= 1e-3 against it on trained-like
- * weights up to 8 blocks with a factor of two to spare (tests/test_net.py, tests/mxemu.py is its CPU emulation); deeper nets
- * keep cz_net_trunk_split.
+ * weights up to 8 blocks with a factor of two to spare, at the edge of 1e-3 at 19 (tests/test_net.py, tests/mxemu.py is its CPU
+ * emulation).  Which of this and cz_net_trunk_split a net runs is MEASURED on its live weights by the host side (precision
+ * "strict", cchess_zero_amd/net.py: strict_check), not decided by depth.
  *   planes16 : [B][90][16] fp16; w0 / b0 : as cz_net_trunk_split with CZ_F16 (the first layer is two fp16 MFMAs per tap)
  *   wpk  : [2*nblocks][9 taps][4 quarters][16384 bytes]: per 32-input-channel quarter of a tap (one LDS-DMA slab)
  *          [fp16 w_hi: 4 = ci/8][128 co][8] (8192 B) [fp6 blocks, first 16 bytes: 2 halves][128 co][16] (4096 B)

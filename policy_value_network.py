@@ -34,8 +34,8 @@ class policy_value_network(object):
     def __init__(self, res_block_nums=7, device=None, dtype=None, save_dir="./models", seed=0, precision=None):
         """precision (or the environment's CCHESS_NET_PRECISION; default "strict"): which engine evaluates the net.
           "strict"   the drop-in default: forward() within 1e-3 ABSOLUTE of the reference's fp32 sess.run
-                     (policy_value_network.py:202-214), MEASURED, not assumed: it starts with "mx6" up to 8 residual blocks and
-                     "fp16x2" beyond, and after every weight change (construction, restore(), each train_step) the engine and
+                     (policy_value_network.py:202-214), MEASURED, not assumed: it starts on "mx6" (on "bf16x2" for bf16 nets)
+                     and after every weight change (construction, restore(), each train_step) the engine and
                      the fp32 module evaluate 64 distinct positions; above 5e-4 in a logit or the value the net falls over
                      mx6 -> fp16x2 -> fp32 and says so (net.strict_report / strict_report() hold the last measurement);
           "mx6"      fp16 hi halves on fp16 MFMAs + both cross terms of the hi + lo split on ONE block-scaled fp6 MFMA
