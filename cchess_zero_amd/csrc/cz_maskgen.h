@@ -76,6 +76,16 @@ CZM_FN uint32_t czm_dot4(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 CZM_FN uint32_t czm_low(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << (n & 31)) - 1u); }   // bits 0 .. n-1, 0 <= n <= 32
+CZM_FN uint32_t czm_bitrev32(uint32_t v) {
+#if defined(__clang__)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1); v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4); v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+CZM_FN int czm_ctz32(uint32_t v) { return __builtin_ctz(v); }   // v != 0
 CZM_FN bool czm_tst(const CzmSet &s, int q) {   // 0 <= q < 90
     const uint32_t v = q < 64 ? (uint32_t)(s.lo >> (q & 63)) : s.hi >> (q & 31);
     return (v & 1u) != 0u;
@@ -540,42 +550,49 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
 #pragma unroll
     for (int s = 0; s < 16; ++s) off[s] = (int)scr(rk[s]);
     mid();
-    // every piece writes its moves at its offset
-    auto emit_desc = [&](uint32_t bits, int label0, int &n) {   // set bits from the highest down
-        while (CZM_ANY(bits != 0u)) {
-            const bool c = bits != 0u;
-            const int i = c ? 31 - __builtin_clz(bits) : 0;
-            put(n, label0 + i, c);
-            n += c ? 1 : 0;
-            bits &= ~(1u << i);
-        }
+    // every piece writes its moves at its offset.  Round 6: no loops over set bits (a `while any lane has a bit left` loop ran as
+    // long as the wave's richest position, ~140 iterations of ~12 instructions per group of 64 positions = 44 % of the list
+    // kernel): every CANDIDATE of a piece is visited once, in the reference's order, with put(n, label, is-it-a-move).  For a
+    // rook / cannon the eight same-rank candidates in emission order are bit p of  perm = reverse(field below x) | field from x up
+    // (p < x: file x - 1 - p, the -x ray from the piece outwards; p >= x: bit p, the +x ray), their label offsets the nibbles of a
+    // word made from x alone; the nine same-file candidates likewise from y.
+    auto cand = [&](bool c, int label, int &n) { put(n, label, c); n += c ? 1 : 0; };
+    auto order_bits = [](uint32_t f, int k) -> uint32_t {   // bits below k reversed (bit p <- bit k - 1 - p), bits from k up in place
+        const uint32_t lo = f & czm_low(k);
+        return (k ? (czm_bitrev32(lo) >> (32 - k)) : 0u) | (f & ~czm_low(k));
     };
-    auto emit_asc = [&](uint32_t bits, int label0, int &n) {    // set bits from the lowest up
-        while (CZM_ANY(bits != 0u)) {
-            const bool c = bits != 0u;
-            const int i = c ? __builtin_ctz(bits) : 0;
-            put(n, label0 + i, c);
-            n += c ? 1 : 0;
-            bits &= bits - 1u;
-        }
+    auto order_nibbles = [](int k) -> uint32_t {            // nibble p = k - 1 - p below k, p from k up (k <= 8)
+        const uint32_t m = k >= 8 ? 0xFFFFFFFFu : ((1u << (4 * k)) - 1u);
+        return (0x76543210u & ~m) | (k ? (0x01234567u >> (4 * (8 - k))) : 0u);
+    };
+    auto slider = [&](int s) {    // -x, +x, -y, +y, each from the piece outwards
+        const int y = q[s] / 9, x = q[s] - y * 9, base = T.base[q[s]];
+        const uint32_t px = order_bits(pay[s] & 0xFFu, x), py = order_bits(pay[s] >> 8, y);
+        const uint32_t wx = order_nibbles(x), wy = y == 9 ? 0x12345678u : order_nibbles(y);
+        int n = off[s];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) cand(((px >> p) & 1u) != 0u, base + (int)((wx >> (4 * p)) & 15u), n);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) cand(((py >> p) & 1u) != 0u, base + 8 + (int)((wy >> (4 * p)) & 15u), n);
+        cand(((py >> 8) & 1u) != 0u, base + 8 + (y == 9 ? 0 : 8), n);
     };
     auto ortho = [&](int s, bool pawn) {
         const int y = q[s] / 9, x = q[s] - y * 9, base = T.base[q[s]];
         const uint32_t rkf = pay[s] & 0xFFu, flf = pay[s] >> 8;
         int n = off[s];
-        if (pawn) {   // forward, x + 1, x - 1
-            emit_asc(flf, base + 8, n);
-            emit_asc(rkf & ~czm_low(x), base, n);
-            emit_desc(rkf & czm_low(x), base, n);
-        } else {      // -x, +x, -y, +y, each from the piece outwards
-            emit_desc(rkf & czm_low(x), base, n);
-            emit_asc(rkf & ~czm_low(x), base, n);
-            emit_desc(flf & czm_low(y), base + 8, n);
-            emit_asc(flf & ~czm_low(y), base + 8, n);
+        if (pawn) {   // forward (the one bit of the file field), x + 1 (rank-field bit x), x - 1 (bit x - 1)
+            cand(flf != 0u, base + 8 + (flf ? czm_ctz32(flf) : 0), n);
+            cand(((rkf >> x) & 1u) != 0u, base + x, n);
+            cand(x > 0 && ((rkf >> (x > 0 ? x - 1 : 0)) & 1u) != 0u, base + x - 1, n);
+        } else {      // the king: x - 1, x + 1, y - 1, y + 1
+            cand(x > 0 && ((rkf >> (x > 0 ? x - 1 : 0)) & 1u) != 0u, base + x - 1, n);
+            cand(((rkf >> x) & 1u) != 0u, base + x, n);
+            cand(y > 0 && ((flf >> (y > 0 ? y - 1 : 0)) & 1u) != 0u, base + 8 + y - 1, n);
+            cand(((flf >> y) & 1u) != 0u, base + 8 + y, n);
         }
     };
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ortho(s, false);
+    for (int s = 0; s < 4; ++s) slider(s);
 #pragma unroll
     for (int s = 4; s < 6; ++s) {   // knights: (2i, j) then (i, 2j) for i, j in (-1, +1)^2 = vocabulary jumps 1, 0, 3, 4, 5, 2, 7, 6
         const uint32_t on = T.knon[q[s]];

@@ -198,7 +198,7 @@ __global__ void k_apply_move(CzTables tab, uint8_t *__restrict__ boards, uint8_t
 // `count` in the last piece are undefined) — the 0xFFFF padding is 2/3 of the list's 256 bytes (~40 moves per position), 65 LDS
 // stores per lane to make and 1.97x the kernel's algorithmic HBM traffic to write.
 template <bool MASK, bool PAD>
-__global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
+__global__ __launch_bounds__(64, MASK ? 2 : 3) void k_movegen_list(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
                                                      const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ moves,
                                                      uint16_t *__restrict__ count, uint32_t *__restrict__ mask) {
     __shared__ __attribute__((aligned(16))) uint32_t rows[64 * CZK_LROW + 4];
@@ -264,7 +264,11 @@ __global__ __launch_bounds__(64) void k_movegen_list(const CzmTables *__restrict
         uint32_t recs[CZM_EMITS];
         int ne = 0;   // compile-time after unrolling: the emits sit in straight-line code
         const int n = czm_list(w, sd, T,
-            [row16](int k, int label, bool c) { if (c) row16[k & 127] = (uint16_t)label; },
+            // an unwanted label goes to the row's padding word (u16 slot 128 of the 130): an unconditional store with a selected
+            // address is cheaper than a store under an exec mask (116 potential moves per position)
+            // (a position of a Xiangqi set has at most 120 moves — 2 x 17 rook, 2 x 17 cannon, 2 x 8 knight, 4 king, 5 x 3 pawn, 2 x 4
+            // advisor, 2 x 4 bishop, the flying general — and czm_list visits 16 fixed piece slots: k < 128 without a mask)
+            [row16](int k, int label, bool c) { row16[c ? k : 128] = (uint16_t)label; },
             [&](int i) -> uint32_t & { return rows[(i & 15) * 64 + lane]; },
             [&]() {   // the scratch has been read: fill the rows with the 0xFFFF padding of the ABI
                 CZK_WAVE_SYNC();
