@@ -453,7 +453,11 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, E
 // piece kind: the pieces are generated KIND BY KIND into 16 payload registers (the same fields as czm_position's), their counts
 // are summed in SQUARE order through 16 words of per-position scratch (a piece's rank = the number of own pieces below its
 // square), and then every piece writes its moves at its offset — label = the square's base + the index of the field bit.
-//   put(n, label, cond): the n-th move of the list is `label` (when cond);   scr(i): the i-th scratch word (i varies per lane);
+//   put(m, label, b): b = 1: `label` is move number n = 128 + m / 2 of the list — m = 2 (n - 128), the byte offset of the n-th 16-bit
+//     slot from slot CZM_IGNORE_SLOT = 128; b = 0: not a move.  A caller stores at byte offset b * m from slot 128 without a select or a
+//     branch (one multiply-add): slot 128 collects what is not a move (a position has at most 120).  put returns the next place,
+//     m + 2 b (its own instruction in the kernel: left to the compiler the running place becomes a count that is scaled per move);
+//   scr(i): the i-th of 17 scratch words (i varies per lane);
 //   mid(): called once between the last use of the scratch and the first put (a caller may keep both in the same memory);
 //   emit(bit, field): the position's SET as well — the same 15 pairs, in the same order, as czm_position hands out
 // Returns the number of moves, or -1 like czm_position.
@@ -462,10 +466,14 @@ CZM_FN int czm_position(const uint32_t (&w)[23], int side, const CzmTables &T, E
 #else
 #define CZM_ANY(c) (c)
 #endif
-CZM_FN int czm_rank_below(const CzmSet &own, int q) {   // own pieces on squares < q
-    const uint64_t ml = q >= 64 ? ~0ull : ((1ull << (q & 63)) - 1ull);
-    const uint32_t mh = q >= 64 ? ((1u << ((q - 64) & 31)) - 1u) : 0u;
-    return __builtin_popcountll(own.lo & ml) + __builtin_popcount(own.hi & mh);
+#define CZM_IGNORE_SLOT 128
+// own pieces on squares < q: the set as three words o0, o1, o2 with p1 = popcount(o0), p2 = p1 + popcount(o1) — the word of q, the
+// pieces in the words below it, one mask (16 calls per position: the two 64-bit masks of the straightforward form were 15 VALU each)
+CZM_FN int czm_rank_below(uint32_t o0, uint32_t o1, uint32_t o2, int p1, int p2, int q) {
+    const int wi = q >> 5;
+    const uint32_t word = wi == 0 ? o0 : (wi == 1 ? o1 : o2);
+    const int below = wi == 0 ? 0 : (wi == 1 ? p1 : p2);
+    return below + __builtin_popcount(word & ((1u << (q & 31)) - 1u));
 }
 template <typename Put, typename Scr, typename Mid, typename Emit>
 CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put put, Scr scr, Mid mid, Emit emit) {
@@ -535,31 +543,51 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
         emit(CZM_NLIT_BASE + 32, (uint32_t)(lits >> 32) & 0xFFFFu);
     }
     // the counts in square order: scratch word r collects the count of the piece of rank r (a missing piece adds 0 to word 0)
+    // (the pieces' ranks are distinct, so a piece WRITES its count — a piece without moves, or a missing one, writes word 16
+    // instead: 16 independent stores, then 16 loads, the sums in registers, 16 stores, 16 loads by rank; a read-modify-write per
+    // piece was 16 LDS round trips one after the other)
     int rk[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) scr(s) = 0u;
+    {
+        const uint32_t o0 = (uint32_t)S.own.lo, o1 = (uint32_t)(S.own.lo >> 32), o2 = S.own.hi;
+        const int p1 = __builtin_popcount(o0), p2 = p1 + __builtin_popcount(o1);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        rk[s] = czm_rank_below(S.own, q[s]) & 15;
-        scr(rk[s]) += (uint32_t)__builtin_popcount(pay[s]);
+        for (int s = 0; s < 16; ++s) {
+            const uint32_t c = (uint32_t)__builtin_popcount(pay[s]);
+            rk[s] = czm_rank_below(o0, o1, o2, p1, p2, q[s]) & 15;
+            scr(c ? rk[s] : 16) = c;
+        }
     }
-    int total = 0;
+    // From here on a place in the list is m = 2 * (n - CZM_IGNORE_SLOT): the byte offset of the n-th 16-bit slot from slot 128
+    // (negative; see put above) — the prefix sums are kept in that form
+    int mtot = -2 * CZM_IGNORE_SLOT;
+    {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const int t = (int)scr(r); scr(r) = (uint32_t)total; total += t; }
+        for (int h = 0; h < 16; h += 8) {   // eight words at a time: sixteen live values cost the list-only kernel its 168-register budget
+            uint32_t t[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = scr(h + r);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int c = (int)t[r]; t[r] = (uint32_t)mtot; mtot += 2 * c; }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) scr(h + r) = t[r];
+        }
+    }
     int off[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) off[s] = (int)scr(rk[s]);
     mid();
     // every piece writes its moves at its offset.  Round 6: no loops over set bits (a `while any lane has a bit left` loop ran as
     // long as the wave's richest position, ~140 iterations of ~12 instructions per group of 64 positions = 44 % of the list
-    // kernel): every CANDIDATE of a piece is visited once, in the reference's order, with put(n, label, is-it-a-move).  For a
+    // kernel): every CANDIDATE of a piece is visited once, in the reference's order, with put(m, label, is-it-a-move).  For a
     // rook / cannon the eight same-rank candidates in emission order are bit p of  perm = reverse(field below x) | field from x up
     // (p < x: file x - 1 - p, the -x ray from the piece outwards; p >= x: bit p, the +x ray), their label offsets the nibbles of a
     // word made from x alone; the nine same-file candidates likewise from y.
-    auto cand = [&](bool c, int label, int &n) { put(n, label, c); n += c ? 1 : 0; };
+    auto cand = [&](uint32_t b, int label, int &m) { m = put(m, label, b); };
     auto order_bits = [](uint32_t f, int k) -> uint32_t {   // bits below k reversed (bit p <- bit k - 1 - p), bits from k up in place
         const uint32_t lo = f & czm_low(k);
-        return (k ? (czm_bitrev32(lo) >> (32 - k)) : 0u) | (f & ~czm_low(k));
+        return (czm_bitrev32(lo) >> ((32 - k) & 31)) | (f & ~czm_low(k));   // k = 0: lo = 0
     };
     auto order_nibbles = [](int k) -> uint32_t {            // nibble p = k - 1 - p below k, p from k up (k <= 8)
         const uint32_t m = k >= 8 ? 0xFFFFFFFFu : ((1u << (4 * k)) - 1u);
@@ -569,26 +597,27 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
         const int y = q[s] / 9, x = q[s] - y * 9, base = T.base[q[s]];
         const uint32_t px = order_bits(pay[s] & 0xFFu, x), py = order_bits(pay[s] >> 8, y);
         const uint32_t wx = order_nibbles(x), wy = y == 9 ? 0x12345678u : order_nibbles(y);
-        int n = off[s];
+        int m = off[s];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) cand(((px >> p) & 1u) != 0u, base + (int)((wx >> (4 * p)) & 15u), n);
+        for (int p = 0; p < 8; ++p) cand((px >> p) & 1u, base + (int)((wx >> (4 * p)) & 15u), m);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) cand(((py >> p) & 1u) != 0u, base + 8 + (int)((wy >> (4 * p)) & 15u), n);
-        cand(((py >> 8) & 1u) != 0u, base + 8 + (y == 9 ? 0 : 8), n);
+        for (int p = 0; p < 8; ++p) cand((py >> p) & 1u, base + 8 + (int)((wy >> (4 * p)) & 15u), m);
+        cand((py >> 8) & 1u, base + 8 + (y == 9 ? 0 : 8), m);
     };
     auto ortho = [&](int s, bool pawn) {
         const int y = q[s] / 9, x = q[s] - y * 9, base = T.base[q[s]];
         const uint32_t rkf = pay[s] & 0xFFu, flf = pay[s] >> 8;
-        int n = off[s];
+        const uint32_t xm = ((rkf << 1) >> x) & 1u, xp = (rkf >> x) & 1u;   // field bit x - 1 (none at x = 0), field bit x
+        int m = off[s];
         if (pawn) {   // forward (the one bit of the file field), x + 1 (rank-field bit x), x - 1 (bit x - 1)
-            cand(flf != 0u, base + 8 + (flf ? czm_ctz32(flf) : 0), n);
-            cand(((rkf >> x) & 1u) != 0u, base + x, n);
-            cand(x > 0 && ((rkf >> (x > 0 ? x - 1 : 0)) & 1u) != 0u, base + x - 1, n);
+            cand(flf != 0u ? 1u : 0u, base + 8 + (flf ? czm_ctz32(flf) : 0), m);
+            cand(xp, base + x, m);
+            cand(xm, base + x - 1, m);
         } else {      // the king: x - 1, x + 1, y - 1, y + 1
-            cand(x > 0 && ((rkf >> (x > 0 ? x - 1 : 0)) & 1u) != 0u, base + x - 1, n);
-            cand(((rkf >> x) & 1u) != 0u, base + x, n);
-            cand(y > 0 && ((flf >> (y > 0 ? y - 1 : 0)) & 1u) != 0u, base + 8 + y - 1, n);
-            cand(((flf >> y) & 1u) != 0u, base + 8 + y, n);
+            cand(xm, base + x - 1, m);
+            cand(xp, base + x, m);
+            cand(((flf << 1) >> y) & 1u, base + 8 + y - 1, m);
+            cand((flf >> y) & 1u, base + 8 + y, m);
         }
     };
 #pragma unroll
@@ -597,13 +626,11 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
     for (int s = 4; s < 6; ++s) {   // knights: (2i, j) then (i, 2j) for i, j in (-1, +1)^2 = vocabulary jumps 1, 0, 3, 4, 5, 2, 7, 6
         const uint32_t on = T.knon[q[s]];
         const int base = T.base[q[s]] + 17;
-        int n = off[s];
+        int m = off[s];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             const int j = o == 0 ? 1 : o == 1 ? 0 : o == 2 ? 3 : o == 3 ? 4 : o == 4 ? 5 : o == 5 ? 2 : o == 6 ? 7 : 6;
-            const bool c = ((pay[s] >> j) & 1u) != 0u;
-            put(n, base + __builtin_popcount(on & czm_low(j)), c);
-            n += c ? 1 : 0;
+            cand((pay[s] >> j) & 1u, base + __builtin_popcount(on & czm_low(j)), m);
         }
     }
     ortho(6, false);
@@ -612,20 +639,17 @@ CZM_FN int czm_list(const uint32_t (&w)[23], int side, const CzmTables &T, Put p
 #pragma unroll
     for (int s = 12; s < 16; ++s) {
         const int kind = s >= 14 ? 1 : 0;
-        int n = off[s];
+        int m = off[s];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const uint32_t l = T.ab[kind][q[s] * 4 + d];
-            const bool g = ((pay[s] >> d) & 1u) != 0u;
-            err |= g & (l == 0xFFu);
-            put(n, CZM_NLIT_BASE + (int)(l & 63u), g);
-            n += g ? 1 : 0;
+            const uint32_t g = (pay[s] >> d) & 1u;
+            err |= (g != 0u) & (l == 0xFFu);
+            cand(g, CZM_NLIT_BASE + (int)(l & 63u), m);
         }
     }
-    {   // the flying general, last
-        const bool c = fg != 0u;
-        put(total, (int)T.base[kq >= 0 ? kq : 0] + (c ? __builtin_ctz(fg) : 0), c);
-        total += c ? 1 : 0;
-    }
+    // the flying general, last
+    cand(fg != 0u ? 1u : 0u, (int)T.base[kq >= 0 ? kq : 0] + (fg ? __builtin_ctz(fg) : 0), mtot);
+    const int total = (mtot >> 1) + CZM_IGNORE_SLOT;
     return err ? -1 : total;
 }

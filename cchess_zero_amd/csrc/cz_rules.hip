@@ -192,8 +192,8 @@ __global__ void k_apply_move(CzTables tab, uint8_t *__restrict__ boards, uint8_t
 // wave, staging rows, a segmented prefix sum, one LUT round trip and one LDS atomic per move) ran at 1.9 G positions/s.
 #define CZK_LROW 65   /* dwords per list row in LDS: 64 + 1 */
 // With mask != NULL the same launch writes the 2086-bit masks too: czm_list hands out the set's 15 (bit, field) pairs beside the
-// list (registers), and once the list rows have left the LDS holds 32 mask rows at a time, as in k_movegen_mask (here each
-// lane applies its own position's pairs while its half-wave has the rows).
+// list (registers), and once the list rows have left the same LDS holds the 64 mask rows (k_movegen_mask builds 32 at a time to
+// stay at 9.4 KB; here the list rows have set the footprint already): each lane applies its own position's pairs to its own row.
 // PAD = false (cz_movegen_ex, CZ_MOVES_NO_PAD; round 6): a row is written up to its count only (in 16-byte pieces: the labels behind
 // `count` in the last piece are undefined) — the 0xFFFF padding is 2/3 of the list's 256 bytes (~40 moves per position), 65 LDS
 // stores per lane to make and 1.97x the kernel's algorithmic HBM traffic to write.
@@ -201,7 +201,7 @@ template <bool MASK, bool PAD>
 __global__ __launch_bounds__(64, MASK ? 2 : 3) void k_movegen_list(const CzmTables *__restrict__ gtab, const uint8_t *__restrict__ boards,
                                                      const uint8_t *__restrict__ side, int G, uint16_t *__restrict__ moves,
                                                      uint16_t *__restrict__ count, uint32_t *__restrict__ mask) {
-    __shared__ __attribute__((aligned(16))) uint32_t rows[64 * CZK_LROW + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[64 * CZ_MASK_WORDS];   // >= 64 * CZK_LROW + 4
     __shared__ __attribute__((aligned(16))) CzmTables T;
     const int lane = threadIdx.x;
     if (lane < (int)(sizeof(CzmTables) / 16)) reinterpret_cast<uint4 *>(&T)[lane] = reinterpret_cast<const uint4 *>(gtab)[lane];
@@ -260,16 +260,22 @@ __global__ __launch_bounds__(64, MASK ? 2 : 3) void k_movegen_list(const CzmTabl
         }
         if (al16 && grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
         CZK_WAVE_SYNC();   // every lane holds its board: the bytes become scratch, then list rows
-        uint16_t *row16 = reinterpret_cast<uint16_t *>(rows) + lane * (2 * CZK_LROW);
+        const uint32_t slot128 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)rows + 2u * (lane * (2 * CZK_LROW) + CZM_IGNORE_SLOT);   // LDS byte address
         uint32_t recs[CZM_EMITS];
         int ne = 0;   // compile-time after unrolling: the emits sit in straight-line code
         const int n = czm_list(w, sd, T,
-            // an unwanted label goes to the row's padding word (u16 slot 128 of the 130): an unconditional store with a selected
-            // address is cheaper than a store under an exec mask (116 potential moves per position)
-            // (a position of a Xiangqi set has at most 120 moves — 2 x 17 rook, 2 x 17 cannon, 2 x 8 knight, 4 king, 5 x 3 pawn, 2 x 4
-            // advisor, 2 x 4 bishop, the flying general — and czm_list visits 16 fixed piece slots: k < 128 without a mask)
-            [row16](int k, int label, bool c) { row16[c ? k : 128] = (uint16_t)label; },
-            [&](int i) -> uint32_t & { return rows[(i & 15) * 64 + lane]; },
+            // what is not a move goes to the row's padding word (u16 slot 128 of the 130) — byte offset b * m from it, one v_mad_i32_i24:
+            // an unconditional store is cheaper than a store under an exec mask, the multiply-add cheaper than compare + select
+            // (120 candidates per position)
+            [slot128](int m, int label, uint32_t b) {
+                typedef __attribute__((address_space(3))) uint16_t lds_u16;
+                uint32_t at;   // (__mul24 leaves its 24-bit sign extension of m in the code: 2 more instructions per candidate)
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(at) : "v"(b), "v"(m), "v"(slot128));
+                *reinterpret_cast<lds_u16 *>(at) = (uint16_t)label;
+                asm("v_lshl_add_u32 %0, %1, 1, %0" : "+v"(m) : "v"(b));
+                return m;
+            },
+            [&](int i) -> uint32_t & { return rows[i * 64 + lane]; },   // 0 <= i <= 16
             [&]() {   // the scratch has been read: fill the rows with the 0xFFFF padding of the ABI
                 CZK_WAVE_SYNC();
                 if (PAD)
@@ -289,32 +295,28 @@ __global__ __launch_bounds__(64, MASK ? 2 : 3) void k_movegen_list(const CzmTabl
                 dst[idx] = make_uint4(src[0], src[1], src[2], src[3]);
             }
         }
-        if constexpr (MASK) {
+        if constexpr (MASK) {   // all 64 mask rows at once: 16 896 bytes, the same fourteen 1 280-byte LDS granules as the list rows
             const bool mal16 = (reinterpret_cast<uintptr_t>(mask) & 15u) == 0;
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                if (h * 32 >= np) break;
-                CZK_WAVE_SYNC();   // the list rows / the first half's mask rows have left
+            CZK_WAVE_SYNC();   // the list rows have left
+            static_assert(64 * CZ_MASK_WORDS / 4 == 16 * 64 + 32, "64 mask rows are 16 1/2 rounds of 16-byte pieces");
 #pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    if (lane + 64 * k < CZK_HALF_WORDS / 4) reinterpret_cast<uint4 *>(rows)[lane + 64 * k] = make_uint4(0, 0, 0, 0);
-                CZK_WAVE_SYNC();
-                if ((lane >> 5) == h) {
-                    uint32_t *row = rows + (lane & 31) * CZ_MASK_WORDS;
+            for (int k = 0; k < 16; ++k) reinterpret_cast<uint4 *>(rows)[lane + 64 * k] = make_uint4(0, 0, 0, 0);
+            if (lane < 32) reinterpret_cast<uint4 *>(rows)[lane + 1024] = make_uint4(0, 0, 0, 0);
+            CZK_WAVE_SYNC();
+            {
+                uint32_t *row = rows + lane * CZ_MASK_WORDS;   // the lane's own row: no other lane touches it
 #pragma unroll
-                    for (int k = 0; k < CZM_EMITS; ++k)
-                        czm_or_field([row](int wi, uint32_t x) { atomicOr(&row[wi], x); }, (int)(recs[k] & 0xFFFu), recs[k] >> 12);
-                }
-                CZK_WAVE_SYNC();
-                const int nph = min(32, np - h * 32);
-                uint32_t *dstm = mask + (size_t)(g0 + h * 32) * CZ_MASK_WORDS;
-                if (mal16 && nph == 32) {
+                for (int k = 0; k < CZM_EMITS; ++k)
+                    czm_or_field([row](int wi, uint32_t x) { atomicOr(&row[wi], x); }, (int)(recs[k] & 0xFFFu), recs[k] >> 12);
+            }
+            CZK_WAVE_SYNC();
+            uint32_t *dstm = mask + (size_t)g0 * CZ_MASK_WORDS;
+            if (mal16 && np == 64) {
 #pragma unroll
-                    for (int k = 0; k < 9; ++k)
-                        if (lane + 64 * k < CZK_HALF_WORDS / 4) reinterpret_cast<uint4 *>(dstm)[lane + 64 * k] = reinterpret_cast<const uint4 *>(rows)[lane + 64 * k];
-                } else {
-                    for (int i = lane; i < nph * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
-                }
+                for (int k = 0; k < 16; ++k) reinterpret_cast<uint4 *>(dstm)[lane + 64 * k] = reinterpret_cast<const uint4 *>(rows)[lane + 64 * k];
+                if (lane < 32) reinterpret_cast<uint4 *>(dstm)[lane + 1024] = reinterpret_cast<const uint4 *>(rows)[lane + 1024];
+            } else {
+                for (int i = lane; i < np * CZ_MASK_WORDS; i += 64) dstm[i] = rows[i];
             }
         }
     }

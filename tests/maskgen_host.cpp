@@ -36,12 +36,12 @@ extern "C" void czm_host_lists(const CzmTables *t, const uint8_t *boards, const 
         memcpy(w, buf, 92);
         uint16_t *row = moves + (size_t)i * 128;
         for (int k = 0; k < 128; ++k) row[k] = 0xFFFF;
-        uint32_t scratch[16], dummy[66];
+        uint32_t scratch[17], dummy[66];
         uint32_t *mrow = mask ? mask + (size_t)i * 66 : dummy;
         memset(mrow, 0, 66 * 4);
         int emits = 0;
-        count[i] = czm_list(w, side[i] ? 1 : 0, *t, [row](int k, int label, bool c) { if (c && k >= 0 && k < 128) row[k] = (uint16_t)label; },
-                            [&scratch](int k) -> uint32_t & { return scratch[k & 15]; }, [] {},
+        count[i] = czm_list(w, side[i] ? 1 : 0, *t, [row](int m, int label, uint32_t b) { const int k = CZM_IGNORE_SLOT + m / 2; if (b && (m & 1) == 0 && k >= 0 && k < 128) row[k] = (uint16_t)label; return m + 2 * (int)b; },
+                            [&scratch](int k) -> uint32_t & { return scratch[k]; }, [] {},
                             [mrow, &emits](int bit, uint32_t field) { ++emits; czm_or_field([mrow](int wi, uint32_t v) { if (wi < 66) mrow[wi] |= v; }, bit, field); });
         if (emits != CZM_EMITS) count[i] = -1000 - emits;
     }
