@@ -20,7 +20,7 @@ for d in ("a", "b", "f", "w"):
     for f in glob.glob(out + "/" + d + "/**/p_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            for key in ("k_movegen_mask", "k_movegen_list<true>", "k_movegen_list<false>", "k_hash"):
+            for key in ("k_movegen_mask", "k_movegen_list<true, true>", "k_movegen_list<true, false>", "k_movegen_list<false, true>", "k_movegen_list<false, false>", "k_hash"):
                 if key in k:
                     acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
