@@ -324,42 +324,67 @@ __global__ __launch_bounds__(64, MASK ? 2 : 3) void k_movegen_list(const CzmTabl
 
 // Zobrist key of a position (the oracle's cz_zhash): one lane = one position, as in k_movegen_mask — a wave stages
 // its 64 boards through LDS with 16-byte loads, every lane pulls its 90 bytes out as 23 dwords, and the 15 x 90 + 1 keys live
-// in LDS (10.8 KB, copied once per persistent wave): 90 ds_read_b64 per position instead of 90 dependent byte loads and 64-bit
-// gathers from global memory per thread (round 3: 1.1 G positions/s on 98 bytes per position).  Code 0's keys are zero, so
-// empty squares need no branch.
-__global__ __launch_bounds__(64) void k_hash(CzTables tab, const uint8_t *__restrict__ boards, const uint8_t *__restrict__ side, int G,
-                                             uint64_t *__restrict__ hash) {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[64 * CZ_NSQ / 4 + 4];
+// in LDS: 90 ds_read_b64 per position instead of 90 dependent byte loads and 64-bit gathers from global memory per thread
+// (round 3: 1.1 G positions/s on 98 bytes per position).  Code 0's keys are zero, so empty squares need no branch.
+// Round 6: the 11.5 KB key table is shared by the FOUR waves of a workgroup (one table per wave had left 9 waves per CU, and SQ
+// counters showed 69 % of a wave's life parked in s_waitcnt: profiles/r05p_pmc_sq_rules.txt) — 34.6 KB per workgroup, 16 waves
+// per CU — and a wave requests its NEXT group's boards into registers before it hashes the current one, as the move generators do.
+#define CZK_HASH_WAVES 4
+__global__ __launch_bounds__(64 * CZK_HASH_WAVES) void k_hash(CzTables tab, const uint8_t *__restrict__ boards, const uint8_t *__restrict__ side, int G,
+                                                              uint64_t *__restrict__ hash) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[CZK_HASH_WAVES][64 * CZ_NSQ / 4 + 4];
     __shared__ uint64_t Z[16 * CZ_NSQ];   // 15 x 90 keys + the side key at [15 * 90]; the rest of row 15 is zero: a byte above 14 (not a piece code) hashes as an empty square instead of reading past the table
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 16 * CZ_NSQ; i += 64) Z[i] = i <= 15 * CZ_NSQ ? tab.zob[i] : 0ull;
-    const int ngroups = (G + 63) >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *stage = stage_all[wv];
+    for (int i = threadIdx.x; i < 16 * CZ_NSQ; i += 64 * CZK_HASH_WAVES) Z[i] = i <= 15 * CZ_NSQ ? tab.zob[i] : 0ull;
+    __syncthreads();   // the only workgroup-wide one: from here on every wave walks its own groups
+    const int ngroups = (G + 63) >> 6, nwaves = gridDim.x * CZK_HASH_WAVES, w0 = blockIdx.x * CZK_HASH_WAVES + wv;
     const bool al16 = (reinterpret_cast<uintptr_t>(boards) & 15u) == 0;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    uint4 pre[6];
+    int presd = 0;
+    auto prefetch = [&](int grp) {
         const int g0 = grp * 64, np = min(64, G - g0), nbytes = np * CZ_NSQ;
         const uint8_t *src = boards + (size_t)g0 * CZ_NSQ;
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = lane + 64 * k;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i * 16 + 16 <= nbytes) v = reinterpret_cast<const uint4 *>(src)[i];
+            pre[k] = v;
+        }
+        presd = (lane < np && side[g0 + lane]) ? 1 : 0;
+    };
+    if (al16 && w0 < ngroups) prefetch(w0);
+    for (int grp = w0; grp < ngroups; grp += nwaves) {
+        const int g0 = grp * 64, np = min(64, G - g0), nbytes = np * CZ_NSQ;
+        const uint8_t *src = boards + (size_t)g0 * CZ_NSQ;
+        CZK_WAVE_SYNC();   // the previous group's bytes have been read
+        int sd;
         if (al16) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int i = lane + 64 * k;
-                if (i * 16 + 16 <= nbytes) reinterpret_cast<uint4 *>(stage)[i] = reinterpret_cast<const uint4 *>(src)[i];
-            }
+            for (int k = 0; k < 6; ++k)
+                if (lane + 64 * k < 64 * CZ_NSQ / 16) reinterpret_cast<uint4 *>(stage)[lane + 64 * k] = pre[k];
             const int full = nbytes & ~15;   // the ragged piece of a batch's last group byte by byte, never past the batch
-            if (lane < nbytes - full) reinterpret_cast<uint8_t *>(stage)[full + lane] = src[full + lane];
+            if (np < 64 && lane < nbytes - full) reinterpret_cast<uint8_t *>(stage)[full + lane] = src[full + lane];
+            sd = presd;
         } else {
             for (int i = lane; i < nbytes; i += 64) reinterpret_cast<uint8_t *>(stage)[i] = src[i];
+            sd = (lane < np && side[g0 + lane]) ? 1 : 0;
         }
-        __syncthreads();
+        CZK_WAVE_SYNC();
+        uint32_t d[24];
+        {
+            const int b0 = (CZ_NSQ * lane) >> 2;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) d[k] = stage[b0 + k];
+        }
+        if (al16 && grp + nwaves < ngroups) prefetch(grp + nwaves);   // in flight while this group is hashed
         if (lane < np) {
-            const int b0 = (CZ_NSQ * lane) >> 2, sh = (lane & 1) * 16;
-            uint64_t h = side[g0 + lane] ? Z[15 * CZ_NSQ] : 0ull;
-            uint32_t lo = stage[b0];
+            const uint32_t sh = (lane & 1) * 16;
+            uint64_t h = sd ? Z[15 * CZ_NSQ] : 0ull;
 #pragma unroll
             for (int k = 0; k < 23; ++k) {
-                const uint32_t hi = stage[b0 + k + 1];
-                const uint32_t w = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
-                lo = hi;
+                const uint32_t w = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int q = 4 * k + j;
@@ -416,8 +441,8 @@ int czk_apply_move(cz_ctx *c, uint8_t *boards, uint8_t *side, const uint16_t *la
 
 int czk_hash(cz_ctx *c, const uint8_t *boards, const uint8_t *side, int G, uint64_t *hash) {
     if (G == 0) return CZ_OK;
-    { const int ngroups = (G + 63) / 64, chip = 256 * 9;   // 16.6 KB of LDS per wave: 9 persistent waves per CU
-      hipLaunchKernelGGL(k_hash, dim3(ngroups < chip ? ngroups : chip), dim3(64), 0, c->stream, c->tab, boards, side, G, hash); }
+    { const int ngroups = (G + 63) / 64, wgs = (ngroups + CZK_HASH_WAVES - 1) / CZK_HASH_WAVES, chip = 256 * 4;   // 34.6 KB of LDS per workgroup of four waves: 4 persistent workgroups per CU
+      hipLaunchKernelGGL(k_hash, dim3(wgs < chip ? wgs : chip), dim3(64 * CZK_HASH_WAVES), 0, c->stream, c->tab, boards, side, G, hash); }
     CZ_HIP(hipGetLastError());
     return CZ_OK;
 }
