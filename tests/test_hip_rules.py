@@ -38,6 +38,34 @@ def test_movegen_golden(rules, rules_golden):
     assert nomask is None and np.array_equal(_u16(count3), g["counts"])
 
 
+def test_movegen_open_boards_with_up_to_100_moves(rules):
+    """Sparse synthetic boards (tests/conftest.py::open_boards, 33-100+ moves per position: twice what playouts from the start
+    position reach) through all four instantiations of k_movegen_list and through k_movegen_mask, against the C oracle: the long
+    end of the 128-slot rows, where a list slot is addressed from the ignore slot at 128."""
+    from conftest import open_boards
+    from oracle import oracle as O
+    boards, side = open_boards(900, 12)
+    want = [np.asarray(O.legal_moves(boards[i], int(side[i])), np.uint16) for i in range(len(boards))]
+    n = np.array([len(w) for w in want])
+    assert n.max() >= 95 and n.mean() > 55
+    exp_mask = np.zeros((len(boards), 66), np.uint32)
+    for i, w in enumerate(want):
+        np.bitwise_or.at(exp_mask[i], w.astype(np.int64) >> 5, np.uint32(1) << (w.astype(np.uint32) & np.uint32(31)))
+    for want_mask in (True, False):
+        for pad in (True, False):
+            mv, cnt, m = rules.movegen(boards, side, want_mask=want_mask, pad=pad)
+            mv, cnt = _u16(mv), _u16(cnt)
+            assert np.array_equal(cnt, n)
+            for i, w in enumerate(want):
+                assert np.array_equal(mv[i, :len(w)], w), (i, pad, want_mask)
+                if pad:
+                    assert (mv[i, len(w):] == 0xFFFF).all()
+            if want_mask:
+                assert np.array_equal(m.cpu().numpy().view(np.uint32), exp_mask)
+    _, cnt, m = rules.movegen(boards, side, want_moves=False)
+    assert np.array_equal(_u16(cnt), n) and np.array_equal(m.cpu().numpy().view(np.uint32), exp_mask)
+
+
 def test_movegen_golden_no_pad(rules, rules_golden):
     """CZ_MOVES_NO_PAD (cz_movegen_ex): the same 4 381 reference lists, counts and masks with rows written
     up to their count only.  The buffer is pre-filled with a sentinel: a row holds the golden labels up to its count, the

@@ -118,6 +118,23 @@ def test_listgen_matches_oracle_on_random_playouts(host):
         assert np.array_equal(host.lists.last_mask[i], _mask_of(want[i])), i
 
 
+def test_list_and_mask_on_open_boards_with_up_to_100_moves(host):
+    """Sparse synthetic boards (tests/conftest.py::open_boards): lists of 33-100+ moves, twice what playouts from the start position
+    reach — the long end of the 128-slot rows, where the list's slots are addressed from the ignore slot at 128."""
+    from conftest import open_boards
+    from oracle import oracle as O
+    boards, side = open_boards(600, 11)
+    want = [O.legal_moves(boards[i], int(side[i])) for i in range(len(boards))]
+    assert max(len(w) for w in want) >= 95 and np.mean([len(w) for w in want]) > 55
+    mv, c = host.lists(boards, side)
+    m, c2 = host(boards, side)
+    for i in range(len(boards)):
+        assert c[i] == len(want[i]) == c2[i], i
+        assert np.array_equal(mv[i, :c[i]], np.asarray(want[i], np.uint16)), (i, mv[i, :c[i]], want[i])
+        assert (mv[i, c[i]:] == 0xFFFF).all()
+        assert np.array_equal(m[i], _mask_of(want[i])) and np.array_equal(host.lists.last_mask[i], m[i]), i
+
+
 def test_boards_with_more_of_a_kind_than_a_set_holds_are_errors(host):
     """the one-lane-per-position generators take a kind's squares as the lowest and highest of its set (pawns: five
     iterations) — a third rook / cannon / knight / advisor / bishop, a sixth pawn or a second king of the side to move would
