@@ -185,12 +185,13 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
     abi = (90 + 1 + 264 + 2) * float(n)
     abi_list = (90 + 1 + 256 + 264 + 2) * float(n)
     # counter traffic of the same launch shapes (tools/pmc_rules.sh -> profiles/pmc_rules_traffic.json), attached when the size matches
-    tr_mask, tr_list, tr_src = None, None, "no committed PMC measurement at %d positions" % n
+    tr_mask, tr_list, tr_nopad, tr_src = None, None, None, "no committed PMC measurement at %d positions" % n
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_rules_traffic.json")))
         if int(tj.get("positions", -1)) == n:
             tr_mask = tj["kernels"]["k_movegen_mask"]["traffic_bytes_per_launch"]
-            tr_list = tj["kernels"]["k_movegen_list<true>"]["traffic_bytes_per_launch"]
+            tr_list = tj["kernels"]["k_movegen_list<true, true>"]["traffic_bytes_per_launch"]
+            tr_nopad = tj["kernels"]["k_movegen_list<true, false>"]["traffic_bytes_per_launch"]
             tr_src = "profiles/pmc_rules_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
     except (OSError, ValueError, KeyError) as e:
         tr_src = "profiles/pmc_rules_traffic.json unusable: %r" % (e,)
@@ -200,12 +201,13 @@ def rules_roofline(rules, boards, side, n=1 << 20, reps=10):
             "abi_bytes_per_position": abi / n, "abi_GBps": abi / sec / 1e9,
             "ordered_list_kernel": {"kernel": "k_movegen_list<MASK, no pad> (ordered move list in the reference's generation order, rows written up to their count — cz_movegen_ex CZ_MOVES_NO_PAD —, and the mask from one launch: one position per lane)",
                                     "positions_per_s": n / sec_list, "us_per_launch": sec_list * 1e6, "achieved": alg / sec_list / 1e9,
-                                    "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "traffic": None, "mean_moves_per_position": mean_moves,
+                                    "frac": alg / sec_list / 1e9 / HBM_PEAK_GBS, "traffic": tr_nopad, "mean_moves_per_position": mean_moves,
                                     "abi_bytes_per_position": 90 + 1 + 264 + 2 + 16.0 * ((mean_moves + 7) // 8 + 0.5),
+                                    "abi_GBps": (90 + 1 + 264 + 2 + 16.0 * ((mean_moves + 7) // 8 + 0.5)) * n / sec_list / 1e9,
                                     "padded": {"kernel": "k_movegen_list<MASK, pad> (cz_movegen: 0xFFFF padding to 128 labels)", "positions_per_s": n / sec_list_pad,
                                                "us_per_launch": sec_list_pad * 1e6, "frac": alg / sec_list_pad / 1e9 / HBM_PEAK_GBS, "traffic": tr_list,
                                                "abi_bytes_per_position": abi_list / n, "abi_GBps": abi_list / sec_list_pad / 1e9},
-                                    "note": "issue-bound (VALU: the per-kind generation, the ordering by square, one LDS write per move), not bandwidth-bound: see DESIGN.md 4.5"}}
+                                    "note": "issue-bound (VALU: the per-kind generation, 120 candidates per position visited once each in the reference's order), not bandwidth-bound: see DESIGN.md 4.5"}}
 
 
 def _pick(d, keys):
