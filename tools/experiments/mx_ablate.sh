@@ -2,6 +2,8 @@
 # Builds timing-ablation variants of the library (here, no GPU): tools/ab/lib_mx_<name>.so with MX_ABLATE=<flags> in the generated
 # slab bodies of k_trunk_mx_c128.  Results of the variants are WRONG on purpose; only their launch time means anything.
 #   usage: tools/experiments/mx_ablate.sh name=flag,flag ...      e.g.  nobarrier=nobarrier noc=noc dmaBC=place2:BC noxch=define:MX2_ABLATE_NO_EXCHANGE
+#   (the experiments' slab bodies cz_trunk_mx2_asm.inc / cz_trunk_mx12_asm.inc are generated: tools/gen_tower_asm.py writes them next to
+#   the sources it is given — here the temporary copy — and they are not kept in git)
 #   mx2 / mx2:<DEFINE>: a library that also holds the round-6 experiment k_trunk_mx2_c128 (tools/experiments/cz_trunk_mx2.h; run with
 #   CCHESS_MX_KERNEL=2), e.g.  mx2=mx2  timing=mx2:MX2_TIMING  noxch=mx2:MX2_ABLATE_NO_EXCHANGE
 # On the GPU box:  for l in tools/ab/lib_mx_*.so; do CCHESS_HIP_LIB=$(realpath $l) python tools/mx_check.py --blocks "" --time --engines mx; done
