@@ -6,6 +6,6 @@ for r in 1 2 3; do
   for l in tree tools/ab/lib_rules_*.so; do
     if [ $l = tree ]; then unset CCHESS_HIP_LIB; else export CCHESS_HIP_LIB=$(realpath $l); fi
     echo "== round $r: $l" | tee -a $OUT
-    timeout 300 python tools/rules_bench.py 2>&1 | grep -E "K1 movegen|Zobrist" | tee -a $OUT
+    timeout 300 python tools/rules_bench.py 2>&1 | grep -E "K1 movegen|Zobrist|K3 planes|K2 apply" | tee -a $OUT
   done
 done
