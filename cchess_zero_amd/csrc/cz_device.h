@@ -393,13 +393,15 @@ template <typename T>
 __device__ __forceinline__ void czd_wave_encode_planes(const uint8_t *b, int side, int quirk_q1, T *out,
                                                        int C, T one, int lane) {
     if (C == 16 && sizeof(T) == 2) {
-        // the fused net kernel's input format: 16 two-byte channels = 32 bytes per cell, one lane per cell, the one-hot
-        // built in registers and written as two 16-byte stores (the generic loop below spends ~25 operations per element)
+        // the fused net kernel's input format: 16 two-byte channels = 32 bytes per cell = two 16-byte pieces; lane l writes pieces
+        // l, l + 64, l + 128 of the position's 180, so every store instruction covers a contiguous kilobyte (one lane per CELL
+        // with two stores each left every instruction writing alternate halves of its 128-byte lines: K3 ran at 3.0 TB/s of a
+        // measured 6.8 TB/s store ceiling, tools/hbm_ceiling.py)
         uint4 *o4 = reinterpret_cast<uint4 *>(out);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int cell = lane + 64 * r;
-            if (cell < 90) {
+        for (int r = 0; r < 3; ++r) {
+            const int piece = lane + 64 * r, cell = piece >> 1, half = piece & 1;
+            if (piece < 180) {
                 int src;
                 if (quirk_q1) { const int h = cell / 10, w = cell - h * 10; src = h * 9 + w; }
                 else { const int xx = cell / 10, yy = cell - xx * 10; src = yy * 9 + xx; }
@@ -413,14 +415,10 @@ __device__ __forceinline__ void czd_wave_encode_planes(const uint8_t *b, int sid
                 }
                 const int idx = code - 1;   // channel of the 1, or -1
                 const unsigned v = (unsigned)(unsigned short)one << ((idx & 1) * 16);
-                uint4 lo4 = make_uint4(0, 0, 0, 0), hi4 = make_uint4(0, 0, 0, 0);
-                const int wd = idx >> 1;    // 32-bit word 0..6 of the cell's 8
-                if (idx >= 0) {
-                    lo4.x = wd == 0 ? v : 0u; lo4.y = wd == 1 ? v : 0u; lo4.z = wd == 2 ? v : 0u; lo4.w = wd == 3 ? v : 0u;
-                    hi4.x = wd == 4 ? v : 0u; hi4.y = wd == 5 ? v : 0u; hi4.z = wd == 6 ? v : 0u;
-                }
-                o4[cell * 2] = lo4;
-                o4[cell * 2 + 1] = hi4;
+                const int wd = (idx >> 1) - 4 * half;    // 32-bit word 0..3 of this piece, or outside it
+                uint4 o = make_uint4(0, 0, 0, 0);
+                if (idx >= 0) { o.x = wd == 0 ? v : 0u; o.y = wd == 1 ? v : 0u; o.z = wd == 2 ? v : 0u; o.w = wd == 3 ? v : 0u; }
+                o4[piece] = o;
             }
         }
         return;

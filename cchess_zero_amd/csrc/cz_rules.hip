@@ -7,18 +7,6 @@
 
 namespace {
 
-__device__ __forceinline__ void load_board(const uint8_t *__restrict__ g, uint8_t *lds, int lane) {
-    // 90 bytes: lanes 0..44 move 2 bytes each (boards are only byte-aligned in the ABI)
-    if (lane < 45) {
-        lds[2 * lane] = g[2 * lane];
-        lds[2 * lane + 1] = g[2 * lane + 1];
-    } else if (lane < 48) {
-        lds[2 * lane] = 0;
-        lds[2 * lane + 1] = 0;
-    }
-    __syncthreads();
-}
-
 // K1m: the legal-move MASK (and count) without the ordered list — cz_movegen(moves = NULL).  One lane = one position; the rules
 // are cz_maskgen.h's czm_position (register bit sets, no list, no LUT, no divergence on the piece kind).  A wave stages its 64
 // boards (5 760 contiguous bytes) into LDS with coalesced 16-byte loads, every lane pulls its own 90 bytes out as 23 dwords
@@ -396,15 +384,28 @@ __global__ __launch_bounds__(64 * CZK_HASH_WAVES) void k_hash(CzTables tab, cons
     }
 }
 
+// K3: one wave per position, walking its positions with a stride.  The next board (two bytes per lane) and side byte are requested
+// before the current planes are written, and between positions only the LDS counter drains (CZK_WAVE_SYNC), so a position's
+// 2.9 KB of stores are not waited for before the next board is asked for.
 template <typename T>
 __global__ __launch_bounds__(64) void k_encode_planes(const uint8_t *__restrict__ boards, const uint8_t *__restrict__ side,
                                                       int G, T *__restrict__ planes, int C, int quirk, T one) {
     __shared__ __attribute__((aligned(16))) uint8_t b[CZD_BOARD_LDS];
     const int lane = threadIdx.x;
+    uint8_t p0 = 0, p1 = 0, psd = 0;
+    auto prefetch = [&](int g) {
+        const uint8_t *src = boards + (size_t)g * CZ_NSQ;
+        if (lane < 45) { p0 = src[2 * lane]; p1 = src[2 * lane + 1]; }
+        psd = side[g];
+    };
+    if ((int)blockIdx.x < G) prefetch(blockIdx.x);
     for (int g = blockIdx.x; g < G; g += gridDim.x) {
-        load_board(boards + (size_t)g * CZ_NSQ, b, lane);
-        czd_wave_encode_planes<T>(b, side[g] ? 1 : 0, quirk, planes + (size_t)g * 90 * C, C, one, lane);
-        __syncthreads();
+        CZK_WAVE_SYNC();   // the previous board has been read
+        if (lane < 48) { b[2 * lane] = lane < 45 ? p0 : (uint8_t)0; b[2 * lane + 1] = lane < 45 ? p1 : (uint8_t)0; }
+        const int sd = psd ? 1 : 0;
+        if (g + (int)gridDim.x < G) prefetch(g + gridDim.x);   // in flight while this position's planes leave
+        CZK_WAVE_SYNC();
+        czd_wave_encode_planes<T>(b, sd, quirk, planes + (size_t)g * 90 * C, C, one, lane);
     }
 }
 
